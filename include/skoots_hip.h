@@ -1,0 +1,153 @@
+/* skoots_hip.h -- C ABI of libskoots_hip.so (MI355X / gfx950).
+ *
+ * The reference (buswinka/skoots) has no FFI: its hot path sits behind the Python
+ * function skoots.lib.eval.eval() and the library functions it calls.  Each entry
+ * point below names the reference code it replaces (file:line, relative to the
+ * reference tree).  The Python host mirror of the reference interface lives in
+ * skoots_amd/lib/ and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - volumes are C-contiguous (X, Y, Z) with Z fastest, exactly the reference's
+ *     (C, X, Y, Z) tensors per channel;
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered, no
+ *     entry point synchronises unless its comment says so;
+ *   - no entry point allocates device memory: callers pass workspaces;
+ *   - return value: SK_OK, or a negative code; sk_last_error() gives the text.
+ */
+#ifndef SKOOTS_HIP_H
+#define SKOOTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SK_OK 0
+#define SK_ERR_ARG (-1)
+#define SK_ERR_HIP (-2)
+#define SK_ERR_CAPACITY (-3)
+
+#define SK_F16 0
+#define SK_F32 1
+#define SK_I16 2
+#define SK_I32 3
+#define SK_U8 4
+
+const char* sk_last_error(void);
+int sk_abi_version(void);
+
+/* ------------------------------------------------------------------------ *
+ * Stage 3: offset following + label assignment
+ * ------------------------------------------------------------------------ */
+
+/* Planar (3, X, Y, Z) fp16 vectors -> interleaved (X, Y, Z, 4) fp16 (4th lane 0).
+ * Internal staging layout for the follow kernel: one 8-byte load per hop instead
+ * of three cache lines.  No reference counterpart (layout choice). */
+int sk_vec_interleave(const void* vec_planar, void* vec4, int64_t nvox, void* stream);
+
+/* Inverse of sk_vec_interleave: (X,Y,Z,4) fp16 -> planar (3,X,Y,Z) fp16, the layout of
+ * the reference's `vectors` zarr array (skoots/lib/eval.py:103). */
+int sk_vec_deinterleave(const void* vec4, void* vec_planar, int64_t nvox, void* stream);
+
+/* skoots.lib.vector_to_embedding.vector_to_embedding (vector_to_embedding.py:79-174)
+ * on one crop: vec (3, w, h, d) planar, fp16 or fp32 (vec_dtype SK_F16/SK_F32);
+ * embed (3, w, h, d) fp32.  step_scale_host[(n)*3]: row 0 = float(scale), row i>=1 =
+ * float(decay^i) * float(scale) (fp32 product), prepared by the host mirror. */
+int sk_vector_to_embedding(const void* vec, int vec_dtype, float* embed, int w, int h, int d,
+                           const float* step_scale_host, int n_iter, void* stream);
+
+/* skoots.lib.skeleton.index_skeleton_by_embed (skeleton.py:656-695):
+ * out[i] = labels[round/clamp(embed[:, i])]; labels (LX, LY, LZ) int16 or int32,
+ * embed (3, n) fp32, out (n) int32. */
+int sk_index_skeleton_by_embed(const void* labels, int label_dtype, int lx, int ly, int lz,
+                               const float* embed, int64_t n, int32_t* out, void* stream);
+
+/* Fused stage 3 (eval.py:245-284): for every voxel of the (X,Y,Z) volume, find the
+ * stage-3 crop that writes it last (owner tables built by the host from the
+ * reference's crop generator, cropper.py:97-144), run the N-step follow inside that
+ * crop's window with the reference's arithmetic, add the crop origin, gather the
+ * label.  vec4: (X,Y,Z,4) fp16.  owner_{x,y,z}: int32[X|Y|Z] crop origin owning each
+ * coordinate or -1 (voxel stays 0).  eff_*: effective crop size.  Only planes
+ * [z_lo, z_hi) are written (Z-sharding); vec4/labels/out are full-volume pointers.
+ * labels int16|int32 (X,Y,Z); out int32 (X,Y,Z). */
+int sk_follow_assign(const void* vec4, const void* labels, int label_dtype, int32_t* out,
+                     int X, int Y, int Z, const int32_t* owner_x, const int32_t* owner_y,
+                     const int32_t* owner_z, int eff_w, int eff_h, int eff_d,
+                     const float* step_scale_host, int n_iter, int z_lo, int z_hi, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Stage 1 tail: gate + dilate + threshold + interior scatter
+ * ------------------------------------------------------------------------ */
+
+/* eval.py:145-176 for one tile.  out5: network output of the tile, (5, w, h, d)
+ * planar, fp16 or fp32 (thresholds follow torch's scalar casting for that dtype).
+ * Writes the tile interior [ov, size-ov) into the volume arrays at origin+ov:
+ * vec4 (X,Y,Z,4) fp16 and/or vec_planar (3,X,Y,Z) fp16 (either may be NULL),
+ * skeleton (X,Y,Z) uint8 in {0,1}.  Dilation = 3x3x3 max then 3x3x1 max twice,
+ * zero padded at the tile faces (morphology.py:155-199). */
+int sk_gate_dilate_scatter(const void* out5, int out_dtype, int w, int h, int d,
+                           int ox, int oy, int oz, int ovx, int ovy, int ovz,
+                           void* vec4, void* vec_planar, uint8_t* skeleton,
+                           int X, int Y, int Z, float prob_thr, float skel_thr, void* stream);
+
+/* skoots.lib.morphology.binary_dilation / binary_dilation_2d (morphology.py:155-199)
+ * as library functions on a (w,h,d) fp32 map: max over a (2rx+1,2ry+1,2rz+1) window,
+ * zero padded. */
+int sk_max_filter3d(const float* in, float* out, int w, int h, int d, int rx, int ry, int rz,
+                    void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Stage 2: skeleton labelling (skoots.lib.flood_fill.efficient_flood_fill,
+ * flood_fill.py:13-122)
+ * ------------------------------------------------------------------------ */
+
+/* Bytes of workspace sk_ccl_crop needs for a crop of n voxels. */
+size_t sk_ccl_workspace_bytes(int64_t crop_voxels);
+
+/* flood_all (flood_fill.py:125-140) for one crop of the flood grid: 6-connected
+ * labelling of src>0 inside the box [x0,x0+w) x [y0,y0+h) x [z0,z0+d) of the
+ * (X,Y,Z) uint8 volume; components are numbered in raster order of their first
+ * voxel (scipy.ndimage.label order) starting at state[0]+2, written to the int32
+ * labels volume (same box).  state (device int32[4]): [0] running max id (init 1,
+ * becomes 0 after an empty crop, exactly as the reference), [1] components in this
+ * crop, [2] total components so far, [3] scratch. */
+int sk_ccl_crop(const uint8_t* src, int32_t* labels, int X, int Y, int Z,
+                int x0, int y0, int z0, int w, int h, int d,
+                void* workspace, size_t workspace_bytes, int32_t* state, void* stream);
+
+/* Seam scan (replaces get_adjacent_labels, flood_fill.py:237-261, with true
+ * adjacency): for plane `v` of `axis` (0=x,1=y,2=z) emit the pairs
+ * (labels[plane v], labels[plane v-1]) of face-adjacent nonzero voxels into
+ * pairs (int32[2*capacity]); *count (device int32) is advanced atomically.
+ * Duplicates are possible; the host sorts and uniques. */
+int sk_seam_pairs(const int32_t* labels, int X, int Y, int Z, int axis, int v,
+                  int32_t* pairs, int32_t* count, int capacity, void* stream);
+
+/* HOST function (no GPU work): collision graph + depth-first components + "last id
+ * represents the component" (flood_fill.py:82-105).  pairs_host: n pairs in the
+ * reference's emission order.  Writes up to capacity (to_replace, replace_with)
+ * entries; returns the number written or a negative code. */
+int sk_seam_components_host(const int32_t* pairs_host, int n_pairs, int32_t* to_replace_host,
+                            int32_t* replace_with_host, int capacity);
+
+/* labels[i] = lut[labels[i]] for 0 <= labels[i] < lut_size (in place; flood_fill.py:177-234). */
+int sk_relabel_lut(int32_t* labels, int64_t n, const int32_t* lut, int lut_size, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Renumber (fastremap.renumber call, eval.py:304-306)
+ * ------------------------------------------------------------------------ */
+
+size_t sk_renumber_workspace_bytes(int64_t n, int max_label);
+
+/* Relabel to 1..K by first appearance in C order, 0 preserved, in place.
+ * labels int32 (n), values in [0, max_label].  *n_labels (device int32) = K. */
+int sk_renumber(int32_t* labels, int64_t n, int max_label, void* workspace,
+                size_t workspace_bytes, int32_t* n_labels, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKOOTS_HIP_H */

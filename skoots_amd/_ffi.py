@@ -1,0 +1,122 @@
+"""ctypes binding of libskoots_hip.so (C ABI: include/skoots_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C skoots_amd/csrc``.  Loading fails loudly if it is absent: the product
+has no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libskoots_hip.so")
+
+SK_F16, SK_F32, SK_I16, SK_I32, SK_U8 = 0, 1, 2, 3, 4
+
+_DTYPE_CODE = {torch.float16: SK_F16, torch.float32: SK_F32, torch.int16: SK_I16,
+               torch.int32: SK_I32, torch.uint8: SK_U8}
+
+
+class SkootsHipError(RuntimeError):
+    pass
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP library first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C skoots_amd/csrc). "
+            "skoots_amd has no CPU fallback.")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int32)
+
+
+class ConvSrc(C.Structure):
+    _fields_ = [("data", vp), ("affine", vp), ("c", i32), ("upsample", i32)]
+
+
+_SIGS = {
+    "sk_last_error": (C.c_char_p, []),
+    "sk_abi_version": (i32, []),
+    "sk_vec_interleave": (i32, [vp, vp, i64, vp]),
+    "sk_vec_deinterleave": (i32, [vp, vp, i64, vp]),
+    "sk_vector_to_embedding": (i32, [vp, i32, vp, i32, i32, i32, fp, i32, vp]),
+    "sk_index_skeleton_by_embed": (i32, [vp, i32, i32, i32, i32, vp, i64, vp, vp]),
+    "sk_follow_assign": (i32, [vp, vp, i32, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, fp, i32,
+                               i32, i32, vp]),
+    "sk_gate_dilate_scatter": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp,
+                                     i32, i32, i32, f32, f32, vp]),
+    "sk_max_filter3d": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "sk_ccl_workspace_bytes": (sz, [i64]),
+    "sk_ccl_crop": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
+    "sk_seam_pairs": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]),
+    "sk_seam_components_host": (i32, [ip, i32, ip, ip, i32]),
+    "sk_relabel_lut": (i32, [vp, i64, vp, i32, vp]),
+    "sk_renumber_workspace_bytes": (sz, [i64, i32]),
+    "sk_renumber": (i32, [vp, i64, i32, vp, sz, vp, vp]),
+}
+
+EXPORTS = tuple(_SIGS)
+_missing = []
+for _name, (_res, _args) in _SIGS.items():
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError:
+        _missing.append(_name)
+        continue
+    _fn.restype = _res
+    _fn.argtypes = _args
+if _missing:
+    raise ImportError(f"{LIB_PATH} lacks symbols declared in include/skoots_hip.h: {_missing}")
+
+
+def last_error() -> str:
+    return lib.sk_last_error().decode()
+
+
+def check(rc: int) -> None:
+    """Map the C status convention onto Python exceptions."""
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == -1:
+        raise ValueError(msg)
+    raise SkootsHipError(f"[{rc}] {msg}")
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPE_CODE[t.dtype]
+    except KeyError:
+        raise ValueError(f"unsupported dtype {t.dtype}") from None
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} must live on the MI355X (got device {t.device}); skoots_amd runs HIP kernels "
+            "only and has no CPU fallback")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+def float_array(values):
+    arr = (C.c_float * len(values))(*values)
+    return arr

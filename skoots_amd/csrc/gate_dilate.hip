@@ -1,0 +1,221 @@
+// Stage-1 tail of skoots.lib.eval.eval(): gate, dilate, threshold, interior scatter.
+//
+// Replaces (reference file:line)
+//   skoots/lib/eval.py:145-150      channel split + gating by prob > 0.8
+//   skoots/lib/morphology.py:155-199 binary_dilation (3x3x3 max) + 2x binary_dilation_2d
+//                                   (3x3x1 max), called at eval.py:152-157
+//   skoots/lib/eval.py:160-176      interior crop scatter, skeleton > 0.8
+//
+// The reference materialises 3 x 27-channel one-hot conv3d outputs (194 MB fp32 per
+// call).  Max filters commute with the final threshold and compose to one box of
+// radius (3,3,1), zero padded at the tile faces, so the whole thing is a separable
+// OR over a byte mask staged in LDS: HBM traffic is one read of channels 3,4 around
+// the interior, one read of channels 0..2 on the interior, and the interior writes.
+#include "common.h"
+
+namespace {
+
+struct GateGeom {
+    int w, h, d;          // tile extents
+    int ox, oy, oz;       // tile origin in the volume
+    int ovx, ovy, ovz;    // margins
+    int X, Y, Z;          // volume extents
+    int px, py;           // interior patch handled per block
+    float prob_thr, skel_thr;
+};
+
+template <typename T>
+__device__ __forceinline__ float ld(const T* p, long long i);
+template <>
+__device__ __forceinline__ float ld<__half>(const __half* p, long long i) {
+    return __half2float(p[i]);
+}
+template <>
+__device__ __forceinline__ float ld<float>(const float* p, long long i) {
+    return p[i];
+}
+
+constexpr int RX = 3, RY = 3, RZ = 1;  // 1+1+1 in x,y ; 1 in z  (eval.py:152-157)
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+gate_dilate_scatter_kernel(const T* __restrict__ out5, GateGeom g, uint2* __restrict__ vec4,
+                           __half* __restrict__ vec_planar, uint8_t* __restrict__ skeleton) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int iw = g.w - 2 * g.ovx, ih = g.h - 2 * g.ovy;  // interior extents
+    const int nbx = (iw + g.px - 1) / g.px;
+    const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
+    const int x0 = g.ovx + bx * g.px, y0 = g.ovy + by * g.py;  // tile-local patch origin
+    const int sx = g.px + 2 * RX, sy = g.py + 2 * RY;          // staged columns
+    const int d = g.d;
+    unsigned char* m0 = smem;                      // [sx][sy][d]
+    unsigned char* m1 = smem + (size_t)sx * sy * d;  // [sx][sy][d]
+    const long long plane = (long long)g.w * g.h * d;
+    const int tid = threadIdx.x, nth = blockDim.x;
+
+    // phase 1: mask = skel > skel_thr && prob > prob_thr, zero outside the tile
+    for (int i = tid; i < sx * sy * d; i += nth) {
+        int z = i % d;
+        int c = i / d;
+        int ly = c % sy, lx = c / sy;
+        int tx = x0 - RX + lx, ty = y0 - RY + ly;
+        unsigned char m = 0;
+        if (tx >= 0 && tx < g.w && ty >= 0 && ty < g.h) {
+            long long o = ((long long)tx * g.h + ty) * d + z;
+            float skel = ld(out5, 3 * plane + o);
+            float prob = ld(out5, 4 * plane + o);
+            m = (prob > g.prob_thr && skel > g.skel_thr) ? 1 : 0;
+        }
+        m0[i] = m;
+    }
+    __syncthreads();
+    // phase 2: z dilation (radius 1), zero padded at the tile faces
+    for (int i = tid; i < sx * sy * d; i += nth) {
+        int z = i % d;
+        unsigned char m = m0[i];
+        if (z > 0) m |= m0[i - 1];
+        if (z + 1 < d) m |= m0[i + 1];
+        m1[i] = m;
+    }
+    __syncthreads();
+    // phase 3: y dilation (radius 3) for the columns the x pass needs -> m0[sx][py][d]
+    for (int i = tid; i < sx * g.py * d; i += nth) {
+        int z = i % d;
+        int c = i / d;
+        int ly = c % g.py, lx = c / g.py;
+        unsigned char m = 0;
+#pragma unroll
+        for (int k = 0; k <= 2 * RY; ++k) m |= m1[((size_t)lx * sy + ly + k) * d + z];
+        m0[i] = m;
+    }
+    __syncthreads();
+    // phase 4: x dilation (radius 3) + scatter of the interior
+    const int iz0 = g.ovz, iz1 = d - g.ovz;
+    const int idp = iz1 - iz0;
+    for (int i = tid; i < g.px * g.py * idp; i += nth) {
+        int zz = i % idp;
+        int c = i / idp;
+        int ly = c % g.py, lx = c / g.py;
+        int tx = x0 + lx, ty = y0 + ly, tz = iz0 + zz;
+        if (tx >= g.w - g.ovx || ty >= g.h - g.ovy) continue;
+        unsigned char m = 0;
+#pragma unroll
+        for (int k = 0; k <= 2 * RX; ++k) m |= m0[((size_t)(lx + k) * g.py + ly) * d + tz];
+        long long vo = ((long long)(g.ox + tx) * g.Y + (g.oy + ty)) * g.Z + (g.oz + tz);
+        skeleton[vo] = m;
+        // vectors: vec * (prob > thr), stored fp16 (eval.py:149,175)
+        long long o = ((long long)tx * g.h + ty) * d + tz;
+        bool gate = ld(out5, 4 * plane + o) > g.prob_thr;
+        float v0 = ld(out5, o), v1 = ld(out5, plane + o), v2 = ld(out5, 2 * plane + o);
+        if (!gate) {
+            v0 = copysignf(0.0f, v0);
+            v1 = copysignf(0.0f, v1);
+            v2 = copysignf(0.0f, v2);
+        }
+        __half h0 = __float2half_rn(v0), h1 = __float2half_rn(v1), h2 = __float2half_rn(v2);
+        if (vec4) {
+            __half2 lo = __halves2half2(h0, h1);
+            __half2 hi = __halves2half2(h2, __ushort_as_half(0));
+            uint2 r;
+            r.x = *reinterpret_cast<unsigned*>(&lo);
+            r.y = *reinterpret_cast<unsigned*>(&hi);
+            vec4[vo] = r;
+        }
+        if (vec_planar) {
+            long long nv = (long long)g.X * g.Y * g.Z;
+            vec_planar[vo] = h0;
+            vec_planar[vo + nv] = h1;
+            vec_planar[vo + 2 * nv] = h2;
+        }
+    }
+}
+
+// Library max filter (binary_dilation / binary_dilation_2d on arbitrary fp32 maps).
+__global__ void __launch_bounds__(256) max_filter_kernel(const float* __restrict__ in,
+                                                         float* __restrict__ out, int w, int h,
+                                                         int d, int rx, int ry, int rz) {
+    long long n = (long long)w * h * d;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int z = (int)(i % d);
+    long long c = i / d;
+    int y = (int)(c % h), x = (int)(c / h);
+    // zero padding: out-of-bounds taps contribute 0.0 (morphology.py:170-175)
+    bool clipped = (x - rx < 0) || (x + rx >= w) || (y - ry < 0) || (y + ry >= h) || (z - rz < 0) ||
+                   (z + rz >= d);
+    float m = clipped ? 0.0f : -INFINITY;
+    bool any = clipped;
+    for (int dx = -rx; dx <= rx; ++dx) {
+        int xx = x + dx;
+        if (xx < 0 || xx >= w) continue;
+        for (int dy = -ry; dy <= ry; ++dy) {
+            int yy = y + dy;
+            if (yy < 0 || yy >= h) continue;
+            for (int dz = -rz; dz <= rz; ++dz) {
+                int zz = z + dz;
+                if (zz < 0 || zz >= d) continue;
+                float v = in[((long long)xx * h + yy) * d + zz];
+                m = any ? fmaxf(m, v) : v;
+                any = true;
+            }
+        }
+    }
+    out[i] = m;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sk_gate_dilate_scatter(const void* out5, int out_dtype, int w, int h, int d, int ox, int oy,
+                           int oz, int ovx, int ovy, int ovz, void* vec4, void* vec_planar,
+                           uint8_t* skeleton, int X, int Y, int Z, float prob_thr, float skel_thr,
+                           void* stream) {
+    SK_CHECK_ARG(out5 && skeleton, "sk_gate_dilate_scatter: NULL pointer");
+    SK_CHECK_ARG(out_dtype == SK_F16 || out_dtype == SK_F32,
+                 "sk_gate_dilate_scatter: out dtype must be fp16 or fp32");
+    SK_CHECK_ARG(w > 0 && h > 0 && d > 0, "sk_gate_dilate_scatter: bad tile extents");
+    SK_CHECK_ARG(ovx > 0 && ovy > 0 && ovz > 0 && w > 2 * ovx && h > 2 * ovy && d > 2 * ovz,
+                 "sk_gate_dilate_scatter: margins (%d,%d,%d) must be positive and smaller than half "
+                 "the tile (%d,%d,%d)", ovx, ovy, ovz, w, h, d);
+    SK_CHECK_ARG(ox >= 0 && oy >= 0 && oz >= 0 && ox + w <= X && oy + h <= Y && oz + d <= Z,
+                 "sk_gate_dilate_scatter: tile [%d+%d,%d+%d,%d+%d) outside volume (%d,%d,%d)", ox, w,
+                 oy, h, oz, d, X, Y, Z);
+    GateGeom g{w, h, d, ox, oy, oz, ovx, ovy, ovz, X, Y, Z, 16, 16, prob_thr, skel_thr};
+    size_t lds = 2ull * (g.px + 2 * RX) * (g.py + 2 * RY) * d;
+    if (lds > 64 * 1024) {
+        g.px = g.py = 8;
+        lds = 2ull * (g.px + 2 * RX) * (g.py + 2 * RY) * d;
+    }
+    SK_CHECK_ARG(lds <= 96 * 1024, "sk_gate_dilate_scatter: tile depth %d too large", d);
+    int iw = w - 2 * ovx, ih = h - 2 * ovy;
+    unsigned grid = ((iw + g.px - 1) / g.px) * ((ih + g.py - 1) / g.py);
+    if (out_dtype == SK_F16) {
+        if (lds > 48 * 1024)
+            SK_CHECK_HIP(hipFuncSetAttribute((const void*)gate_dilate_scatter_kernel<__half>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        gate_dilate_scatter_kernel<__half><<<grid, 256, lds, (hipStream_t)stream>>>(
+            (const __half*)out5, g, (uint2*)vec4, (__half*)vec_planar, skeleton);
+    } else {
+        if (lds > 48 * 1024)
+            SK_CHECK_HIP(hipFuncSetAttribute((const void*)gate_dilate_scatter_kernel<float>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        gate_dilate_scatter_kernel<float><<<grid, 256, lds, (hipStream_t)stream>>>(
+            (const float*)out5, g, (uint2*)vec4, (__half*)vec_planar, skeleton);
+    }
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_max_filter3d(const float* in, float* out, int w, int h, int d, int rx, int ry, int rz,
+                    void* stream) {
+    SK_CHECK_ARG(in && out && in != out, "sk_max_filter3d: bad pointers");
+    SK_CHECK_ARG(w > 0 && h > 0 && d > 0 && rx >= 0 && ry >= 0 && rz >= 0,
+                 "sk_max_filter3d: bad extents");
+    long long n = (long long)w * h * d;
+    max_filter_kernel<<<sk::cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(in, out, w, h, d, rx, ry, rz);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+}  // extern "C"

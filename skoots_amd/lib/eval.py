@@ -1,0 +1,189 @@
+"""``skoots.lib.eval.eval`` on the MI355X (reference: skoots/lib/eval.py:33-320).
+
+The reference streams 300x300x20 tiles host->GPU->host through zarr arrays and runs
+flood fill, offset following and assignment on the CPU.  Here the whole volume stays
+resident in HBM (a 2048x2048x512 volume needs ~35 GB of the 288 GB): the image, the
+vectors (interleaved fp16x4), the skeleton mask, the labels and the instance mask
+never leave the device between stages, tiles are read in place, clamped duplicate
+tiles are skipped and stage 3 evaluates every voxel exactly once.
+
+Stage boundaries (and the timed region of ``<image>_skoots_benchmark.txt``) are the
+reference's: stage 1 = tiles -> network -> gate/dilate/scatter (eval.py:126-176),
+stage 2 = skeleton labelling (:223), stage 3 = follow + assign (:245-284), then
+renumber (:304-306).
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .. import _ffi
+from . import cropper
+from .flood_fill import label_skeleton
+from .vector_to_embedding import step_scales
+
+TILE = (300, 300, 20)          # eval.py:126
+TILE_OVERLAP = (50, 50, 5)     # eval.py:127
+ASSIGN_CROP = (500, 500, 50)   # eval.py:248
+ASSIGN_OVERLAP = (50, 50, 5)   # eval.py:249
+PROB_THR = 0.8                 # eval.py:149-150
+SKEL_THR = 0.8                 # eval.py:176
+FOLLOW_N = 10                  # eval.py:272
+
+
+def thresholds_for(dtype: torch.dtype) -> Tuple[float, float]:
+    """``tensor.gt(0.8)`` compares in the tensor's dtype: the python scalar is cast to
+    fp16 for an fp16 network output (autocast path, eval.py:142-150) and to fp32
+    otherwise; ``skeleton_map`` is always fp32 (eval.py:146)."""
+    prob = float(torch.tensor(PROB_THR, dtype=dtype).float())
+    skel = float(torch.tensor(SKEL_THR, dtype=torch.float32))
+    return prob, skel
+
+
+class VolumeState:
+    """HBM-resident arrays of one volume (or one Z-slab of it)."""
+
+    def __init__(self, shape: Sequence[int], device, keep_planar_vectors: bool = False):
+        X, Y, Z = (int(s) for s in shape)
+        self.shape = (X, Y, Z)
+        self.device = torch.device(device)
+        # vectors: interleaved (X,Y,Z,4) fp16 -- zero = the never-written frame (eval.py:103)
+        self.vec4 = torch.zeros((X, Y, Z, 4), dtype=torch.float16, device=device)
+        self.skeleton = torch.zeros((X, Y, Z), dtype=torch.uint8, device=device)  # eval.py:102
+        self.vec_planar = (torch.zeros((3, X, Y, Z), dtype=torch.float16, device=device)
+                           if keep_planar_vectors else None)
+        self.labels: Optional[Tensor] = None
+        self.instance: Optional[Tensor] = None
+
+    # -- stage 1 tail ------------------------------------------------------------------
+    def scatter_tile(self, out5: Tensor, origin: Sequence[int], overlap=TILE_OVERLAP) -> None:
+        """Gate + dilate + threshold + interior scatter of one tile's network output
+        (5, w, h, d) fp16/fp32 (eval.py:145-176)."""
+        _ffi.require_gpu(out5, "out5")
+        assert out5.ndim == 4 and out5.shape[0] == 5
+        _, w, h, d = out5.shape
+        X, Y, Z = self.shape
+        pthr, sthr = thresholds_for(out5.dtype)
+        _ffi.check(_ffi.lib.sk_gate_dilate_scatter(
+            _ffi.ptr(out5), _ffi.dtype_code(out5), w, h, d, origin[0], origin[1], origin[2],
+            overlap[0], overlap[1], overlap[2], _ffi.ptr(self.vec4), _ffi.ptr(self.vec_planar),
+            _ffi.ptr(self.skeleton), X, Y, Z, pthr, sthr, _ffi.stream_ptr(self.device)))
+
+    # -- stage 2 -----------------------------------------------------------------------
+    def label(self) -> Tensor:
+        self.labels = label_skeleton(self.skeleton)
+        return self.labels
+
+    # -- stage 3 -----------------------------------------------------------------------
+    def assign(self, scale, n: int = FOLLOW_N, decay: float = 1.0, crop=ASSIGN_CROP,
+               overlap=ASSIGN_OVERLAP, labels: Optional[Tensor] = None,
+               z_range: Optional[Tuple[int, int]] = None) -> Tensor:
+        """Follow + assign for every voxel (eval.py:245-284); ``instance`` int32 (X,Y,Z)."""
+        labels = self.labels if labels is None else labels
+        assert labels is not None, "run label() first"
+        X, Y, Z = self.shape
+        eff = cropper.clamp_crop_(list(crop), (X, Y, Z))
+        own = [torch.from_numpy(cropper.owner_table(dm, c, o)).to(self.device)
+               for dm, c, o in zip((X, Y, Z), eff, overlap)]
+        if self.instance is None:
+            self.instance = torch.zeros((X, Y, Z), dtype=torch.int32, device=self.device)
+        z_lo, z_hi = (0, Z) if z_range is None else z_range
+        sc = step_scales(scale, n, decay)
+        _ffi.check(_ffi.lib.sk_follow_assign(
+            _ffi.ptr(self.vec4), _ffi.ptr(labels), _ffi.dtype_code(labels), _ffi.ptr(self.instance),
+            X, Y, Z, _ffi.ptr(own[0]), _ffi.ptr(own[1]), _ffi.ptr(own[2]), eff[0], eff[1], eff[2],
+            _ffi.float_array(sc), n, z_lo, z_hi, _ffi.stream_ptr(self.device)))
+        self._own = own  # keep the tables alive until the stream has consumed them
+        return self.instance
+
+    # -- renumber ----------------------------------------------------------------------
+    def renumber(self, max_label: Optional[int] = None) -> int:
+        """In-place relabel of ``instance`` to 1..K by first appearance (eval.py:304-306)."""
+        inst = self.instance
+        assert inst is not None
+        if max_label is None:
+            max_label = int(inst.max().item())
+        n = inst.numel()
+        ws_bytes = _ffi.lib.sk_renumber_workspace_bytes(n, max_label)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        k = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _ffi.check(_ffi.lib.sk_renumber(_ffi.ptr(inst), n, max_label, _ffi.ptr(ws), ws_bytes,
+                                        _ffi.ptr(k), _ffi.stream_ptr(self.device)))
+        return int(k.item())
+
+    def vectors_planar(self) -> Tensor:
+        """(3, X, Y, Z) fp16, the layout of the reference's ``vectors`` array."""
+        X, Y, Z = self.shape
+        out = torch.empty((3, X, Y, Z), dtype=torch.float16, device=self.device)
+        _ffi.check(_ffi.lib.sk_vec_deinterleave(_ffi.ptr(self.vec4), _ffi.ptr(out), X * Y * Z,
+                                                _ffi.stream_ptr(self.device)))
+        return out
+
+
+def tile_grid(shape: Sequence[int], tile=TILE, overlap=TILE_OVERLAP):
+    """Distinct stage-1 tile origins in reference order + the effective tile size."""
+    eff = list(tile)
+    origins = cropper.distinct_origins(shape, eff, overlap)
+    return origins, eff
+
+
+def eval_volume(image: Tensor, model, scale, mean=None, std=None, n: int = FOLLOW_N,
+                tile=TILE, tile_overlap=TILE_OVERLAP, tile_batch: int = 4,
+                inject: Optional[Callable] = None, keep_planar_vectors: bool = False,
+                timings: Optional[Dict[str, float]] = None) -> Dict[str, Tensor]:
+    """In-memory variant of :func:`eval`: (1, X, Y, Z) or (X, Y, Z) image on the GPU ->
+    instance mask, vectors, skeleton, labels (all HBM-resident tensors).
+
+    ``model`` is a :class:`skoots_amd.unet.HipUNet` (``model.forward_tiles``);
+    ``inject(out5, origin, eff) -> out5`` may replace a tile's network output (tests
+    and the assignment-workload generator of bench.py use it).
+    """
+    img = image.squeeze(0) if image.ndim == 4 else image
+    _ffi.require_gpu(img, "image")
+    dev = img.device
+    img16 = img if img.dtype == torch.float16 else img.to(torch.float16)  # eval.py:80
+    if mean is None or std is None:
+        # eval.py:87-88 fallback: statistics of the fp16 image, evaluated by the same torch
+        # CPU reduction the reference uses (outside the timed region).
+        cpu = img16.cpu()
+        mean = float(cpu.mean()) if mean is None else mean
+        std = float(cpu.std()) if std is None else std
+    X, Y, Z = img16.shape
+    state = VolumeState((X, Y, Z), dev, keep_planar_vectors)
+
+    def tick(name, t0):
+        if timings is not None:
+            torch.cuda.synchronize(dev)
+            timings[name] = timings.get(name, 0.0) + (time.perf_counter() - t0)
+
+    t0 = time.perf_counter()
+    origins, eff = tile_grid((X, Y, Z), tile, tile_overlap)
+    for i in range(0, len(origins), tile_batch):
+        batch = origins[i:i + tile_batch]
+        out5 = model.forward_tiles(img16, batch, eff, float(mean), float(std)) if model is not None else None
+        for b, org in enumerate(batch):
+            o = out5[b] if out5 is not None else None
+            if inject is not None:
+                o = inject(o, org, eff)
+            state.scatter_tile(o, org, tile_overlap)
+    tick("stage1", t0)
+
+    t0 = time.perf_counter()
+    state.label()
+    tick("stage2", t0)
+
+    t0 = time.perf_counter()
+    state.assign(scale, n=n)
+    tick("stage3", t0)
+
+    t0 = time.perf_counter()
+    k = state.renumber()
+    tick("renumber", t0)
+    return {"instance_mask": state.instance, "labels": state.labels, "skeleton": state.skeleton,
+            "vec4": state.vec4, "vectors": state.vec_planar, "n_instances": k, "state": state}

@@ -1,0 +1,139 @@
+"""CPU tests: the C-ABI library loads and exports everything include/skoots_hip.h
+declares, and the host logic (tile grid, owner tables, step scales, seam graph)
+matches the golden fixtures / the oracle.  No GPU compute is called here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from skoots_amd import _ffi
+    hdr = open(os.path.join(ROOT, "include", "skoots_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sk_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(_ffi.lib, name), f"libskoots_hip.so does not export {name}"
+    assert declared == set(_ffi.EXPORTS), declared ^ set(_ffi.EXPORTS)
+    assert _ffi.lib.sk_abi_version() >= 1
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    from skoots_amd.lib.vector_to_embedding import vector_to_embedding
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        vector_to_embedding(torch.tensor((1, 1, 1)), torch.zeros((1, 3, 4, 4, 4)))
+
+
+def test_crop_grid_matches_reference(golden):
+    from skoots_amd.lib import cropper
+    g = golden("tiling.npz")
+    for i in range(int(g["n"])):
+        shape = g[f"shape_{i}"].tolist()
+        crop = g[f"crop_{i}"].tolist()
+        ov = g[f"overlap_{i}"].tolist()
+        c1 = list(crop)
+        origins = cropper.crop_origins(shape[1:], c1, ov)
+        assert c1 == g[f"eff_{i}"].tolist()  # clamped in place like the reference
+        assert np.array_equal(np.array(origins, dtype=np.int32), g[f"origins_{i}"])
+        assert cropper.get_total_num_crops(shape, list(crop), ov) == len(origins)
+        # generator API
+        if np.prod(shape) < 5e6:
+            got = [o for _, o in cropper.crops(torch.zeros(shape), list(crop), tuple(ov))]
+            assert got == [list(o) for o in origins]
+
+
+def _last_writer_bruteforce(dim, crop, ov):
+    own = np.full(dim, -1, dtype=np.int32)
+    v = 0
+    while v < dim:
+        o = v if v + crop <= dim else dim - crop
+        own[o + ov:o + crop - ov] = o
+        v += crop - 2 * ov
+    return own
+
+
+@pytest.mark.parametrize("shape,crop,ov", [
+    ((128, 128, 32), (300, 300, 20), (50, 50, 5)),
+    ((1024, 1024, 256), (300, 300, 20), (50, 50, 5)),
+    ((1024, 1024, 256), (500, 500, 50), (50, 50, 5)),
+    ((777, 500, 51), (500, 500, 50), (50, 50, 5)),
+    ((301, 299, 21), (300, 300, 20), (50, 50, 5)),
+])
+def test_owner_tables_and_distinct_origins(shape, crop, ov):
+    from skoots_amd.lib import cropper
+    eff = list(crop)
+    all_origins = cropper.crop_origins(shape, eff, ov)
+    distinct = cropper.distinct_origins(shape, list(crop), ov)
+    assert len(set(distinct)) == len(distinct) and set(distinct) == set(all_origins)
+    # replay both lists as "write my origin index into my interior": same final owner map
+    def replay(origins):
+        vol = np.full(shape, -1, dtype=np.int64)
+        for (x, y, z) in origins:
+            key = (x * 4096 + y) * 4096 + z
+            vol[x + ov[0]:x + eff[0] - ov[0], y + ov[1]:y + eff[1] - ov[1], z + ov[2]:z + eff[2] - ov[2]] = key
+        return vol
+    if np.prod(shape) <= 3e7:
+        full = replay(all_origins)
+        assert np.array_equal(full, replay(distinct))
+        own = [cropper.owner_table(d, c, o) for d, c, o in zip(shape, eff, ov)]
+        ox, oy, oz = np.meshgrid(*own, indexing="ij")
+        sep = np.where((ox < 0) | (oy < 0) | (oz < 0), -1, (ox.astype(np.int64) * 4096 + oy) * 4096 + oz)
+        assert np.array_equal(full, sep)
+    for d, c, o in zip(shape, eff, ov):
+        assert np.array_equal(cropper.owner_table(d, c, o), _last_writer_bruteforce(d, c, o))
+
+
+def test_step_scales_match_reference_promotion(golden):
+    from skoots_amd.lib.vector_to_embedding import step_scales
+    sc = step_scales((60, 60, 12), 4, 0.95)
+    num = torch.tensor((60, 60, 12)).float()
+    s, rows = 1.0, [num.clone()]
+    for _ in range(3):
+        s *= 0.95
+        rows.append(s * num)  # python double * fp32 tensor, as vector_to_embedding.py:115
+    assert sc == torch.stack(rows).reshape(-1).tolist()
+
+
+def test_seam_components_host_matches_oracle():
+    from skoots_amd import _ffi
+    rng = np.random.default_rng(0)
+    ip = C.POINTER(C.c_int32)
+    for trial in range(50):
+        n = int(rng.integers(1, 40))
+        pairs = rng.integers(3, 30, size=(n, 2)).astype(np.int32)
+        graph = {}
+        for a, b in pairs.tolist():
+            graph.setdefault(a, []).append(b)
+            graph.setdefault(b, []).append(a)
+        want = []
+        for comp in O.connected_components(graph):
+            want += [(v, comp[-1]) for v in comp[:-1]]
+        a = np.empty(4 * n, np.int32)
+        b = np.empty(4 * n, np.int32)
+        k = _ffi.lib.sk_seam_components_host(pairs.ctypes.data_as(ip), n, a.ctypes.data_as(ip),
+                                             b.ctypes.data_as(ip), 4 * n)
+        assert k == len(want)
+        assert list(zip(a[:k].tolist(), b[:k].tolist())) == want
+    # known answer of the reference's __main__ block (flood_fill.py:264-277)
+    pairs = np.array([[1, 2], [1, 3], [3, 5], [3, 4], [4, 5], [6, 7], [7, 8], [7, 9]], dtype=np.int32)
+    a = np.empty(16, np.int32); b = np.empty(16, np.int32)
+    k = _ffi.lib.sk_seam_components_host(pairs.ctypes.data_as(ip), 8, a.ctypes.data_as(ip),
+                                         b.ctypes.data_as(ip), 16)
+    assert a[:k].tolist() == [1, 2, 3, 5, 6, 7, 8] and b[:k].tolist() == [4, 4, 4, 4, 9, 9, 9]
+
+
+def test_thresholds_follow_torch_scalar_casting():
+    from skoots_amd.lib.eval import thresholds_for
+    p16, s16 = thresholds_for(torch.float16)
+    p32, s32 = thresholds_for(torch.float32)
+    assert p16 == 0.7998046875 and p32 == float(np.float32(0.8)) and s16 == s32 == p32
+    x = torch.tensor([0.7998046875, 0.80029296875], dtype=torch.float16)
+    assert x.gt(0.8).tolist() == (x.float() > p16).tolist()
