@@ -147,6 +147,66 @@ size_t sk_renumber_workspace_bytes(int64_t n, int max_label);
 int sk_renumber(int32_t* labels, int64_t n, int max_label, void* workspace,
                 size_t workspace_bytes, int32_t* n_labels, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * Stage 1 body: U-Net layers (the network the reference builds with
+ * cfg_to_bism_model, skoots/lib/utils.py:17-107, and runs at eval.py:117-143).
+ * Graph and parity reference: oracle/unet_spec.py.  Activations are channels-last
+ * fp16 (B, X, Y, Z, C).  A conv writes RAW outputs (bias added) plus per-block
+ * GroupNorm partial sums; sk_groupnorm_finalize + sk_groupnorm_silu then normalise
+ * and activate the tensor in place, so every conv input is already activated.
+ * ------------------------------------------------------------------------ */
+
+typedef struct sk_conv_src {
+    const void* data;   /* (B, sx, sy, sz, c) fp16 channels-last, activated                 */
+    int c;              /* channels of this source (multiple of 32 for ksize 3)            */
+    int upsample;       /* 1: source is half resolution, read at (x>>1, y>>1, z>>1)        */
+} sk_conv_src;
+
+/* Implicit-GEMM 3-D convolution on the matrix cores (v_mfma_f32_32x32x16_f16).
+ * ksize 3: stride 1, zero pad 1, input = channel concat of n_src (<= 2) sources, the
+ * second optionally nearest-upsampled x2 (torch.cat([skip, interpolate(x)]) never
+ * materialised).  ksize 2: stride 2, no pad.  ksize 1: pointwise.  weight: packed by
+ * sk_conv3d_pack_weight_host; bias (cout) fp32; out (B, ox, oy, oz, cout) fp16 raw.
+ * gn_partial: (B, sk_conv3d_num_blocks, cout/4, 2) fp32 per-block (sum, sumsq) of
+ * the fp32 accumulators per channel quad, or NULL.  zeros: >= 1 KiB of zero bytes
+ * (source of the halo / padding lanes of the LDS-DMA). */
+int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias,
+              void* out, int B, int ox, int oy, int oz, int cout, int ksize,
+              float* gn_partial, const void* zeros, void* stream);
+
+/* Rows of gn_partial per batch item that sk_conv3d writes for this output shape. */
+int sk_conv3d_num_blocks(int B, int ox, int oy, int oz, int cout, int ksize);
+
+/* HOST: torch-layout weight (cout, cin, k, k, k) fp32 -> MFMA A-fragment order fp16.
+ * Returns the bytes needed / written (dst_host == NULL only queries). */
+int64_t sk_conv3d_pack_weight_host(const float* w_host, int cout, int cin, int ksize,
+                                   void* dst_host);
+
+/* Stem: first conv of the network (Cin = 1).  Reads B tiles of extent (Xt,Yt,Zt) at
+ * origins_host[3*b..] straight from the (X,Y,Z) fp16 image volume, normalises
+ * (x - mean)/std in fp16 arithmetic exactly as eval.py:139, conv3 zero padded ->
+ * out (B, Xt, Yt, Zt, 32) fp16 raw + gn partials (B, stem_num_blocks, 8, 2).
+ * weight (27, 32) fp32 [tap=(dx*3+dy)*3+dz][cout]. */
+int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origins_host, int B,
+                   int Xt, int Yt, int Zt, float mean, float std, const float* weight,
+                   const float* bias, void* out, int cout, float* gn_partial, void* stream);
+int sk_conv3d_stem_num_blocks(int X, int Y, int Z);
+
+/* GroupNorm statistics -> per-channel affine, reduced in a fixed order (deterministic):
+ * gn_partial (B, nblocks, C/4, 2); affine (B, 2, C): a = gamma*rstd, b = beta - mean*a. */
+int sk_groupnorm_finalize(const float* gn_partial, int B, int nblocks, int groups, int C,
+                          int64_t voxels, const float* gamma, const float* beta, float eps,
+                          float* affine, void* stream);
+
+/* Fused GroupNorm affine + SiLU, in place on (B, voxels, C) fp16. */
+int sk_groupnorm_silu(void* x, const float* affine, int B, int64_t voxels, int C, void* stream);
+
+/* Heads: 1x1x1 conv C->5 on the activated features, tanh on [0:3], sigmoid on [3:5];
+ * out5 (B, 5, voxels) planar fp16 = the reference's output layout (eval.py:145-147).
+ * weight (5, C) fp32, bias (5). */
+int sk_heads(const void* x, const float* weight, const float* bias, void* out5, int B,
+             int64_t voxels, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,55 @@ class UNetSpec(nn.Module):
         return torch.cat([torch.tanh(y[:, 0:3]), torch.sigmoid(y[:, 3:5])], dim=1)
 
 
+def _q16(t):
+    return t.half().float()
+
+
+def forward_fp16_storage(model: "UNetSpec", x):
+    """The same graph with the HIP path's STORAGE precision restated in fp32 torch ops:
+    MFMA layers use fp16 weights and fp16 activations with fp32 accumulation; a conv's
+    raw output is stored as fp16, GroupNorm statistics come from the fp32 accumulators,
+    the affine + SiLU result is stored as fp16; the stem and the heads keep fp32
+    weights; the 5 output channels are stored as fp16.  Used to separate kernel
+    correctness (HIP vs this, tight tolerance) from the cost of fp16 storage itself
+    (this vs the fp32 forward)."""
+
+    def block(m: ConvGNAct, t, fp32_weights=False):
+        w = m.conv.weight if fp32_weights else _q16(m.conv.weight)
+        y = F.conv3d(t, w, m.conv.bias, stride=m.conv.stride, padding=m.conv.padding)
+        B, C = y.shape[:2]
+        g = y.double().reshape(B, GN_GROUPS, -1)
+        mu = g.mean(-1, keepdim=True)
+        var = (g * g).mean(-1, keepdim=True) - mu * mu
+        rstd = (1.0 / (var.clamp_min(0) + GN_EPS).sqrt()).float()
+        gam = m.norm.weight.reshape(1, GN_GROUPS, -1)
+        a = (gam * rstd).reshape(1, C, 1, 1, 1)
+        b = (m.norm.bias.reshape(1, GN_GROUPS, -1) - mu.float() * gam * rstd).reshape(1, C, 1, 1, 1)
+        return _q16(F.silu(a * _q16(y) + b))
+
+    t = x
+    for i, m in enumerate(model.enc0):
+        t = block(m, t, fp32_weights=(i == 0))
+    s0 = t
+    t = block(model.down0, t)
+    for m in model.enc1:
+        t = block(m, t)
+    s1 = t
+    t = block(model.down1, t)
+    for m in model.mid:
+        t = block(m, t)
+    t = F.interpolate(block(model.red1, t), size=s1.shape[2:], mode="nearest")
+    t = torch.cat([s1, t], dim=1)
+    for m in model.dec1:
+        t = block(m, t)
+    t = F.interpolate(block(model.red0, t), size=s0.shape[2:], mode="nearest")
+    t = torch.cat([s0, t], dim=1)
+    for m in model.dec0:
+        t = block(m, t)
+    y = model.heads(t)
+    return _q16(torch.cat([torch.tanh(y[:, 0:3]), torch.sigmoid(y[:, 3:5])], dim=1))
+
+
 def flops_per_voxel(dims=(32, 64, 128, 64, 32), depths=(2, 2, 2, 2, 2), in_channels=1) -> float:
     """Algorithmic conv FLOPs (2*Cin*Cout*k^3 per output voxel) per full-resolution voxel."""
     d0, d1, d2, d3, d4 = dims

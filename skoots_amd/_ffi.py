@@ -41,7 +41,7 @@ ip = C.POINTER(C.c_int32)
 
 
 class ConvSrc(C.Structure):
-    _fields_ = [("data", vp), ("affine", vp), ("c", i32), ("upsample", i32)]
+    _fields_ = [("data", vp), ("c", i32), ("upsample", i32)]
 
 
 _SIGS = {
@@ -63,6 +63,14 @@ _SIGS = {
     "sk_relabel_lut": (i32, [vp, i64, vp, i32, vp]),
     "sk_renumber_workspace_bytes": (sz, [i64, i32]),
     "sk_renumber": (i32, [vp, i64, i32, vp, sz, vp, vp]),
+    "sk_conv3d": (i32, [C.POINTER(ConvSrc), i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "sk_conv3d_num_blocks": (i32, [i32, i32, i32, i32, i32, i32]),
+    "sk_conv3d_pack_weight_host": (i64, [fp, i32, i32, i32, vp]),
+    "sk_conv3d_stem": (i32, [vp, i32, i32, i32, ip, i32, i32, i32, i32, f32, f32, vp, vp, vp, i32, vp, vp]),
+    "sk_conv3d_stem_num_blocks": (i32, [i32, i32, i32]),
+    "sk_groupnorm_finalize": (i32, [vp, i32, i32, i32, i32, i64, vp, vp, f32, vp, vp]),
+    "sk_groupnorm_silu": (i32, [vp, vp, i32, i64, i32, vp]),
+    "sk_heads": (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -1,0 +1,624 @@
+// 3x3x3 convolution (stride 1, zero pad 1) of the U-Net body as an implicit GEMM on
+// the gfx950 matrix cores -- the dominant kernel of stage 1.
+//
+// Replaces the conv layers of the network the reference builds with
+// cfg_to_bism_model (skoots/lib/utils.py:17-107) and runs under torch.compile +
+// fp16 autocast at skoots/lib/eval.py:122-124,142-143.  Graph: oracle/unet_spec.py.
+//
+// Design (MI355X-first, not a translation of a cuDNN-style im2col):
+//   * activations are channels-last fp16 (B, X, Y, Z, C), already normalised +
+//     activated by the fused GroupNorm+SiLU pass; weights are pre-packed on the host
+//     in MFMA A-fragment order (sk_conv3d_pack_weight_host);
+//   * D[cout][voxel] += W[cout][cin,tap] * act[cin,tap][voxel] with
+//     v_mfma_f32_32x32x16_f16: rows = 32 output channels, columns = 32 voxels of a
+//     (y,z) patch, K = 16 input channels of one tap;
+//   * a workgroup (4 waves, one 32-voxel column set each) owns a 128-voxel (y,z)
+//     patch and MARCHES along x, XS output planes per step.  The input planes of a
+//     step (XS+2, with y/z halo) sit in an LDS ring filled by LDS-DMA
+//     (global_load_lds_dwordx4: no VGPRs, no VALU; halo / out-of-tile lanes read a
+//     zero page, the nearest-neighbour upsample of the decoder is just the per-lane
+//     source address); two planes are reused by the next step;
+//   * one B fragment (ds_read_b128) feeds the three x-taps of three different output
+//     planes, so LDS traffic is (XS+2)/(3*XS) reads per MFMA; the LDS image is
+//     XOR-swizzled on the DMA *source* address (the destination is lane-linear) so the
+//     16-lane groups of ds_read_b128 hit 16 distinct bank slots;
+//   * input channels are consumed in chunks of 32 (the channel concat of skip +
+//     upsampled tensors is two chunks from two sources, never materialised);
+//   * the epilogue adds the bias, stores fp16 raw outputs (8 B per lane) and
+//     accumulates per-channel-quad (sum, sumsq) of the fp32 accumulators for the
+//     GroupNorm that follows; per-block partials are reduced in a fixed order by
+//     sk_groupnorm_finalize (deterministic, no float atomics).
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kChunk = 32;       // input channels per LDS image
+constexpr int kPosBytes = 64;    // kChunk * sizeof(fp16)
+constexpr int kPatch = 128;      // voxels per (y,z) patch = 4 waves x 32 columns
+constexpr int kMaxDma = 4;       // DMA wave-instructions per plane per wave (nposp <= 256)
+
+struct SrcDev {
+    const char* data;
+    int C;              // channels of this tensor
+    int up;             // 1: half resolution, read at (x>>1, y>>1, z>>1)
+    int Ys, Zs;         // its own y / z extents
+    long long plane;    // bytes per x-plane
+    long long batch;    // bytes per batch item
+};
+
+struct Conv3Args {
+    SrcDev src[2];
+    int nchunks, c0chunks;
+    const char* wpk;
+    const float* bias;
+    char* out;
+    float* partial;
+    const char* zeros;
+    int B, Xt, Yt, Zt;
+    int XC, nxc, npatch;
+    int mode;           // 0: linear (y,z) ranges (small Zt), 1: TY x TZ rectangles
+    int TZ, nzc;
+    int pitch, nposp;
+};
+
+__device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int COUT, int XS>
+__global__ void __launch_bounds__(256) conv3_kernel(Conv3Args a) {
+    constexpr int NT = COUT / 32;
+    constexpr int R = XS + 2;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, h = lane >> 5;
+
+    int blk = blockIdx.x;
+    const int patch = blk % a.npatch;
+    blk /= a.npatch;
+    const int xc = blk % a.nxc;
+    const int b = blk / a.nxc;
+    const int block_in_batch = xc * a.npatch + patch;
+    const int nblk = a.npatch * a.nxc;
+
+    // ---- patch geometry ------------------------------------------------------------
+    const int pitch = a.pitch;
+    int off, ybase, zbase;      // region position q -> (y, z): P = q + off; y = ybase + P/pitch; z = zbase + P%pitch
+    int vy, vz;                 // this lane's output voxel
+    int q_row;                  // its position in the region
+    bool vvalid;
+    if (a.mode == 0) {
+        int v0 = patch * kPatch;
+        int y0 = v0 / a.Zt, z0 = v0 - y0 * a.Zt;
+        off = z0;
+        ybase = y0 - 1;
+        zbase = -1;
+        int v = v0 + 32 * w + col;
+        vy = v / a.Zt;
+        vz = v - vy * a.Zt;
+        vvalid = v < a.Yt * a.Zt;
+        q_row = (vy + 1) * pitch + (vz + 1) - (y0 * pitch + z0);
+    } else {
+        const int TY = kPatch / a.TZ;
+        int yg = patch / a.nzc, zc = patch - yg * a.nzc;
+        int y0 = yg * TY, zc0 = zc * a.TZ;
+        off = 0;
+        ybase = y0 - 1;
+        zbase = zc0 - 1;
+        int vl = 32 * w + col;
+        int yl = vl / a.TZ, zl = vl - yl * a.TZ;
+        vy = y0 + yl;
+        vz = zc0 + zl;
+        vvalid = vy < a.Yt && vz < a.Zt;
+        q_row = (yl + 1) * pitch + (zl + 1);
+    }
+    const long long out_vox = ((long long)vy * a.Zt + vz);  // in-plane voxel index of the output
+
+    // ---- DMA bookkeeping: this lane's slots of a plane --------------------------------
+    const int ndma = a.nposp / 16;  // wave-instructions per plane
+    int d_vox[kMaxDma], d_up[kMaxDma], d_cs[kMaxDma];
+#pragma unroll
+    for (int k = 0; k < kMaxDma; ++k) {
+        int t = w + 4 * k;
+        int slot = 64 * t + lane;
+        int q = slot >> 2, c = slot & 3;
+        int P = q + off;
+        int y = ybase + P / pitch, z = zbase + P % pitch;
+        bool ok = (t < ndma) && y >= 0 && y < a.Yt && z >= 0 && z < a.Zt;
+        d_vox[k] = ok ? y * a.Zt + z : -1;
+        d_up[k] = ok ? (y >> 1) * a.src[1].Zs + (z >> 1) : -1;
+        d_cs[k] = (c ^ ((q >> 2) & 3)) * 16;  // source 16-byte chunk (swizzle on the SOURCE side)
+    }
+
+    // ---- accumulators + GroupNorm partials ----------------------------------------------
+    f32x16 acc[XS][NT];
+    float gsum[NT][4], gsq[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gsum[nt][q] = gsq[nt][q] = 0.0f;
+
+    const int xa = xc * a.XC;
+    const int xb = min(xa + a.XC, a.Xt);
+    const int plane_bytes = a.nposp * kPosBytes;
+    const bool ring = (a.nchunks == 1);
+    const long long out_plane = (long long)a.Yt * a.Zt * COUT * 2;
+    char* outb = a.out + (long long)b * a.Xt * out_plane;
+
+    int step = 0;
+    for (int x0 = xa; x0 < xb; x0 += XS, ++step) {
+        // bias as the initial accumulator: row (cout) = 32nt + (r&3) + 8(r>>2) + 4h
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 init;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + 32 * nt + 8 * q + 4 * h);
+                init[4 * q + 0] = bv[0];
+                init[4 * q + 1] = bv[1];
+                init[4 * q + 2] = bv[2];
+                init[4 * q + 3] = bv[3];
+            }
+#pragma unroll
+            for (int o = 0; o < XS; ++o) acc[o][nt] = init;
+        }
+
+        for (int ch = 0; ch < a.nchunks; ++ch) {
+            // ---------------- stage the input planes of this (step, chunk) ------------------
+            const int si = ch < a.c0chunks ? 0 : 1;
+            const SrcDev s = a.src[si];
+            const int choff = (ch - (si ? a.c0chunks : 0)) * kChunk * 2;  // byte offset of the chunk
+            const int first_new = (ring && step > 0) ? 2 : 0;  // planes 0,1 survive in the ring
+            __syncthreads();  // every wave is done reading the planes about to be overwritten
+            for (int i = first_new; i < R; ++i) {
+                const int x = x0 - 1 + i;
+                const int slotp = ring ? (step * XS + i) % R : i;
+                const bool xok = x >= 0 && x < a.Xt;
+                const char* pbase = s.data + (long long)b * s.batch +
+                                    (long long)(s.up ? (x >> 1) : x) * s.plane + choff;
+                char* lbase = lds + slotp * plane_bytes;
+#pragma unroll
+                for (int k = 0; k < kMaxDma; ++k) {
+                    const int t = w + 4 * k;
+                    if (t < ndma) {
+                        const int vox = s.up ? d_up[k] : d_vox[k];
+                        const char* g = (xok && vox >= 0)
+                                            ? pbase + (long long)vox * (s.C * 2) + d_cs[k]
+                                            : a.zeros + lane * 16;
+                        dma16(g, lbase + t * 1024);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+
+            // ---------------- MFMA over the 27 taps of this chunk ---------------------------
+            const char* wch = a.wpk + (long long)ch * (9 * 2 * 3 * NT) * 1024 + lane * 16;
+#pragma unroll 1
+            for (int dydz = 0; dydz < 9; ++dydz) {
+                const int dy = dydz / 3 - 1, dz = dydz % 3 - 1;
+                const int q = q_row + dy * pitch + dz;
+                const int f = (q >> 2) & 3;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    half8 afr[3][NT];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            afr[d][nt] = *reinterpret_cast<const half8*>(
+                                wch + (((dydz * 2 + ks) * 3 + d) * NT + nt) * 1024);
+                    const int addr = (q * 4 + ((ks * 2 + h) ^ f)) * 16;
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const int slotp = ring ? (step * XS + i) % R : i;
+                        const half8 bfr = *reinterpret_cast<const half8*>(lds + slotp * plane_bytes + addr);
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            const int o = i - d;  // x_in = x_out + (d - 1)
+                            if (o >= 0 && o < XS) {
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    acc[o][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                        afr[d][nt], bfr, acc[o][nt], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---------------- epilogue: raw fp16 store + GroupNorm partial sums ------------------
+#pragma unroll
+        for (int o = 0; o < XS; ++o) {
+            const int x = x0 + o;
+            const bool ok = vvalid && x < xb;
+            char* op = outb + (long long)x * out_plane + out_vox * (COUT * 2);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v0 = acc[o][nt][4 * q], v1 = acc[o][nt][4 * q + 1];
+                    float v2 = acc[o][nt][4 * q + 2], v3 = acc[o][nt][4 * q + 3];
+                    if (ok) {
+                        half4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+                        *reinterpret_cast<half4*>(op + (32 * nt + 8 * q + 4 * h) * 2) = hv;
+                        gsum[nt][q] += (v0 + v1) + (v2 + v3);
+                        gsq[nt][q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- block-level reduction of the GroupNorm partials ------------------------------------
+    if (a.partial) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds);  // [4 waves][NT*8 quads][2]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float s = gsum[nt][q], ss = gsq[nt][q];
+#pragma unroll
+                for (int m = 16; m > 0; m >>= 1) {
+                    s += __shfl_xor(s, m);
+                    ss += __shfl_xor(ss, m);
+                }
+                if (col == 0) {
+                    int quad = 8 * nt + 2 * q + h;  // channel quad = cout / 4
+                    red[(w * (NT * 8) + quad) * 2 + 0] = s;
+                    red[(w * (NT * 8) + quad) * 2 + 1] = ss;
+                }
+            }
+        __syncthreads();
+        if (tid < NT * 8 * 2) {
+            float t = red[tid] + red[NT * 16 + tid] + red[2 * NT * 16 + tid] + red[3 * NT * 16 + tid];
+            a.partial[((long long)b * nblk + block_in_batch) * (NT * 16) + tid] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Gather GEMM for the layers with no spatial reuse of activations: 2x2x2 stride-2
+// down-sampling convs (8 taps, each input voxel feeds one output voxel) and 1x1x1
+// channel reducers.  B fragments come straight from global memory (16 B per lane),
+// weights in the same packed A-fragment order.  A wave owns PV tiles of 32 voxels.
+// ------------------------------------------------------------------------------------------
+struct GatherArgs {
+    const char* in;
+    const char* wpk;
+    const float* bias;
+    char* out;
+    float* partial;
+    int B, Xo, Yo, Zo;      // output extents
+    int Xi, Yi, Zi, Cin;    // input extents / channels
+    int ksize;              // 1 or 2 (stride == ksize)
+    int nblk;
+};
+
+template <int COUT, int PV>
+__global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
+    constexpr int NT = COUT / 32;
+    __shared__ float red[4 * NT * 16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x / a.nblk;
+    const int blk = blockIdx.x % a.nblk;
+    const long long nvox = (long long)a.Xo * a.Yo * a.Zo;
+    const int ntaps = a.ksize * a.ksize * a.ksize;
+    const int nks = a.Cin / 16;
+
+    f32x16 acc[PV][NT];
+    long long vin[PV];   // input voxel index of tap (0,0,0)
+    long long vout[PV];
+    bool ok[PV];
+#pragma unroll
+    for (int p = 0; p < PV; ++p) {
+        long long v = ((long long)blk * 4 + w) * (32 * PV) + p * 32 + col;
+        ok[p] = v < nvox;
+        long long vv = ok[p] ? v : 0;
+        int z = (int)(vv % a.Zo);
+        long long t = vv / a.Zo;
+        int y = (int)(t % a.Yo), x = (int)(t / a.Yo);
+        vout[p] = vv;
+        vin[p] = ((long long)(x * a.ksize) * a.Yi + y * a.ksize) * a.Zi + z * a.ksize;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + 32 * nt + 8 * q + 4 * h);
+                acc[p][nt][4 * q] = bv[0];
+                acc[p][nt][4 * q + 1] = bv[1];
+                acc[p][nt][4 * q + 2] = bv[2];
+                acc[p][nt][4 * q + 3] = bv[3];
+            }
+        }
+    }
+    const char* inb = a.in + (long long)b * a.Xi * a.Yi * a.Zi * a.Cin * 2;
+    for (int tap = 0; tap < ntaps; ++tap) {
+        int dx = tap / (a.ksize * a.ksize), dy = (tap / a.ksize) % a.ksize, dz = tap % a.ksize;
+        long long toff = ((long long)dx * a.Yi + dy) * a.Zi + dz;
+        for (int ks = 0; ks < nks; ++ks) {
+            half8 afr[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                afr[nt] = *reinterpret_cast<const half8*>(
+                    a.wpk + ((long long)(tap * nks + ks) * NT + nt) * 1024 + lane * 16);
+#pragma unroll
+            for (int p = 0; p < PV; ++p) {
+                half8 bfr = *reinterpret_cast<const half8*>(
+                    inb + ((vin[p] + toff) * a.Cin + ks * 16 + 8 * h) * 2);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[nt], bfr, acc[p][nt], 0, 0, 0);
+            }
+        }
+    }
+    float gsum[NT][4], gsq[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gsum[nt][q] = gsq[nt][q] = 0.0f;
+    char* outb = a.out + (long long)b * nvox * COUT * 2;
+#pragma unroll
+    for (int p = 0; p < PV; ++p) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v0 = acc[p][nt][4 * q], v1 = acc[p][nt][4 * q + 1];
+                float v2 = acc[p][nt][4 * q + 2], v3 = acc[p][nt][4 * q + 3];
+                if (ok[p]) {
+                    half4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+                    *reinterpret_cast<half4*>(outb + (vout[p] * COUT + 32 * nt + 8 * q + 4 * h) * 2) = hv;
+                    gsum[nt][q] += (v0 + v1) + (v2 + v3);
+                    gsq[nt][q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                }
+            }
+    }
+    if (a.partial) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float s = gsum[nt][q], ss = gsq[nt][q];
+#pragma unroll
+                for (int m = 16; m > 0; m >>= 1) {
+                    s += __shfl_xor(s, m);
+                    ss += __shfl_xor(ss, m);
+                }
+                if (col == 0) {
+                    int quad = 8 * nt + 2 * q + h;
+                    red[(w * (NT * 8) + quad) * 2 + 0] = s;
+                    red[(w * (NT * 8) + quad) * 2 + 1] = ss;
+                }
+            }
+        __syncthreads();
+        if (tid < NT * 16) {
+            float t = red[tid] + red[NT * 16 + tid] + red[2 * NT * 16 + tid] + red[3 * NT * 16 + tid];
+            a.partial[((long long)b * a.nblk + blk) * (NT * 16) + tid] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side planning
+// ------------------------------------------------------------------------------------------
+struct Plan {
+    int mode, TZ, nzc, pitch, nposp, npatch, XC, nxc, xs;
+    size_t lds;
+};
+
+int conv3_xs(int cout) { return cout == 128 ? 2 : 4; }
+
+int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
+    p.xs = conv3_xs(cout);
+    if (Zt <= 40) {
+        p.mode = 0;
+        p.TZ = Zt;
+        p.nzc = 1;
+        p.pitch = Zt + 2;
+        long long nv = (long long)Yt * Zt;
+        p.npatch = (int)((nv + kPatch - 1) / kPatch);
+        int worst = 0;
+        for (int pa = 0; pa < p.npatch; ++pa) {
+            long long v0 = (long long)pa * kPatch, v1 = v0 + kPatch - 1;
+            if (v1 >= nv) v1 = nv - 1;
+            long long y0 = v0 / Zt, z0 = v0 % Zt, y1 = v1 / Zt, z1 = v1 % Zt;
+            long long plo = y0 * p.pitch + z0;                       // p(v0) - pitch - 1
+            long long phi = (y1 + 1) * p.pitch + (z1 + 1) + p.pitch + 1;
+            int n = (int)(phi - plo + 1);
+            // the last patch may be ragged: its lanes past nv still index the region
+            long long vl = v0 + kPatch - 1;
+            long long yl = vl / Zt, zl = vl % Zt;
+            long long phl = (yl + 1) * p.pitch + (zl + 1) + p.pitch + 1;
+            n = std::max(n, (int)(phl - plo + 1));
+            worst = std::max(worst, n);
+        }
+        p.nposp = (worst + 15) / 16 * 16;
+    } else {
+        p.mode = 1;
+        p.TZ = 32;
+        p.nzc = (Zt + 31) / 32;
+        p.pitch = p.TZ + 2;
+        int TY = kPatch / p.TZ;
+        p.npatch = ((Yt + TY - 1) / TY) * p.nzc;
+        p.nposp = ((TY + 2) * p.pitch + 15) / 16 * 16;
+    }
+    if (p.nposp > 64 * kMaxDma) return -1;
+    p.lds = (size_t)(p.xs + 2) * p.nposp * kPosBytes;
+    // x-chunks: enough workgroups to fill 256 CUs x 2 several times over
+    int target = 256 * 2 * 6;
+    int nxc = (target + p.npatch * B - 1) / (p.npatch * B);
+    int max_nxc = (Xt + 2 * p.xs - 1) / (2 * p.xs);  // at least two steps per chunk
+    if (nxc > max_nxc) nxc = max_nxc;
+    if (nxc < 1) nxc = 1;
+    int XC = (Xt + nxc - 1) / nxc;
+    XC = (XC + p.xs - 1) / p.xs * p.xs;
+    p.XC = XC;
+    p.nxc = (Xt + XC - 1) / XC;
+    return 0;
+}
+
+template <int COUT, int XS>
+int launch_conv3(const Conv3Args& a, const Plan& p, hipStream_t stream) {
+    auto kern = conv3_kernel<COUT, XS>;
+    if (p.lds > 48 * 1024)
+        SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)p.lds));
+    unsigned grid = (unsigned)(p.npatch * p.nxc * a.B);
+    kern<<<grid, 256, p.lds, stream>>>(a);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sk_conv3d_num_blocks(int B, int ox, int oy, int oz, int cout, int ksize) {
+    if (ksize == 3) {
+        Plan p;
+        if (make_plan(p, ox, oy, oz, cout, B)) return -1;
+        return p.npatch * p.nxc;
+    }
+    int pv = cout == 128 ? 1 : 2;
+    long long nv = (long long)ox * oy * oz;
+    return (int)((nv + 128 * pv - 1) / (128 * pv));
+}
+
+int64_t sk_conv3d_pack_weight_host(const float* w, int cout, int cin, int ksize, void* dst) {
+    // torch layout (cout, cin, kx, ky, kz) fp32 -> A fragments of v_mfma_f32_32x32x16_f16:
+    // fragment (1 KiB) = 64 lanes x 8 halves, lane l holds W[cout = 32nt + (l&31)][cin = c0 + 8(l>>5) + j]
+    // ksize 3: order [chunk32][dy*3+dz][ks(2)][dx][nt];  ksize 1/2: order [tap][ks(cin/16)][nt]
+    if (!(ksize == 1 || ksize == 2 || ksize == 3) || cout % 32 || cin % (ksize == 3 ? 32 : 16)) {
+        sk::set_error("sk_conv3d_pack_weight_host: unsupported shape cout=%d cin=%d k=%d", cout, cin, ksize);
+        return SK_ERR_ARG;
+    }
+    const int NT = cout / 32, k3 = ksize * ksize * ksize;
+    int64_t nfrag = (int64_t)k3 * (cin / 16) * NT;
+    if (!dst) return nfrag * 1024;
+    __half* out = (__half*)dst;
+    auto W = [&](int co, int ci, int kx, int ky, int kz) {
+        return w[((((int64_t)co * cin + ci) * ksize + kx) * ksize + ky) * ksize + kz];
+    };
+    int64_t f = 0;
+    auto emit = [&](int nt, int c0, int kx, int ky, int kz) {
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j)
+                out[f * 512 + l * 8 + j] = __float2half(W(32 * nt + (l & 31), c0 + 8 * (l >> 5) + j, kx, ky, kz));
+        ++f;
+    };
+    if (ksize == 3) {
+        for (int ch = 0; ch < cin / 32; ++ch)
+            for (int dydz = 0; dydz < 9; ++dydz)
+                for (int ks = 0; ks < 2; ++ks)
+                    for (int dx = 0; dx < 3; ++dx)
+                        for (int nt = 0; nt < NT; ++nt) emit(nt, ch * 32 + ks * 16, dx, dydz / 3, dydz % 3);
+    } else {
+        for (int tap = 0; tap < k3; ++tap)
+            for (int ks = 0; ks < cin / 16; ++ks)
+                for (int nt = 0; nt < NT; ++nt)
+                    emit(nt, ks * 16, tap / (ksize * ksize), (tap / ksize) % ksize, tap % ksize);
+    }
+    return nfrag * 1024;
+}
+
+int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,
+              int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial,
+              const void* zeros, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SK_CHECK_ARG(srcs && weight && bias && out, "sk_conv3d: NULL pointer");
+    SK_CHECK_ARG(n_src == 1 || n_src == 2, "sk_conv3d: n_src must be 1 or 2");
+    SK_CHECK_ARG(B > 0 && ox > 0 && oy > 0 && oz > 0, "sk_conv3d: bad output extents");
+    SK_CHECK_ARG(cout == 32 || cout == 64 || cout == 128, "sk_conv3d: cout must be 32, 64 or 128");
+    if (ksize == 3) {
+        SK_CHECK_ARG(zeros, "sk_conv3d: zero page is NULL");
+        Conv3Args a{};
+        int cin = 0;
+        for (int i = 0; i < n_src; ++i) {
+            SK_CHECK_ARG(srcs[i].data && srcs[i].c > 0 && srcs[i].c % kChunk == 0,
+                         "sk_conv3d: source %d must have a multiple of 32 channels", i);
+            SK_CHECK_ARG(i == 1 || !srcs[i].upsample, "sk_conv3d: only the second source may be upsampled");
+            int up = srcs[i].upsample ? 1 : 0;
+            SK_CHECK_ARG(!up || (ox % 2 == 0 && oy % 2 == 0 && oz % 2 == 0),
+                         "sk_conv3d: upsampled source needs even output extents");
+            int xs = up ? ox / 2 : ox, ys = up ? oy / 2 : oy, zs = up ? oz / 2 : oz;
+            a.src[i].data = (const char*)srcs[i].data;
+            a.src[i].C = srcs[i].c;
+            a.src[i].up = up;
+            a.src[i].Ys = ys;
+            a.src[i].Zs = zs;
+            a.src[i].plane = (long long)ys * zs * srcs[i].c * 2;
+            a.src[i].batch = a.src[i].plane * xs;
+            cin += srcs[i].c;
+        }
+        if (n_src == 1) a.src[1] = a.src[0];
+        a.nchunks = cin / kChunk;
+        a.c0chunks = srcs[0].c / kChunk;
+        a.wpk = (const char*)weight;
+        a.bias = bias;
+        a.out = (char*)out;
+        a.partial = gn_partial;
+        a.zeros = (const char*)zeros;
+        a.B = B;
+        a.Xt = ox;
+        a.Yt = oy;
+        a.Zt = oz;
+        Plan p;
+        SK_CHECK_ARG(make_plan(p, ox, oy, oz, cout, B) == 0, "sk_conv3d: plane geometry (%d,%d) unsupported", oy, oz);
+        a.XC = p.XC;
+        a.nxc = p.nxc;
+        a.npatch = p.npatch;
+        a.mode = p.mode;
+        a.TZ = p.TZ;
+        a.nzc = p.nzc;
+        a.pitch = p.pitch;
+        a.nposp = p.nposp;
+        if (cout == 32) return launch_conv3<32, 4>(a, p, stream);
+        if (cout == 64) return launch_conv3<64, 4>(a, p, stream);
+        return launch_conv3<128, 2>(a, p, stream);
+    }
+    SK_CHECK_ARG(ksize == 1 || ksize == 2, "sk_conv3d: ksize must be 1, 2 or 3");
+    SK_CHECK_ARG(n_src == 1 && !srcs[0].upsample, "sk_conv3d: ksize %d takes one plain source", ksize);
+    SK_CHECK_ARG(srcs[0].c % 16 == 0, "sk_conv3d: cin must be a multiple of 16");
+    GatherArgs g{};
+    g.in = (const char*)srcs[0].data;
+    g.wpk = (const char*)weight;
+    g.bias = bias;
+    g.out = (char*)out;
+    g.partial = gn_partial;
+    g.B = B;
+    g.Xo = ox;
+    g.Yo = oy;
+    g.Zo = oz;
+    g.Xi = ox * ksize;
+    g.Yi = oy * ksize;
+    g.Zi = oz * ksize;
+    g.Cin = srcs[0].c;
+    g.ksize = ksize;
+    g.nblk = sk_conv3d_num_blocks(B, ox, oy, oz, cout, ksize);
+    unsigned grid = (unsigned)(g.nblk * B);
+    if (cout == 32)
+        gather_gemm_kernel<32, 2><<<grid, 256, 0, stream>>>(g);
+    else if (cout == 64)
+        gather_gemm_kernel<64, 2><<<grid, 256, 0, stream>>>(g);
+    else
+        gather_gemm_kernel<128, 1><<<grid, 256, 0, stream>>>(g);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,311 @@
+// The non-MFMA layers of the U-Net body (oracle/unet_spec.py), all HBM-bound:
+//   * stem conv (Cin = 1, 27 taps): normalise the fp16 image exactly as
+//     skoots/lib/eval.py:139 does (fp16 sub, fp16 div), conv in fp32 on the VALU;
+//   * GroupNorm finalize (deterministic reduction of the conv epilogue partials) and
+//     the fused GroupNorm-affine + SiLU pass, in place, 16 B per lane;
+//   * heads: 1x1x1 conv to 5 channels + tanh / sigmoid, written in the reference's
+//     (B, 5, X, Y, Z) output layout (eval.py:145-147).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------ stem
+struct StemArgs {
+    const __half* image;   // (X, Y, Z) fp16 volume
+    int X, Y, Z;           // volume extents
+    int ox[16], oy[16], oz[16];  // tile origins (B <= 16)
+    int B, Xt, Yt, Zt;     // tile extents
+    float mean, stdv;
+    const float* weight;   // (27, 32) fp32: [tap = (dx*3+dy)*3+dz][cout]
+    const float* bias;     // (32)
+    __half* out;           // (B, Xt, Yt, Zt, 32) fp16 raw
+    float* partial;        // (B, nblk, 8, 2)
+    int nblk;
+};
+
+__global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
+    __shared__ float wsm[27 * 32 + 32];
+    __shared__ float red[4 * 16];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 27 * 32; i += 256) wsm[i] = a.weight[i];
+    if (tid < 32) wsm[27 * 32 + tid] = a.bias[tid];
+    __syncthreads();
+    const int b = blockIdx.x / a.nblk, blk = blockIdx.x % a.nblk;
+    const long long nvox = (long long)a.Xt * a.Yt * a.Zt;
+    long long v = (long long)blk * 256 + tid;
+    const bool ok = v < nvox;
+    long long vv = ok ? v : 0;
+    int z = (int)(vv % a.Zt);
+    long long t = vv / a.Zt;
+    int y = (int)(t % a.Yt), x = (int)(t / a.Yt);
+    const int gx = a.ox[b], gy = a.oy[b], gz = a.oz[b];
+
+    float acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = wsm[27 * 32 + c];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                int xx = x + dx - 1, yy = y + dy - 1, zz = z + dz - 1;
+                float n = 0.0f;  // conv zero padding applies to the NORMALISED tile
+                if (xx >= 0 && xx < a.Xt && yy >= 0 && yy < a.Yt && zz >= 0 && zz < a.Zt) {
+                    float raw = __half2float(
+                        a.image[((long long)(gx + xx) * a.Y + (gy + yy)) * a.Z + (gz + zz)]);
+                    // eval.py:139  crop.sub(mean).div(std) on an fp16 tensor: each op rounds to fp16
+                    float s = __half2float(__float2half_rn(raw - a.mean));
+                    n = __half2float(__float2half_rn(s / a.stdv));
+                }
+                const float* wt = wsm + ((dx * 3 + dy) * 3 + dz) * 32;
+#pragma unroll
+                for (int c = 0; c < 32; ++c) acc[c] = fmaf(wt[c], n, acc[c]);
+            }
+    if (ok) {
+        half8* op = reinterpret_cast<half8*>(a.out + ((long long)b * nvox + v) * 32);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            half8 hv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hv[j] = (_Float16)acc[8 * k + j];
+            op[k] = hv;
+        }
+    }
+    if (a.partial) {
+        const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float s = 0.0f, ss = 0.0f;
+            if (ok) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float u = acc[4 * q + j];
+                    s += u;
+                    ss += u * u;
+                }
+            }
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) {
+                s += __shfl_xor(s, m);
+                ss += __shfl_xor(ss, m);
+            }
+            if (lane == 0) {
+                red[(w * 8 + q) * 2] = s;
+                red[(w * 8 + q) * 2 + 1] = ss;
+            }
+        }
+        __syncthreads();
+        if (tid < 16)
+            a.partial[((long long)b * a.nblk + blk) * 16 + tid] =
+                red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+    }
+}
+
+// ------------------------------------------------------------------------------ GroupNorm
+// partial: (B, nblk, C/4, 2) fp32 -> affine (B, 2, C): a = gamma*rstd, b = beta - mean*a
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partial, int nblk,
+                                                          int groups, int C, double count,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ affine) {
+    __shared__ double qs[64], qss[64];   // per channel quad (C/4 <= 32) x up to 2 halves
+    __shared__ double acc_s[256], acc_ss[256];
+    const int b = blockIdx.x;
+    const int nq = C / 4;
+    const int tid = threadIdx.x;
+    // thread (q, lane-slice): slices of the block list, fixed order -> deterministic
+    const int q = tid % nq, sl = tid / nq, nsl = 256 / nq;
+    double s = 0.0, ss = 0.0;
+    if (sl < nsl)
+        for (int k = sl; k < nblk; k += nsl) {
+            const float* p = partial + (((long long)b * nblk + k) * nq + q) * 2;
+            s += (double)p[0];
+            ss += (double)p[1];
+        }
+    acc_s[tid] = s;
+    acc_ss[tid] = ss;
+    __syncthreads();
+    if (tid < nq) {
+        double a = 0.0, c = 0.0;
+        for (int k = 0; k < nsl; ++k) {
+            a += acc_s[k * nq + tid];
+            c += acc_ss[k * nq + tid];
+        }
+        qs[tid] = a;
+        qss[tid] = c;
+    }
+    __syncthreads();
+    if (tid < C) {
+        const int gs = C / groups;          // channels per group
+        const int g = tid / gs;
+        const int q0 = g * gs / 4, q1 = (g + 1) * gs / 4;
+        double a = 0.0, c = 0.0;
+        for (int k = q0; k < q1; ++k) {
+            a += qs[k];
+            c += qss[k];
+        }
+        double n = count * gs;
+        double mean = a / n;
+        double var = c / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        float ga = gamma[tid] * rstd;
+        affine[((long long)b * 2) * C + tid] = ga;
+        affine[((long long)b * 2 + 1) * C + tid] = beta[tid] - (float)mean * ga;
+    }
+}
+
+// in place: x = silu(a*x + b), 8 channels (16 B) per lane
+__global__ void __launch_bounds__(256) gn_silu_kernel(__half* __restrict__ x,
+                                                      const float* __restrict__ affine, int C,
+                                                      long long nvec_per_batch) {
+    const int b = blockIdx.y;
+    const int vpc = C / 8;  // 16-byte vectors per voxel
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;  // multiple of vpc (C/8 divides 256)
+    const int c0 = (int)(i % vpc) * 8;
+    float ga[8], gb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ga[j] = affine[((long long)b * 2) * C + c0 + j];
+        gb[j] = affine[((long long)b * 2 + 1) * C + c0 + j];
+    }
+    half8* p = reinterpret_cast<half8*>(x) + (long long)b * nvec_per_batch;
+    for (; i < nvec_per_batch; i += stride) {
+        half8 v = p[i];
+        half8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float y = fmaf(ga[j], (float)v[j], gb[j]);
+            float sg = 1.0f / (1.0f + __expf(-y));
+            r[j] = (_Float16)(y * sg);
+        }
+        p[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------ heads
+struct HeadArgs {
+    const __half* x;     // (B, n, C) fp16 activated
+    const float* weight; // (5, C)
+    const float* bias;   // (5)
+    __half* out5;        // (B, 5, n)
+    long long n;
+    int C;
+};
+
+template <int C>
+__global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
+    __shared__ float wsm[5 * C + 8];
+    for (int i = threadIdx.x; i < 5 * C; i += 256) wsm[i] = a.weight[i];
+    if (threadIdx.x < 5) wsm[5 * C + threadIdx.x] = a.bias[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.y;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const half8* p = reinterpret_cast<const half8*>(a.x + ((long long)b * a.n + i) * C);
+    float o[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) o[k] = wsm[5 * C + k];
+#pragma unroll
+    for (int c8 = 0; c8 < C / 8; ++c8) {
+        half8 v = p[c8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)v[j];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) o[k] = fmaf(wsm[k * C + c8 * 8 + j], f, o[k]);
+        }
+    }
+    __half* ob = a.out5 + (long long)b * 5 * a.n + i;
+    ob[0] = __float2half_rn(tanhf(o[0]));
+    ob[a.n] = __float2half_rn(tanhf(o[1]));
+    ob[2 * a.n] = __float2half_rn(tanhf(o[2]));
+    ob[3 * a.n] = __float2half_rn(1.0f / (1.0f + expf(-o[3])));
+    ob[4 * a.n] = __float2half_rn(1.0f / (1.0f + expf(-o[4])));
+}
+
+}  // namespace
+
+extern "C" {
+
+int sk_conv3d_stem_num_blocks(int X, int Y, int Z) {
+    return (int)(((long long)X * Y * Z + 255) / 256);
+}
+
+int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origins_host, int B, int Xt,
+                   int Yt, int Zt, float mean, float stdv, const float* weight, const float* bias,
+                   void* out, int cout, float* gn_partial, void* stream) {
+    SK_CHECK_ARG(image && origins_host && weight && bias && out, "sk_conv3d_stem: NULL pointer");
+    SK_CHECK_ARG(cout == 32, "sk_conv3d_stem: cout must be 32");
+    SK_CHECK_ARG(B >= 1 && B <= 16, "sk_conv3d_stem: batch must be in [1,16]");
+    SK_CHECK_ARG(stdv != 0.0f, "sk_conv3d_stem: std must be non-zero");
+    StemArgs a{};
+    a.image = (const __half*)image;
+    a.X = X;
+    a.Y = Y;
+    a.Z = Z;
+    for (int b = 0; b < B; ++b) {
+        a.ox[b] = origins_host[3 * b];
+        a.oy[b] = origins_host[3 * b + 1];
+        a.oz[b] = origins_host[3 * b + 2];
+        SK_CHECK_ARG(a.ox[b] >= 0 && a.oy[b] >= 0 && a.oz[b] >= 0 && a.ox[b] + Xt <= X &&
+                         a.oy[b] + Yt <= Y && a.oz[b] + Zt <= Z,
+                     "sk_conv3d_stem: tile %d at (%d,%d,%d)+(%d,%d,%d) outside volume (%d,%d,%d)", b,
+                     a.ox[b], a.oy[b], a.oz[b], Xt, Yt, Zt, X, Y, Z);
+    }
+    a.B = B;
+    a.Xt = Xt;
+    a.Yt = Yt;
+    a.Zt = Zt;
+    a.mean = mean;
+    a.stdv = stdv;
+    a.weight = weight;
+    a.bias = bias;
+    a.out = (__half*)out;
+    a.partial = gn_partial;
+    a.nblk = sk_conv3d_stem_num_blocks(Xt, Yt, Zt);
+    stem_kernel<<<(unsigned)(a.nblk * B), 256, 0, (hipStream_t)stream>>>(a);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_groupnorm_finalize(const float* gn_partial, int B, int nblocks, int groups, int C,
+                          int64_t voxels, const float* gamma, const float* beta, float eps,
+                          float* affine, void* stream) {
+    SK_CHECK_ARG(gn_partial && gamma && beta && affine, "sk_groupnorm_finalize: NULL pointer");
+    SK_CHECK_ARG(C % 4 == 0 && C <= 128 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0,
+                 "sk_groupnorm_finalize: C=%d groups=%d unsupported", C, groups);
+    SK_CHECK_ARG(256 % (C / 4) == 0, "sk_groupnorm_finalize: C/4 must divide 256");
+    gn_finalize_kernel<<<B, 256, 0, (hipStream_t)stream>>>(gn_partial, nblocks, groups, C, (double)voxels,
+                                                            gamma, beta, eps, affine);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_groupnorm_silu(void* x, const float* affine, int B, int64_t voxels, int C, void* stream) {
+    SK_CHECK_ARG(x && affine, "sk_groupnorm_silu: NULL pointer");
+    SK_CHECK_ARG(C % 8 == 0 && 256 % (C / 8) == 0, "sk_groupnorm_silu: C=%d unsupported", C);
+    long long nvec = voxels * (C / 8);
+    unsigned gx = sk::stream_grid(nvec, 256, 4);
+    dim3 grid(gx, B);
+    gn_silu_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((__half*)x, affine, C, nvec);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_heads(const void* x, const float* weight, const float* bias, void* out5, int B, int64_t voxels,
+             int C, void* stream) {
+    SK_CHECK_ARG(x && weight && bias && out5, "sk_heads: NULL pointer");
+    SK_CHECK_ARG(C == 32, "sk_heads: C must be 32");
+    HeadArgs a{(const __half*)x, weight, bias, (__half*)out5, voxels, C};
+    dim3 grid(sk::cdiv(voxels, 256), B);
+    heads_kernel<32><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+}  // extern "C"

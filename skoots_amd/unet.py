@@ -1,0 +1,325 @@
+"""HIP runner of the build's U-Net (graph: oracle/unet_spec.py ``UNetSpec``).
+
+Stands where the reference calls ``cfg_to_bism_model(cfg)`` + ``torch.compile`` and
+runs the model on each tile under fp16 autocast (skoots/lib/utils.py:17-107,
+skoots/lib/eval.py:117-124,142-143).  PyTorch only owns the device memory and the
+stream; every layer is a kernel of libskoots_hip.so:
+
+  stem (VALU, Cin=1)  ->  [conv3 MFMA -> GroupNorm finalize -> fused GN+SiLU] x N
+  2x2x2 stride-2 / 1x1x1 convs through the gather GEMM, heads (tanh / sigmoid).
+
+Tiles are read in place from the HBM-resident fp16 volume (no crop copies); a batch of
+B tiles runs per launch so that every launch has >> 256 workgroups.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _ffi
+
+GN_GROUPS = 8
+GN_EPS = 1e-5
+
+
+class _ConvLayer:
+    """One Conv3d -> GroupNorm -> SiLU block with weights packed for the kernels."""
+
+    def __init__(self, prefix: str, sd: Dict[str, Tensor], device, ksize: int):
+        w = sd[prefix + ".conv.weight"].detach().float().cpu().contiguous()
+        self.cout, self.cin = int(w.shape[0]), int(w.shape[1])
+        assert tuple(w.shape[2:]) == (ksize,) * 3, (prefix, tuple(w.shape))
+        self.ksize = ksize
+        self.name = prefix
+        self.bias = sd[prefix + ".conv.bias"].detach().float().to(device).contiguous()
+        self.gamma = sd[prefix + ".norm.weight"].detach().float().to(device).contiguous()
+        self.beta = sd[prefix + ".norm.bias"].detach().float().to(device).contiguous()
+        if self.cin == 1:  # stem: (27, cout) fp32, tap-major
+            assert ksize == 3
+            self.weight = w.reshape(self.cout, 27).t().contiguous().to(device)
+        else:
+            wp = w.numpy()
+            fpt = wp.ctypes.data_as(C.POINTER(C.c_float))
+            nbytes = _ffi.lib.sk_conv3d_pack_weight_host(fpt, self.cout, self.cin, ksize, None)
+            if nbytes < 0:
+                _ffi.check(int(nbytes))
+            buf = np.empty(nbytes, dtype=np.uint8)
+            _ffi.lib.sk_conv3d_pack_weight_host(fpt, self.cout, self.cin, ksize,
+                                                buf.ctypes.data_as(C.c_void_p))
+            self.weight = torch.from_numpy(buf).to(device)
+        self.flops_per_out_voxel = 2.0 * self.cin * self.cout * ksize ** 3
+
+
+class HipUNet:
+    """``model.forward_tiles(image, origins, tile, mean, std) -> (B, 5, w, h, d)`` fp16."""
+
+    def __init__(self, state_dict: Dict[str, Tensor], device="cuda:0",
+                 dims: Sequence[int] = (32, 64, 128, 64, 32),
+                 depths: Sequence[int] = (2, 2, 2, 2, 2)):
+        self.device = torch.device(device)
+        self.dims, self.depths = tuple(dims), tuple(depths)
+        d0, d1, d2, d3, d4 = self.dims
+        if not (d0 == d4 == 32 and d1 == d3 and d1 in (32, 64, 128) and d2 in (32, 64, 128)):
+            raise ValueError(f"unsupported dims {dims}: kernels are built for widths 32/64/128")
+        sd = state_dict
+        dev = self.device
+
+        def stack(name, n):
+            return [_ConvLayer(f"{name}.{i}", sd, dev, 3) for i in range(n)]
+
+        self.enc0 = stack("enc0", depths[0])
+        self.down0 = _ConvLayer("down0", sd, dev, 2)
+        self.enc1 = stack("enc1", depths[1])
+        self.down1 = _ConvLayer("down1", sd, dev, 2)
+        self.mid = stack("mid", depths[2])
+        self.red1 = _ConvLayer("red1", sd, dev, 1)
+        self.dec1 = stack("dec1", depths[3])
+        self.red0 = _ConvLayer("red0", sd, dev, 1)
+        self.dec0 = stack("dec0", depths[4])
+        if self.enc0[0].cin != 1:
+            raise ValueError("the stem kernel is built for IN_CHANNELS == 1")
+        self.head_w = sd["heads.weight"].detach().float().reshape(5, d4).to(dev).contiguous()
+        self.head_b = sd["heads.bias"].detach().float().to(dev).contiguous()
+        self.zeros = torch.zeros(4096, dtype=torch.uint8, device=dev)
+        self._bufs: Dict[Tuple, Tensor] = {}
+        self.last_features: Dict[str, Tensor] = {}
+
+    # -- reference-compatible construction ---------------------------------------------
+    @classmethod
+    def from_module(cls, module: torch.nn.Module, device="cuda:0") -> "HipUNet":
+        return cls(module.state_dict(), device, getattr(module, "dims", (32, 64, 128, 64, 32)),
+                   getattr(module, "depths", (2, 2, 2, 2, 2)))
+
+    # -- buffers -----------------------------------------------------------------------
+    def _buf(self, tag: str, shape: Tuple[int, ...], dtype=torch.float16) -> Tensor:
+        key = (tag, shape, dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            for k in [k for k in self._bufs if k[0] == tag]:
+                del self._bufs[k]
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    # -- layer launchers ---------------------------------------------------------------
+    def _norm_act(self, layer: _ConvLayer, x: Tensor, partial: Tensor, nblk: int) -> None:
+        B = x.shape[0]
+        vox = x.shape[1] * x.shape[2] * x.shape[3]
+        aff = self._buf("affine_" + layer.name, (B, 2, layer.cout), torch.float32)
+        st = _ffi.stream_ptr(self.device)
+        _ffi.check(_ffi.lib.sk_groupnorm_finalize(_ffi.ptr(partial), B, nblk, GN_GROUPS, layer.cout, vox,
+                                                  _ffi.ptr(layer.gamma), _ffi.ptr(layer.beta), GN_EPS,
+                                                  _ffi.ptr(aff), st))
+        _ffi.check(_ffi.lib.sk_groupnorm_silu(_ffi.ptr(x), _ffi.ptr(aff), B, vox, layer.cout, st))
+
+    def _conv(self, layer: _ConvLayer, srcs: List[Tuple[Tensor, int]], out_shape: Tuple[int, int, int],
+              tag: str, activate: bool = True) -> Tensor:
+        B = srcs[0][0].shape[0]
+        ox, oy, oz = out_shape
+        out = self._buf(tag, (B, ox, oy, oz, layer.cout))
+        nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, layer.cout, layer.ksize)
+        if nblk <= 0:
+            raise ValueError(f"{layer.name}: unsupported output shape {out_shape}")
+        partial = self._buf("partial", (B * nblk * (layer.cout // 4) * 2,), torch.float32)
+        arr = (_ffi.ConvSrc * len(srcs))()
+        cin = 0
+        for i, (t, up) in enumerate(srcs):
+            arr[i].data = t.data_ptr()
+            arr[i].c = t.shape[-1]
+            arr[i].upsample = up
+            cin += t.shape[-1]
+        assert cin == layer.cin, (layer.name, cin, layer.cin)
+        _ffi.check(_ffi.lib.sk_conv3d(arr, len(srcs), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
+                                      _ffi.ptr(out), B, ox, oy, oz, layer.cout, layer.ksize,
+                                      _ffi.ptr(partial), _ffi.ptr(self.zeros), _ffi.stream_ptr(self.device)))
+        if activate:
+            self._norm_act(layer, out, partial, nblk)
+        return out
+
+    def _stem(self, layer: _ConvLayer, image: Tensor, origins, tile, mean: float, std: float,
+              tag: str = "L0a") -> Tensor:
+        B = len(origins)
+        X, Y, Z = image.shape
+        xt, yt, zt = tile
+        out = self._buf(tag, (B, xt, yt, zt, layer.cout))
+        nblk = _ffi.lib.sk_conv3d_stem_num_blocks(xt, yt, zt)
+        partial = self._buf("partial", (B * nblk * (layer.cout // 4) * 2,), torch.float32)
+        org = (C.c_int32 * (3 * B))(*[int(v) for o in origins for v in o])
+        _ffi.check(_ffi.lib.sk_conv3d_stem(_ffi.ptr(image), X, Y, Z, org, B, xt, yt, zt, mean, std,
+                                           _ffi.ptr(layer.weight), _ffi.ptr(layer.bias), _ffi.ptr(out),
+                                           layer.cout, _ffi.ptr(partial), _ffi.stream_ptr(self.device)))
+        self._norm_act(layer, out, partial, nblk)
+        return out
+
+    # -- forward -----------------------------------------------------------------------
+    def forward_tiles(self, image: Tensor, origins: Sequence[Sequence[int]], tile: Sequence[int],
+                      mean: float, std: float, keep_features: bool = False) -> Tensor:
+        """image (X, Y, Z) fp16 on the GPU; B tile origins; tile extents (w, h, d)."""
+        _ffi.require_gpu(image, "image")
+        if image.dtype != torch.float16 or image.ndim != 3:
+            raise ValueError("image must be an (X, Y, Z) fp16 tensor")
+        xt, yt, zt = (int(v) for v in tile)
+        if xt % 4 or yt % 4 or zt % 4:
+            raise ValueError(f"tile extents {tuple(tile)} must be multiples of 4 (two stride-2 levels)")
+        B = len(origins)
+        L0, L1, L2 = (xt, yt, zt), (xt // 2, yt // 2, zt // 2), (xt // 4, yt // 4, zt // 4)
+        feats = self.last_features = {}
+
+        def keep(name, t):
+            if keep_features:
+                feats[name] = t.clone()
+
+        a = self._stem(self.enc0[0], image, origins, L0, float(mean), float(std),
+                       "skip0" if len(self.enc0) == 1 else "L0a")
+        keep("enc0.0", a)
+        tags = ["L0b", "L0a"]
+        for i, layer in enumerate(self.enc0[1:]):
+            a = self._conv(layer, [(a, 0)], L0, "skip0" if i == len(self.enc0) - 2 else tags[i % 2])
+            keep(layer.name, a)
+        s0 = a
+        a = self._conv(self.down0, [(s0, 0)], L1, "L1a")
+        keep("down0", a)
+        tags = ["L1b", "L1a"]
+        for i, layer in enumerate(self.enc1):
+            a = self._conv(layer, [(a, 0)], L1, "skip1" if i == len(self.enc1) - 1 else tags[i % 2])
+            keep(layer.name, a)
+        s1 = a
+        a = self._conv(self.down1, [(s1, 0)], L2, "L2a")
+        keep("down1", a)
+        tags = ["L2b", "L2a"]
+        for i, layer in enumerate(self.mid):
+            a = self._conv(layer, [(a, 0)], L2, tags[i % 2])
+            keep(layer.name, a)
+        r1 = self._conv(self.red1, [(a, 0)], L2, "L2r")
+        keep("red1", r1)
+        tags = ["L1a", "L1b"]
+        a = self._conv(self.dec1[0], [(s1, 0), (r1, 1)], L1, tags[0])
+        keep("dec1.0", a)
+        for i, layer in enumerate(self.dec1[1:]):
+            a = self._conv(layer, [(a, 0)], L1, tags[(i + 1) % 2])
+            keep(layer.name, a)
+        r0 = self._conv(self.red0, [(a, 0)], L1, "L1r")
+        keep("red0", r0)
+        tags = ["L0a", "L0b"]
+        a = self._conv(self.dec0[0], [(s0, 0), (r0, 1)], L0, tags[0])
+        keep("dec0.0", a)
+        for i, layer in enumerate(self.dec0[1:]):
+            a = self._conv(layer, [(a, 0)], L0, tags[(i + 1) % 2])
+            keep(layer.name, a)
+        out5 = self._buf("out5", (B, 5, xt, yt, zt))
+        _ffi.check(_ffi.lib.sk_heads(_ffi.ptr(a), _ffi.ptr(self.head_w), _ffi.ptr(self.head_b),
+                                     _ffi.ptr(out5), B, xt * yt * zt, a.shape[-1],
+                                     _ffi.stream_ptr(self.device)))
+        return out5
+
+    def flops_per_tile_voxel(self) -> float:
+        """Algorithmic conv FLOPs per full-resolution tile voxel (2*Cin*Cout*k^3 / downsampling)."""
+        f = 0.0
+        for layers, s in ((self.enc0, 1), ([self.down0], 8), (self.enc1, 8), ([self.down1], 64),
+                          (self.mid, 64), ([self.red1], 64), (self.dec1, 8), ([self.red0], 8),
+                          (self.dec0, 1)):
+            f += sum(l.flops_per_out_voxel for l in layers) / s
+        return f + 2.0 * self.dims[4] * 5
+
+
+def cfg_to_model(cfg, device="cuda:0", state_dict: Optional[Dict[str, Tensor]] = None) -> HipUNet:
+    """Counterpart of ``cfg_to_bism_model`` (skoots/lib/utils.py:17-107): reads the same
+    ``cfg.MODEL`` keys (DIMS, DEPTHS, IN_CHANNELS) from an attribute/dict config."""
+    model = cfg["MODEL"] if isinstance(cfg, dict) else cfg.MODEL
+    get = (lambda k, d: model.get(k, d)) if isinstance(model, dict) else (lambda k, d: getattr(model, k, d))
+    dims, depths = get("DIMS", [32, 64, 128, 64, 32]), get("DEPTHS", [2, 2, 2, 2, 2])
+    if get("IN_CHANNELS", 1) != 1:
+        raise RuntimeError("IN_CHANNELS must be 1")
+    if state_dict is None:
+        raise RuntimeError("a model_state_dict is required (random init lives in oracle/unet_spec.py)")
+    return HipUNet(state_dict, device, dims, depths)
+
+
+def smoke_model(device="cuda:0") -> Optional[HipUNet]:
+    """Deterministic random-init network for __graft_entry__.smoke() (built without the oracle)."""
+    g = torch.Generator().manual_seed(101196)  # train/engine.py:53
+    dims, depths = (32, 64, 128, 64, 32), (2, 2, 2, 2, 2)
+    sd: Dict[str, Tensor] = {}
+
+    def conv(name, cin, cout, k):
+        fan = cin * k ** 3
+        sd[name + ".conv.weight"] = (torch.rand((cout, cin, k, k, k), generator=g) * 2 - 1) / fan ** 0.5
+        sd[name + ".conv.bias"] = (torch.rand(cout, generator=g) * 2 - 1) / fan ** 0.5
+        sd[name + ".norm.weight"] = torch.rand(cout, generator=g) + 0.5
+        sd[name + ".norm.bias"] = torch.rand(cout, generator=g) * 0.6 - 0.3
+
+    d0, d1, d2, d3, d4 = dims
+    for i in range(depths[0]):
+        conv(f"enc0.{i}", 1 if i == 0 else d0, d0, 3)
+    conv("down0", d0, d1, 2)
+    for i in range(depths[1]):
+        conv(f"enc1.{i}", d1, d1, 3)
+    conv("down1", d1, d2, 2)
+    for i in range(depths[2]):
+        conv(f"mid.{i}", d2, d2, 3)
+    conv("red1", d2, d3, 1)
+    for i in range(depths[3]):
+        conv(f"dec1.{i}", d1 + d3 if i == 0 else d3, d3, 3)
+    conv("red0", d3, d4, 1)
+    for i in range(depths[4]):
+        conv(f"dec0.{i}", d0 + d4 if i == 0 else d4, d4, 3)
+    sd["heads.weight"] = (torch.rand((5, d4, 1, 1, 1), generator=g) * 2 - 1) / d4 ** 0.5
+    sd["heads.bias"] = (torch.rand(5, generator=g) * 2 - 1) / d4 ** 0.5
+    return HipUNet(sd, device, dims, depths)
+
+
+# ----------------------------------------------------------------------------------------
+# Operator-level entry points (used by the parity tests and by bench.py's conv-only leg)
+# ----------------------------------------------------------------------------------------
+def pack_conv_weight(weight: Tensor, device) -> Tensor:
+    """(cout, cin, k, k, k) fp32 -> MFMA A-fragment order (fp16 bytes) on the device."""
+    w = weight.detach().float().cpu().contiguous().numpy()
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    fpt = w.ctypes.data_as(C.POINTER(C.c_float))
+    nbytes = _ffi.lib.sk_conv3d_pack_weight_host(fpt, cout, cin, k, None)
+    if nbytes < 0:
+        _ffi.check(int(nbytes))
+    buf = np.empty(nbytes, dtype=np.uint8)
+    _ffi.lib.sk_conv3d_pack_weight_host(fpt, cout, cin, k, buf.ctypes.data_as(C.c_void_p))
+    return torch.from_numpy(buf).to(device)
+
+
+def conv3d(srcs: List[Tuple[Tensor, int]], packed_weight: Tensor, bias: Tensor, cout: int, ksize: int,
+           out_shape: Sequence[int], zeros: Tensor, want_stats: bool = True):
+    """Raw conv (no normalisation): srcs [(B,x,y,z,c) fp16 tensor, upsample flag] ->
+    ((B, ox, oy, oz, cout) fp16, gn_partial (B, nblk, cout/4, 2) fp32 or None)."""
+    B = srcs[0][0].shape[0]
+    dev = srcs[0][0].device
+    ox, oy, oz = (int(v) for v in out_shape)
+    out = torch.empty((B, ox, oy, oz, cout), dtype=torch.float16, device=dev)
+    nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, cout, ksize)
+    if nblk <= 0:
+        raise ValueError(f"unsupported conv output shape {tuple(out_shape)}")
+    partial = torch.zeros((B, nblk, cout // 4, 2), dtype=torch.float32, device=dev) if want_stats else None
+    arr = (_ffi.ConvSrc * len(srcs))()
+    for i, (t, up) in enumerate(srcs):
+        _ffi.require_gpu(t, "src")
+        arr[i].data = t.data_ptr()
+        arr[i].c = t.shape[-1]
+        arr[i].upsample = up
+    _ffi.check(_ffi.lib.sk_conv3d(arr, len(srcs), _ffi.ptr(packed_weight), _ffi.ptr(bias), _ffi.ptr(out), B,
+                                  ox, oy, oz, cout, ksize, _ffi.ptr(partial), _ffi.ptr(zeros),
+                                  _ffi.stream_ptr(dev)))
+    return out, partial
+
+
+def groupnorm_silu_(x: Tensor, partial: Tensor, gamma: Tensor, beta: Tensor, groups: int = GN_GROUPS,
+                    eps: float = GN_EPS) -> Tensor:
+    """In place GroupNorm (statistics from the conv partials) + SiLU on (B, x, y, z, C) fp16."""
+    B, C_ = x.shape[0], x.shape[-1]
+    vox = x[0].numel() // C_
+    aff = torch.empty((B, 2, C_), dtype=torch.float32, device=x.device)
+    st = _ffi.stream_ptr(x.device)
+    _ffi.check(_ffi.lib.sk_groupnorm_finalize(_ffi.ptr(partial), B, partial.shape[1], groups, C_, vox,
+                                              _ffi.ptr(gamma), _ffi.ptr(beta), eps, _ffi.ptr(aff), st))
+    _ffi.check(_ffi.lib.sk_groupnorm_silu(_ffi.ptr(x), _ffi.ptr(aff), B, vox, C_, st))
+    return x
