@@ -65,18 +65,21 @@ int sk_vector_to_embedding(const void* vec, int vec_dtype, float* embed, int w, 
 int sk_index_skeleton_by_embed(const void* labels, int label_dtype, int lx, int ly, int lz,
                                const float* embed, int64_t n, int32_t* out, void* stream);
 
-/* Fused stage 3 (eval.py:245-284): for every voxel of the (X,Y,Z) volume, find the
+/* Fused stage 3 (eval.py:245-284): for every voxel of planes [z_lo, z_hi), find the
  * stage-3 crop that writes it last (owner tables built by the host from the
  * reference's crop generator, cropper.py:97-144), run the N-step follow inside that
  * crop's window with the reference's arithmetic, add the crop origin, gather the
- * label.  vec4: (X,Y,Z,4) fp16.  owner_{x,y,z}: int32[X|Y|Z] crop origin owning each
- * coordinate or -1 (voxel stays 0).  eff_*: effective crop size.  Only planes
- * [z_lo, z_hi) are written (Z-sharding); vec4/labels/out are full-volume pointers.
- * labels int16|int32 (X,Y,Z); out int32 (X,Y,Z). */
+ * label.  (X,Y,Z) is the GLOBAL volume; labels is the full (X,Y,Z) int16|int32 volume.
+ * vec4 ((.,.,.,4) fp16) is an array over the z-window [win_lo, win_hi): shape
+ * (X, Y, win_hi-win_lo, 4) -- the whole volume on one GPU, slab + halo when Z-sharded; the
+ * window must contain every crop that owns a written plane.  out (int32) holds exactly
+ * the written planes: shape (X, Y, z_hi-z_lo).  owner_{x,y,z}:
+ * int32[X|Y|Z] origin of the owning crop per GLOBAL coordinate, or -1 (voxel stays 0). */
 int sk_follow_assign(const void* vec4, const void* labels, int label_dtype, int32_t* out,
-                     int X, int Y, int Z, const int32_t* owner_x, const int32_t* owner_y,
-                     const int32_t* owner_z, int eff_w, int eff_h, int eff_d,
-                     const float* step_scale_host, int n_iter, int z_lo, int z_hi, void* stream);
+                     int X, int Y, int Z, int win_lo, int win_hi, const int32_t* owner_x,
+                     const int32_t* owner_y, const int32_t* owner_z, int eff_w, int eff_h,
+                     int eff_d, const float* step_scale_host, int n_iter, int z_lo, int z_hi,
+                     void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Stage 1 tail: gate + dilate + threshold + interior scatter
@@ -141,6 +144,13 @@ int sk_relabel_lut(int32_t* labels, int64_t n, const int32_t* lut, int lut_size,
  * ------------------------------------------------------------------------ */
 
 size_t sk_renumber_workspace_bytes(int64_t n, int max_label);
+
+/* Distributed renumber, step 1: first[v] = min over this array of the GLOBAL C-order
+ * index of label v (atomicMin into a table the caller pre-filled with 0xFFFFFFFF).
+ * labels is the (X, Y, zl) slab at planes [z_off, z_off+zl) of a volume with Zg planes;
+ * the ranks then all-reduce(MIN) the table, rank it and apply sk_relabel_lut. */
+int sk_first_seen(const int32_t* labels, int X, int Y, int zl, int z_off, int Zg, int max_label,
+                  uint32_t* first, void* stream);
 
 /* Relabel to 1..K by first appearance in C order, 0 preserved, in place.
  * labels int32 (n), values in [0, max_label].  *n_labels (device int32) = K. */

@@ -51,8 +51,8 @@ _SIGS = {
     "sk_vec_deinterleave": (i32, [vp, vp, i64, vp]),
     "sk_vector_to_embedding": (i32, [vp, i32, vp, i32, i32, i32, fp, i32, vp]),
     "sk_index_skeleton_by_embed": (i32, [vp, i32, i32, i32, i32, vp, i64, vp, vp]),
-    "sk_follow_assign": (i32, [vp, vp, i32, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, fp, i32,
-                               i32, i32, vp]),
+    "sk_follow_assign": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, fp,
+                               i32, i32, i32, vp]),
     "sk_gate_dilate_scatter": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp,
                                      i32, i32, i32, f32, f32, vp]),
     "sk_max_filter3d": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -62,6 +62,7 @@ _SIGS = {
     "sk_seam_components_host": (i32, [ip, i32, ip, ip, i32]),
     "sk_relabel_lut": (i32, [vp, i64, vp, i32, vp]),
     "sk_renumber_workspace_bytes": (sz, [i64, i32]),
+    "sk_first_seen": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "sk_renumber": (i32, [vp, i64, i32, vp, sz, vp, vp]),
     "sk_conv3d": (i32, [C.POINTER(ConvSrc), i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "sk_conv3d_num_blocks": (i32, [i32, i32, i32, i32, i32, i32]),

@@ -113,8 +113,9 @@ __global__ void __launch_bounds__(256) index_by_embed_kernel(const L* __restrict
 
 // ---------------------------------------------------------------- fused stage-3 kernel
 struct AssignGeom {
-    int X, Y, Z;
-    int z_lo, z_hi;
+    int X, Y, Z;          // global volume (the label volume)
+    int win_lo, win_hi;   // z-window held by the vec4 / out arrays (Z-sharding: slab + halo)
+    int z_lo, z_hi;       // planes written by this launch (global z)
 };
 
 __device__ __forceinline__ void unpack_vec4(uint2 raw, float& a, float& b, float& c) {
@@ -139,11 +140,13 @@ follow_assign_kernel(const uint2* __restrict__ vec4, const L* __restrict__ label
     long long xy = t / zspan;
     int y = (int)(xy % g.Y);
     int x = (int)(xy / g.Y);
-    long long self = ((long long)x * g.Y + y) * g.Z + z;
+    const int Zl = g.win_hi - g.win_lo;
+    long long self = ((long long)x * g.Y + y) * Zl + (z - g.win_lo);
 
     int ox = own_x[x], oy = own_y[y], oz = own_z[z];
+    const long long oidx = ((long long)x * g.Y + y) * zspan + (z - g.z_lo);  // out is (X, Y, z_hi-z_lo)
     if ((ox | oy | oz) < 0) {  // no crop interior covers this voxel (eval.py:245 zeros)
-        out[self] = 0;
+        out[oidx] = 0;
         return;
     }
     float v0, v1, v2;
@@ -162,7 +165,7 @@ follow_assign_kernel(const uint2* __restrict__ vec4, const L* __restrict__ label
             qy = r / p.d;
             qz = r - qy * p.d;
         }
-        long long gi = ((long long)(ox + qx) * g.Y + (oy + qy)) * g.Z + (oz + qz);
+        long long gi = ((long long)(ox + qx) * g.Y + (oy + qy)) * Zl + (oz + qz - g.win_lo);
         float g0, g1, g2;
         unpack_vec4(vec4[gi], g0, g1, g2);
         if (g0 == 0.0f && g1 == 0.0f && g2 == 0.0f) break;  // fixed point: all later hops add 0
@@ -175,7 +178,7 @@ follow_assign_kernel(const uint2* __restrict__ vec4, const L* __restrict__ label
     int xi = (int)clampf(rintf(ex), 0.0f, (float)(g.X - 1));
     int yi = (int)clampf(rintf(ey), 0.0f, (float)(g.Y - 1));
     int zi = (int)clampf(rintf(ez), 0.0f, (float)(g.Z - 1));
-    out[self] = (int32_t)labels[((long long)xi * g.Y + yi) * g.Z + zi];
+    out[oidx] = (int32_t)labels[((long long)xi * g.Y + yi) * g.Z + zi];
 }
 
 // ---------------------------------------------------------------- layout kernels
@@ -282,14 +285,16 @@ int sk_index_skeleton_by_embed(const void* labels, int label_dtype, int lx, int 
 }
 
 int sk_follow_assign(const void* vec4, const void* labels, int label_dtype, int32_t* out, int X,
-                     int Y, int Z, const int32_t* owner_x, const int32_t* owner_y,
-                     const int32_t* owner_z, int eff_w, int eff_h, int eff_d,
+                     int Y, int Z, int win_lo, int win_hi, const int32_t* owner_x,
+                     const int32_t* owner_y, const int32_t* owner_z, int eff_w, int eff_h, int eff_d,
                      const float* step_scale_host, int n_iter, int z_lo, int z_hi, void* stream) {
     SK_CHECK_ARG(vec4 && labels && out && owner_x && owner_y && owner_z,
                  "sk_follow_assign: NULL pointer");
     SK_CHECK_ARG(X > 0 && Y > 0 && Z > 0, "sk_follow_assign: bad volume extents");
-    SK_CHECK_ARG(0 <= z_lo && z_lo <= z_hi && z_hi <= Z, "sk_follow_assign: bad z range [%d,%d)",
-                 z_lo, z_hi);
+    SK_CHECK_ARG(0 <= win_lo && win_lo < win_hi && win_hi <= Z,
+                 "sk_follow_assign: bad z window [%d,%d) for Z=%d", win_lo, win_hi, Z);
+    SK_CHECK_ARG(win_lo <= z_lo && z_lo <= z_hi && z_hi <= win_hi,
+                 "sk_follow_assign: z range [%d,%d) outside window [%d,%d)", z_lo, z_hi, win_lo, win_hi);
     SK_CHECK_ARG(eff_w <= X && eff_h <= Y && eff_d <= Z, "sk_follow_assign: crop exceeds volume");
     SK_CHECK_ARG(label_dtype == SK_I16 || label_dtype == SK_I32,
                  "sk_follow_assign: labels must be int16 or int32");
@@ -297,7 +302,7 @@ int sk_follow_assign(const void* vec4, const void* labels, int label_dtype, int3
     FollowParams p;
     int rc = fill_params(p, eff_w, eff_h, eff_d, step_scale_host, n_iter);
     if (rc) return rc;
-    AssignGeom g{X, Y, Z, z_lo, z_hi};
+    AssignGeom g{X, Y, Z, win_lo, win_hi, z_lo, z_hi};
     long long total = (long long)X * Y * (z_hi - z_lo);
     SK_CHECK_ARG(total / 256 < 0x7fffffffLL, "sk_follow_assign: volume too large for one launch");
     unsigned grid = sk::cdiv(total, 256);

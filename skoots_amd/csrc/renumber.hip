@@ -27,6 +27,23 @@ __global__ void __launch_bounds__(256) first_seen_kernel(const int32_t* __restri
     }
 }
 
+__global__ void __launch_bounds__(256) first_seen_slab_kernel(const int32_t* __restrict__ labels,
+                                                              int Y, int zl, int z_off, int Zg,
+                                                              long long n, int max_label,
+                                                              unsigned* __restrict__ first) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        int v = labels[i];
+        if (v <= 0 || v > max_label) continue;
+        int z = (int)(i % zl);
+        if (z > 0 && labels[i - 1] == v) continue;
+        long long xy = i / zl;
+        unsigned gidx = (unsigned)(xy * Zg + z_off + z);
+        if (first[v] > gidx) atomicMin(&first[v], gidx);
+    }
+}
+
 __global__ void __launch_bounds__(256) mark_kernel(const unsigned* __restrict__ first, int max_label,
                                                    unsigned* __restrict__ bitmap) {
     int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,6 +183,19 @@ extern "C" {
 size_t sk_renumber_workspace_bytes(int64_t n, int max_label) {
     if (n <= 0 || max_label < 0) return 0;
     return layout(n, max_label).total;
+}
+
+int sk_first_seen(const int32_t* labels, int X, int Y, int zl, int z_off, int Zg, int max_label,
+                  uint32_t* first, void* stream) {
+    SK_CHECK_ARG(labels && first, "sk_first_seen: NULL pointer");
+    SK_CHECK_ARG(X > 0 && Y > 0 && zl > 0 && z_off >= 0 && z_off + zl <= Zg && max_label >= 0,
+                 "sk_first_seen: bad extents");
+    SK_CHECK_ARG((long long)X * Y * Zg <= 0xFFFFFFFELL, "sk_first_seen: volume too large");
+    long long n = (long long)X * Y * zl;
+    first_seen_slab_kernel<<<sk::stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(
+        labels, Y, zl, z_off, Zg, n, max_label, first);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
 }
 
 int sk_renumber(int32_t* labels, int64_t n, int max_label, void* workspace, size_t workspace_bytes,

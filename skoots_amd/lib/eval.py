@@ -47,16 +47,23 @@ def thresholds_for(dtype: torch.dtype) -> Tuple[float, float]:
 
 
 class VolumeState:
-    """HBM-resident arrays of one volume (or one Z-slab of it)."""
+    """HBM-resident arrays of one volume, or of one rank's z-window of it (slab + halo).
 
-    def __init__(self, shape: Sequence[int], device, keep_planar_vectors: bool = False):
+    ``shape`` is the GLOBAL (X, Y, Z); ``window`` = (w_lo, w_hi) are the planes the local
+    arrays cover (the whole volume on one GPU)."""
+
+    def __init__(self, shape: Sequence[int], device, window: Optional[Tuple[int, int]] = None,
+                 keep_planar_vectors: bool = False):
         X, Y, Z = (int(s) for s in shape)
         self.shape = (X, Y, Z)
+        self.window = (0, Z) if window is None else (int(window[0]), int(window[1]))
+        zl = self.window[1] - self.window[0]
+        self.local_shape = (X, Y, zl)
         self.device = torch.device(device)
-        # vectors: interleaved (X,Y,Z,4) fp16 -- zero = the never-written frame (eval.py:103)
-        self.vec4 = torch.zeros((X, Y, Z, 4), dtype=torch.float16, device=device)
-        self.skeleton = torch.zeros((X, Y, Z), dtype=torch.uint8, device=device)  # eval.py:102
-        self.vec_planar = (torch.zeros((3, X, Y, Z), dtype=torch.float16, device=device)
+        # vectors: interleaved (X,Y,Zl,4) fp16 -- zero = the never-written frame (eval.py:103)
+        self.vec4 = torch.zeros((X, Y, zl, 4), dtype=torch.float16, device=device)
+        self.skeleton = torch.zeros((X, Y, zl), dtype=torch.uint8, device=device)  # eval.py:102
+        self.vec_planar = (torch.zeros((3, X, Y, zl), dtype=torch.float16, device=device)
                            if keep_planar_vectors else None)
         self.labels: Optional[Tensor] = None
         self.instance: Optional[Tensor] = None
@@ -64,19 +71,21 @@ class VolumeState:
     # -- stage 1 tail ------------------------------------------------------------------
     def scatter_tile(self, out5: Tensor, origin: Sequence[int], overlap=TILE_OVERLAP) -> None:
         """Gate + dilate + threshold + interior scatter of one tile's network output
-        (5, w, h, d) fp16/fp32 (eval.py:145-176)."""
+        (5, w, h, d) fp16/fp32 (eval.py:145-176); ``origin`` in GLOBAL coordinates."""
         _ffi.require_gpu(out5, "out5")
         assert out5.ndim == 4 and out5.shape[0] == 5
         _, w, h, d = out5.shape
-        X, Y, Z = self.shape
+        X, Y, zl = self.local_shape
         pthr, sthr = thresholds_for(out5.dtype)
         _ffi.check(_ffi.lib.sk_gate_dilate_scatter(
-            _ffi.ptr(out5), _ffi.dtype_code(out5), w, h, d, origin[0], origin[1], origin[2],
-            overlap[0], overlap[1], overlap[2], _ffi.ptr(self.vec4), _ffi.ptr(self.vec_planar),
-            _ffi.ptr(self.skeleton), X, Y, Z, pthr, sthr, _ffi.stream_ptr(self.device)))
+            _ffi.ptr(out5), _ffi.dtype_code(out5), w, h, d, origin[0], origin[1],
+            origin[2] - self.window[0], overlap[0], overlap[1], overlap[2], _ffi.ptr(self.vec4),
+            _ffi.ptr(self.vec_planar), _ffi.ptr(self.skeleton), X, Y, zl, pthr, sthr,
+            _ffi.stream_ptr(self.device)))
 
     # -- stage 2 -----------------------------------------------------------------------
     def label(self) -> Tensor:
+        assert self.window == (0, self.shape[2]), "label() is the single-GPU path"
         self.labels = label_skeleton(self.skeleton)
         return self.labels
 
@@ -84,21 +93,27 @@ class VolumeState:
     def assign(self, scale, n: int = FOLLOW_N, decay: float = 1.0, crop=ASSIGN_CROP,
                overlap=ASSIGN_OVERLAP, labels: Optional[Tensor] = None,
                z_range: Optional[Tuple[int, int]] = None) -> Tensor:
-        """Follow + assign for every voxel (eval.py:245-284); ``instance`` int32 (X,Y,Z)."""
+        """Follow + assign for the planes ``z_range`` (eval.py:245-284) against the FULL
+        (X, Y, Z) label volume; returns ``instance`` int32 (X, Y, planes)."""
         labels = self.labels if labels is None else labels
         assert labels is not None, "run label() first"
         X, Y, Z = self.shape
+        assert tuple(labels.shape) == (X, Y, Z), "labels must be the full-volume label array"
         eff = cropper.clamp_crop_(list(crop), (X, Y, Z))
-        own = [torch.from_numpy(cropper.owner_table(dm, c, o)).to(self.device)
-               for dm, c, o in zip((X, Y, Z), eff, overlap)]
-        if self.instance is None:
-            self.instance = torch.zeros((X, Y, Z), dtype=torch.int32, device=self.device)
+        tables = [cropper.owner_table(dm, c, o) for dm, c, o in zip((X, Y, Z), eff, overlap)]
         z_lo, z_hi = (0, Z) if z_range is None else z_range
+        oz = tables[2][z_lo:z_hi]
+        oz = oz[oz >= 0]
+        if oz.size:
+            assert self.window[0] <= oz.min() and oz.max() + eff[2] <= self.window[1], (
+                "a stage-3 crop reaches outside the rank's window: increase the halo")
+        own = [torch.from_numpy(t).to(self.device) for t in tables]
+        self.instance = torch.zeros((X, Y, z_hi - z_lo), dtype=torch.int32, device=self.device)
         sc = step_scales(scale, n, decay)
         _ffi.check(_ffi.lib.sk_follow_assign(
             _ffi.ptr(self.vec4), _ffi.ptr(labels), _ffi.dtype_code(labels), _ffi.ptr(self.instance),
-            X, Y, Z, _ffi.ptr(own[0]), _ffi.ptr(own[1]), _ffi.ptr(own[2]), eff[0], eff[1], eff[2],
-            _ffi.float_array(sc), n, z_lo, z_hi, _ffi.stream_ptr(self.device)))
+            X, Y, Z, self.window[0], self.window[1], _ffi.ptr(own[0]), _ffi.ptr(own[1]), _ffi.ptr(own[2]),
+            eff[0], eff[1], eff[2], _ffi.float_array(sc), n, z_lo, z_hi, _ffi.stream_ptr(self.device)))
         self._own = own  # keep the tables alive until the stream has consumed them
         return self.instance
 
@@ -118,8 +133,8 @@ class VolumeState:
         return int(k.item())
 
     def vectors_planar(self) -> Tensor:
-        """(3, X, Y, Z) fp16, the layout of the reference's ``vectors`` array."""
-        X, Y, Z = self.shape
+        """(3, X, Y, Zl) fp16, the layout of the reference's ``vectors`` array."""
+        X, Y, Z = self.local_shape
         out = torch.empty((3, X, Y, Z), dtype=torch.float16, device=self.device)
         _ffi.check(_ffi.lib.sk_vec_deinterleave(_ffi.ptr(self.vec4), _ffi.ptr(out), X * Y * Z,
                                                 _ffi.stream_ptr(self.device)))
@@ -137,16 +152,16 @@ def eval_volume(image: Tensor, model, scale, mean=None, std=None, n: int = FOLLO
                 tile=TILE, tile_overlap=TILE_OVERLAP, tile_batch: int = 4,
                 inject: Optional[Callable] = None, keep_planar_vectors: bool = False,
                 timings: Optional[Dict[str, float]] = None) -> Dict[str, Tensor]:
-    """In-memory variant of :func:`eval`: (1, X, Y, Z) or (X, Y, Z) image on the GPU ->
-    instance mask, vectors, skeleton, labels (all HBM-resident tensors).
+    """In-memory variant of :func:`eval` on one GPU: (1, X, Y, Z) or (X, Y, Z) image on the
+    device -> instance mask, vectors, skeleton, labels (all HBM-resident tensors).
 
-    ``model`` is a :class:`skoots_amd.unet.HipUNet` (``model.forward_tiles``);
-    ``inject(out5, origin, eff) -> out5`` may replace a tile's network output (tests
-    and the assignment-workload generator of bench.py use it).
+    ``model`` is a :class:`skoots_amd.unet.HipUNet`; ``inject(out5, origin, eff) -> out5``
+    may replace a tile's network output (parity tests and bench.py's assignment workload
+    use it).  The multi-GPU form is :class:`skoots_amd.parallel.ShardedVolume`.
     """
+    from ..parallel import ShardedVolume
     img = image.squeeze(0) if image.ndim == 4 else image
     _ffi.require_gpu(img, "image")
-    dev = img.device
     img16 = img if img.dtype == torch.float16 else img.to(torch.float16)  # eval.py:80
     if mean is None or std is None:
         # eval.py:87-88 fallback: statistics of the fp16 image, evaluated by the same torch
@@ -154,36 +169,10 @@ def eval_volume(image: Tensor, model, scale, mean=None, std=None, n: int = FOLLO
         cpu = img16.cpu()
         mean = float(cpu.mean()) if mean is None else mean
         std = float(cpu.std()) if std is None else std
-    X, Y, Z = img16.shape
-    state = VolumeState((X, Y, Z), dev, keep_planar_vectors)
-
-    def tick(name, t0):
-        if timings is not None:
-            torch.cuda.synchronize(dev)
-            timings[name] = timings.get(name, 0.0) + (time.perf_counter() - t0)
-
-    t0 = time.perf_counter()
-    origins, eff = tile_grid((X, Y, Z), tile, tile_overlap)
-    for i in range(0, len(origins), tile_batch):
-        batch = origins[i:i + tile_batch]
-        out5 = model.forward_tiles(img16, batch, eff, float(mean), float(std)) if model is not None else None
-        for b, org in enumerate(batch):
-            o = out5[b] if out5 is not None else None
-            if inject is not None:
-                o = inject(o, org, eff)
-            state.scatter_tile(o, org, tile_overlap)
-    tick("stage1", t0)
-
-    t0 = time.perf_counter()
-    state.label()
-    tick("stage2", t0)
-
-    t0 = time.perf_counter()
-    state.assign(scale, n=n)
-    tick("stage3", t0)
-
-    t0 = time.perf_counter()
-    k = state.renumber()
-    tick("renumber", t0)
-    return {"instance_mask": state.instance, "labels": state.labels, "skeleton": state.skeleton,
-            "vec4": state.vec4, "vectors": state.vec_planar, "n_instances": k, "state": state}
+    sv = ShardedVolume(tuple(img16.shape), 0, 1, img16.device)
+    res = sv.run(img16.contiguous(), model, scale, float(mean), float(std), n=n, tile=tile,
+                 tile_overlap=tile_overlap, tile_batch=tile_batch, inject=inject,
+                 keep_planar_vectors=keep_planar_vectors)
+    if timings is not None:
+        timings.update(sv.timings)
+    return res

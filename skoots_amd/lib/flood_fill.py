@@ -93,6 +93,88 @@ def label_skeleton(skeleton_u8: Tensor, crop=FLOOD_CROP) -> Tensor:
     return labels
 
 
+def label_slab(skeleton_win: Tensor, shape, slab, window, slabs, rank: int, comm):
+    """Z-sharded labelling.  ``skeleton_win``: this rank's (X, Y, window) uint8 mask.
+    Labels the rank's slab, merges components across slab boundaries (exchange of the
+    boundary label planes + all-gather of the seam equivalences) and all-gathers the
+    slabs.  Returns (full (X, Y, Z) int32 label volume, number of labels before merging).
+    Ids are 1..K in rank order, not the single-GPU flood-grid numbering; the partition
+    (what stage 3 and renumber consume) is identical."""
+    X, Y, Z = shape
+    dev = skeleton_win.device
+    st = _ffi.stream_ptr(dev)
+    zlo, zhi = slab
+    zl = zhi - zlo
+    w0 = window[0]
+    local = torch.zeros((X, Y, skeleton_win.shape[2]), dtype=torch.int32, device=dev)
+    ws_bytes = _ffi.lib.sk_ccl_workspace_bytes(X * Y * zl)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    state = torch.tensor([-1, 0, 0, 0], dtype=torch.int32, device=dev)  # first id = state[0] + 2 = 1
+    _ffi.check(_ffi.lib.sk_ccl_crop(_ffi.ptr(skeleton_win), _ffi.ptr(local), X, Y, skeleton_win.shape[2],
+                                    0, 0, zlo - w0, X, Y, zl, _ffi.ptr(ws), ws_bytes, _ffi.ptr(state), st))
+    del ws
+    mine = local[:, :, zlo - w0:zhi - w0].contiguous()
+    k_local = int(state[1].item())
+    counts = [int(t.item()) for t in comm.all_gather(torch.tensor([k_local], dtype=torch.int64, device=dev))]
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    total = int(offsets[-1])
+    off = int(offsets[rank])
+    # boundary planes: the first plane of every slab goes to the rank below it
+    world = len(slabs)
+    sends, like = [], []
+    if rank > 0:
+        sends.append((rank - 1, mine[:, :, 0].contiguous()))
+    if rank < world - 1:
+        like.append((rank + 1, torch.empty((X, Y), dtype=torch.int32, device=dev)))
+    got = comm.exchange(sends, like)
+    pairs_np = np.zeros((0, 2), dtype=np.int32)
+    if rank < world - 1:
+        upper = got[0]
+        two = torch.stack([mine[:, :, zl - 1] + (mine[:, :, zl - 1] > 0) * off,
+                           upper + (upper > 0) * int(offsets[rank + 1])], dim=2).to(torch.int32).contiguous()
+        cap = X * Y
+        pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        _ffi.check(_ffi.lib.sk_seam_pairs(_ffi.ptr(two), X, Y, 2, 2, 1, _ffi.ptr(pairs), _ffi.ptr(count), cap, st))
+        n = int(count.item())
+        if n:
+            pairs_np = np.unique(pairs[:n].cpu().numpy(), axis=0)
+    # all-gather the (few) seam equivalences, padded to a common length
+    lens = [int(t.item()) for t in comm.all_gather(torch.tensor([len(pairs_np)], dtype=torch.int64, device=dev))]
+    mx = max(max(lens), 1)
+    pad = np.zeros((mx, 2), dtype=np.int32)
+    pad[:len(pairs_np)] = pairs_np
+    allp = [t.cpu().numpy()[:l] for t, l in zip(comm.all_gather(torch.from_numpy(pad).to(dev)), lens)]
+    allp = np.ascontiguousarray(np.concatenate(allp, axis=0).astype(np.int32))
+    lut = np.arange(total + 1, dtype=np.int32)
+    if len(allp):
+        to_rep = np.empty(2 * len(allp), dtype=np.int32)
+        rep_with = np.empty(2 * len(allp), dtype=np.int32)
+        ip = C.POINTER(C.c_int32)
+        k = _ffi.lib.sk_seam_components_host(allp.ctypes.data_as(ip), len(allp), to_rep.ctypes.data_as(ip),
+                                             rep_with.ctypes.data_as(ip), 2 * len(allp))
+        if k < 0:
+            _ffi.check(k)
+        lut[to_rep[:k]] = rep_with[:k]
+    # local id l (1..k_local) -> merged global id
+    my_lut = np.zeros(k_local + 1, dtype=np.int32)
+    my_lut[1:] = lut[off + 1:off + k_local + 1]
+    if k_local:
+        lut_d = torch.from_numpy(my_lut).to(dev)
+        _ffi.check(_ffi.lib.sk_relabel_lut(_ffi.ptr(mine), mine.numel(), _ffi.ptr(lut_d), k_local + 1, st))
+        torch.cuda.current_stream(dev).synchronize()
+    # all-gather the slabs into the full label volume (slabs may differ in thickness by one plane)
+    zmax = max(b - a for a, b in slabs)
+    if zl < zmax:
+        padded = torch.zeros((X, Y, zmax), dtype=torch.int32, device=dev)
+        padded[:, :, :zl] = mine
+    else:
+        padded = mine
+    parts = comm.all_gather(padded)
+    full = torch.cat([p[:, :, :b - a] for p, (a, b) in zip(parts, slabs)], dim=2).contiguous()
+    return full, total
+
+
 def efficient_flood_fill(skeleton: Tensor) -> Tensor:
     """Labels every 6-connected component of a binary skeleton mask.
 

@@ -1,0 +1,234 @@
+"""Z-sharded execution of the eval hot path: one process per GPU, ``torch.distributed``
+(backend "nccl" = RCCL over xGMI on the MI355X node; "gloo" for the CPU / single-GPU
+rehearsals in tests/).
+
+The reference is single device (skoots/lib/eval.py:57).  The path shards naturally:
+
+  stage 1  tiles are independent.  Rank r owns the planes [z_lo, z_hi) of the volume and
+           evaluates every tile (global 300x300x20 grid, unchanged) that is the last
+           writer of one of its planes; tiles straddling a slab boundary are evaluated by
+           both neighbours (no stage-1 collective; input halo comes with the image).
+  stage 2  each rank labels its slab; the label planes either side of every slab
+           boundary are exchanged, the (few) seam equivalences are all-gathered and
+           every rank applies the same union to its slab.  The slabs are then
+           all-gathered into the full label volume: a 10-step follow can end ~165 planes
+           away from where it started, more than two 64-plane slabs.
+  stage 3  vectors are exchanged with the neighbours (window = slab +- halo) and
+           sk_follow_assign runs on the rank's planes against the full label volume.
+  renumber first-appearance positions are all-reduced (MIN) so that every rank derives
+           the same 1..K numbering.
+
+xGMI is point to point (7 links x ~153 GB/s per GPU): the halo traffic rides one link
+per neighbour, the all-gather uses all of them; both are small next to stage 1.
+With world == 1 this is exactly the single-GPU pipeline of ``skoots_amd.lib.eval``.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from .lib import cropper
+
+HALO = 64  # planes kept either side of the slab: >= 45 (stage-3 crop reach) and tile depth reach
+
+
+def slab_bounds(Z: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, near-equal plane ranges; rank r owns [lo, hi)."""
+    return [(Z * r // world, Z * (r + 1) // world) for r in range(world)]
+
+
+def window_of(slab: Tuple[int, int], Z: int, world: int, halo: int = HALO) -> Tuple[int, int]:
+    if world == 1:
+        return (0, Z)
+    return (max(0, slab[0] - halo), min(Z, slab[1] + halo))
+
+
+def tiles_for_slab(shape: Sequence[int], tile: Sequence[int], overlap: Sequence[int],
+                   slab: Tuple[int, int]) -> Tuple[List[Tuple[int, int, int]], List[int]]:
+    """Distinct tile origins (reference order) that write at least one plane of ``slab``
+    last, plus the effective tile size (cropper.py:97-144 grid, eval.py:160-176 scatter)."""
+    eff = list(tile)
+    origins = cropper.distinct_origins(shape, eff, overlap)
+    own_z = cropper.owner_table(shape[2], eff[2], overlap[2])
+    mine = set(int(v) for v in np.unique(own_z[slab[0]:slab[1]]) if v >= 0)
+    return [o for o in origins if o[2] in mine], eff
+
+
+def halo_plan(slabs: List[Tuple[int, int]], windows: List[Tuple[int, int]], rank: int):
+    """(sends, recvs): lists of (peer, z_lo, z_hi) plane ranges (global z).  Rank r sends
+    the part of its slab that falls into a peer's window and receives the parts of its
+    own window owned by peers."""
+    sends, recvs = [], []
+    my_slab, my_win = slabs[rank], windows[rank]
+    for q in range(len(slabs)):
+        if q == rank:
+            continue
+        lo, hi = max(my_slab[0], windows[q][0]), min(my_slab[1], windows[q][1])
+        if lo < hi:
+            sends.append((q, lo, hi))
+        lo, hi = max(slabs[q][0], my_win[0]), min(slabs[q][1], my_win[1])
+        if lo < hi:
+            recvs.append((q, lo, hi))
+    return sends, recvs
+
+
+class Comm:
+    """Thin wrapper: RCCL moves device tensors directly; gloo stages through the host."""
+
+    def __init__(self, rank: int, world: int):
+        self.rank, self.world = rank, world
+        self.staged = world > 1 and dist.get_backend() == "gloo"
+
+    def _out(self, t: Tensor) -> Tensor:
+        return t.cpu() if (self.staged and t.is_cuda) else t
+
+    def all_gather(self, t: Tensor) -> List[Tensor]:
+        if self.world == 1:
+            return [t]
+        src = self._out(t.contiguous())
+        outs = [torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(outs, src)
+        return [o.to(t.device) for o in outs]
+
+    def all_reduce_min(self, t: Tensor) -> Tensor:
+        if self.world == 1:
+            return t
+        src = self._out(t)
+        dist.all_reduce(src, op=dist.ReduceOp.MIN)
+        return src.to(t.device)
+
+    def exchange(self, sends: List[Tuple[int, Tensor]], recv_like: List[Tuple[int, Tensor]]) -> List[Tensor]:
+        """Point-to-point batch: sends [(peer, tensor)], recv_like [(peer, empty tensor)]."""
+        if self.world == 1:
+            return []
+        ops, staged_recv = [], []
+        for peer, t in sends:
+            ops.append(dist.P2POp(dist.isend, self._out(t.contiguous()), peer))
+        for peer, t in recv_like:
+            buf = self._out(t) if not self.staged else torch.empty(t.shape, dtype=t.dtype)
+            staged_recv.append(buf)
+            ops.append(dist.P2POp(dist.irecv, buf, peer))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return [b.to(t.device) for b, (_, t) in zip(staged_recv, recv_like)]
+
+
+def exchange_halo(arr: Tensor, slabs, windows, rank: int, comm: Comm) -> None:
+    """Fill the halo planes of a window-shaped array (X, Y, Zl, ...) from their owners."""
+    sends, recvs = halo_plan(slabs, windows, rank)
+    w0 = windows[rank][0]
+    out = [(q, arr[:, :, lo - w0:hi - w0]) for q, lo, hi in sends]
+    like = [(q, torch.empty_like(arr[:, :, lo - w0:hi - w0])) for q, lo, hi in recvs]
+    got = comm.exchange(out, like)
+    for (q, lo, hi), t in zip(recvs, got):
+        arr[:, :, lo - w0:hi - w0] = t
+
+
+class ShardedVolume:
+    """One rank's share of a volume: runs stages 1-3 + renumber, collectives included."""
+
+    def __init__(self, shape: Sequence[int], rank: int, world: int, device, halo: int = HALO):
+        self.shape = tuple(int(v) for v in shape)
+        self.rank, self.world = rank, world
+        self.device = torch.device(device)
+        self.slabs = slab_bounds(self.shape[2], world)
+        self.windows = [window_of(s, self.shape[2], world, halo) for s in self.slabs]
+        self.slab, self.window = self.slabs[rank], self.windows[rank]
+        self.timings: Dict[str, float] = {}
+
+    def _tick(self, name: str, t0: float) -> None:
+        torch.cuda.synchronize(self.device)
+        self.timings[name] = self.timings.get(name, 0.0) + time.perf_counter() - t0
+
+    def run(self, image: Tensor, model, scale, mean: float, std: float, n: int = 10,
+            decay: float = 1.0, tile=(300, 300, 20), tile_overlap=(50, 50, 5), tile_batch: int = 4,
+            inject: Optional[Callable] = None, keep_planar_vectors: bool = False,
+            conv_profile=None) -> Dict[str, object]:
+        """``image``: this rank's window of the fp16 volume, shape (X, Y, window planes)."""
+        from . import _ffi
+        from .lib.eval import ASSIGN_CROP, ASSIGN_OVERLAP, VolumeState
+        from .lib.flood_fill import label_skeleton, label_slab
+
+        X, Y, Z = self.shape
+        (zlo, zhi), (wlo, whi) = self.slab, self.window
+        dev = self.device
+        comm = Comm(self.rank, self.world)
+        assert tuple(image.shape) == (X, Y, whi - wlo), (tuple(image.shape), (X, Y, whi - wlo))
+        state = VolumeState(self.shape, dev, window=self.window, keep_planar_vectors=keep_planar_vectors)
+
+        # ---- stage 1 --------------------------------------------------------------------
+        t0 = time.perf_counter()
+        origins, eff = tiles_for_slab(self.shape, tile, tile_overlap, self.slab)
+        for (_, _, oz) in origins:
+            assert wlo <= oz and oz + eff[2] <= whi, "tile outside the rank's window: increase the halo"
+        if model is not None and conv_profile is not None:
+            model.profile = conv_profile
+        for i in range(0, len(origins), tile_batch):
+            batch = origins[i:i + tile_batch]
+            local = [(x, y, z - wlo) for (x, y, z) in batch]
+            out5 = model.forward_tiles(image, local, eff, mean, std) if model is not None else None
+            for b, org in enumerate(batch):
+                o = out5[b] if out5 is not None else None
+                if inject is not None:
+                    o = inject(o, (org[0], org[1], org[2] - wlo), eff)
+                state.scatter_tile(o, org, tile_overlap)
+        if model is not None:
+            model.profile = None
+        self._tick("stage1", t0)
+
+        # ---- stage 2 --------------------------------------------------------------------
+        t0 = time.perf_counter()
+        if self.world == 1:
+            labels = label_skeleton(state.skeleton)
+            n_labels_hint = None
+        else:
+            labels, n_labels_hint = label_slab(state.skeleton, self.shape, self.slab, self.window,
+                                               self.slabs, self.rank, comm)
+        state.labels = labels
+        self._tick("stage2", t0)
+
+        # ---- stage 3 --------------------------------------------------------------------
+        t0 = time.perf_counter()
+        if self.world > 1:
+            exchange_halo(state.vec4, self.slabs, self.windows, self.rank, comm)
+        inst = state.assign(scale, n=n, decay=decay, crop=ASSIGN_CROP, overlap=ASSIGN_OVERLAP,
+                            labels=labels, z_range=self.slab)
+        self._tick("stage3", t0)
+
+        # ---- renumber -------------------------------------------------------------------
+        t0 = time.perf_counter()
+        if self.world == 1:
+            k = state.renumber()
+        else:
+            k = distributed_renumber(inst, self.shape, self.slab, int(n_labels_hint), comm)
+        self._tick("renumber", t0)
+        return {"instance_mask": inst, "labels": labels, "skeleton": state.skeleton, "vec4": state.vec4,
+                "vectors": state.vec_planar, "n_instances": k, "state": state, "slab": self.slab,
+                "window": self.window}
+
+
+def distributed_renumber(inst: Tensor, shape, slab, max_label: int, comm: Comm) -> int:
+    """fastremap.renumber semantics (eval.py:304-306) across ranks: ids 1..K by first
+    appearance in the GLOBAL C order.  ``inst`` is this rank's (X, Y, slab planes) int32."""
+    from . import _ffi
+    X, Y, Z = shape
+    dev = inst.device
+    first = torch.full((max_label + 1,), -1, dtype=torch.int32, device=dev)  # 0xFFFFFFFF
+    _ffi.check(_ffi.lib.sk_first_seen(_ffi.ptr(inst), X, Y, slab[1] - slab[0], slab[0], Z, max_label,
+                                      _ffi.ptr(first), _ffi.stream_ptr(dev)))
+    f64 = first.to(torch.int64) & 0xFFFFFFFF
+    f64 = comm.all_reduce_min(f64)
+    seen = torch.nonzero(f64 != 0xFFFFFFFF).flatten()
+    order = torch.argsort(f64[seen])
+    lut = torch.zeros(max_label + 1, dtype=torch.int32, device=dev)
+    lut[seen[order]] = torch.arange(1, seen.numel() + 1, dtype=torch.int32, device=dev)
+    _ffi.check(_ffi.lib.sk_relabel_lut(_ffi.ptr(inst), inst.numel(), _ffi.ptr(lut), max_label + 1,
+                                       _ffi.stream_ptr(dev)))
+    torch.cuda.current_stream(dev).synchronize()
+    return int(seen.numel())

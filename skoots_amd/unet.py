@@ -54,6 +54,21 @@ class _ConvLayer:
         self.flops_per_out_voxel = 2.0 * self.cin * self.cout * ksize ** 3
 
 
+class ConvProfile:
+    """HIP-event timing of every 3x3x3 MFMA conv launch (the dominant kernel), recorded on
+    the stream the kernels are launched on; bench.py turns it into the roofline figure."""
+
+    def __init__(self):
+        self.events = []  # (start, end, flops)
+
+    def totals(self):
+        if not self.events:
+            return 0.0, 0.0, 0
+        self.events[-1][1].synchronize()
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.events)
+        return ms, sum(f for _, _, f in self.events), len(self.events)
+
+
 class HipUNet:
     """``model.forward_tiles(image, origins, tile, mean, std) -> (B, 5, w, h, d)`` fp16."""
 
@@ -87,6 +102,7 @@ class HipUNet:
         self.zeros = torch.zeros(4096, dtype=torch.uint8, device=dev)
         self._bufs: Dict[Tuple, Tensor] = {}
         self.last_features: Dict[str, Tensor] = {}
+        self.profile: Optional[ConvProfile] = None
 
     # -- reference-compatible construction ---------------------------------------------
     @classmethod
@@ -133,9 +149,16 @@ class HipUNet:
             arr[i].upsample = up
             cin += t.shape[-1]
         assert cin == layer.cin, (layer.name, cin, layer.cin)
+        timed = self.profile is not None and layer.ksize == 3
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
         _ffi.check(_ffi.lib.sk_conv3d(arr, len(srcs), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
                                       _ffi.ptr(out), B, ox, oy, oz, layer.cout, layer.ksize,
                                       _ffi.ptr(partial), _ffi.ptr(self.zeros), _ffi.stream_ptr(self.device)))
+        if timed:
+            e1.record(torch.cuda.current_stream(self.device))
+            self.profile.events.append((e0, e1, layer.flops_per_out_voxel * B * ox * oy * oz))
         if activate:
             self._norm_act(layer, out, partial, nblk)
         return out
