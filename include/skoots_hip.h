@@ -194,13 +194,15 @@ int64_t sk_conv3d_pack_weight_host(const float* w_host, int cout, int cin, int k
 
 /* Stem: first conv of the network (Cin = 1).  Reads B tiles of extent (Xt,Yt,Zt) at
  * origins_host[3*b..] straight from the (X,Y,Z) fp16 image volume, normalises
- * (x - mean)/std in fp16 arithmetic exactly as eval.py:139, conv3 zero padded ->
- * out (B, Xt, Yt, Zt, 32) fp16 raw + gn partials (B, stem_num_blocks, 8, 2).
- * weight (27, 32) fp32 [tap=(dx*3+dy)*3+dz][cout]. */
+ * (x - mean)/std in fp16 arithmetic exactly as eval.py:139 into a zero-framed workspace,
+ * then conv3 on the exact-fp32 matrix instruction -> out (B, Xt, Yt, Zt, 32) fp16 raw +
+ * gn partials (B, stem_num_blocks, 8, 2).  weight (27, 32) fp32 [tap=(dx*3+dy)*3+dz][cout]. */
 int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origins_host, int B,
                    int Xt, int Yt, int Zt, float mean, float std, const float* weight,
-                   const float* bias, void* out, int cout, float* gn_partial, void* stream);
+                   const float* bias, void* out, int cout, float* gn_partial, void* workspace,
+                   size_t workspace_bytes, void* stream);
 int sk_conv3d_stem_num_blocks(int X, int Y, int Z);
+size_t sk_conv3d_stem_workspace_bytes(int B, int Xt, int Yt, int Zt);
 
 /* GroupNorm statistics -> per-channel affine, reduced in a fixed order (deterministic):
  * gn_partial (B, nblocks, C/4, 2); affine (B, 2, C): a = gamma*rstd, b = beta - mean*a. */

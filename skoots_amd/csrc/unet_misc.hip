@@ -1,6 +1,6 @@
 // The non-MFMA layers of the U-Net body (oracle/unet_spec.py), all HBM-bound:
 //   * stem conv (Cin = 1, 27 taps): normalise the fp16 image exactly as
-//     skoots/lib/eval.py:139 does (fp16 sub, fp16 div), conv in fp32 on the VALU;
+//     skoots/lib/eval.py:139 does (fp16 sub, fp16 div), conv on the exact-fp32 MFMA;
 //   * GroupNorm finalize (deterministic reduction of the conv epilogue partials) and
 //     the fused GroupNorm-affine + SiLU pass, in place, 16 B per lane;
 //   * heads: 1x1x1 conv to 5 channels + tanh / sigmoid, written in the reference's
@@ -12,6 +12,16 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------------------ stem
+// Two launches.  (1) normalise: the B tiles are cut out of the fp16 volume, normalised with
+// the reference's fp16 arithmetic (eval.py:139: fp16 sub, fp16 div) and written with an
+// explicit one-voxel ZERO frame -- conv zero padding applies to the normalised tile.
+// (2) conv: D[cout][voxel] = W[cout][tap] * patch[tap][voxel] on the exact-fp32 matrix
+// instruction v_mfma_f32_32x32x2_f32 (K = 2 taps per instruction, 14 instructions for the
+// 27 taps + one zero): fp32 weights, fp32 products -- the stem keeps full precision.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+
 struct StemArgs {
     const __half* image;   // (X, Y, Z) fp16 volume
     int X, Y, Z;           // volume extents
@@ -20,81 +30,105 @@ struct StemArgs {
     float mean, stdv;
     const float* weight;   // (27, 32) fp32: [tap = (dx*3+dy)*3+dz][cout]
     const float* bias;     // (32)
+    __half* norm;          // workspace (B, Xt+2, Yt+2, Zt+2) fp16
     __half* out;           // (B, Xt, Yt, Zt, 32) fp16 raw
     float* partial;        // (B, nblk, 8, 2)
     int nblk;
 };
 
+constexpr int kStemTilesPerWave = 8;                       // 32-voxel column tiles per wave
+constexpr int kStemVoxPerBlock = 4 * 32 * kStemTilesPerWave;
+
+__global__ void __launch_bounds__(256) stem_norm_kernel(StemArgs a) {
+    const int b = blockIdx.y;
+    const int px = a.Xt + 2, py = a.Yt + 2, pz = a.Zt + 2;
+    const long long n = (long long)px * py * pz;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int z = (int)(i % pz);
+    long long t = i / pz;
+    int y = (int)(t % py), x = (int)(t / py);
+    float v = 0.0f;
+    if (x >= 1 && x <= a.Xt && y >= 1 && y <= a.Yt && z >= 1 && z <= a.Zt) {
+        float raw = __half2float(a.image[((long long)(a.ox[b] + x - 1) * a.Y + (a.oy[b] + y - 1)) * a.Z +
+                                         (a.oz[b] + z - 1)]);
+        // eval.py:139  crop.sub(mean).div(std) on an fp16 tensor: each op rounds to fp16
+        float s = __half2float(__float2half_rn(raw - a.mean));
+        v = __half2float(__float2half_rn(s / a.stdv));
+    }
+    a.norm[(long long)b * n + i] = __float2half_rn(v);
+}
+
 __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
-    __shared__ float wsm[27 * 32 + 32];
     __shared__ float red[4 * 16];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 27 * 32; i += 256) wsm[i] = a.weight[i];
-    if (tid < 32) wsm[27 * 32 + tid] = a.bias[tid];
-    __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
     const int b = blockIdx.x / a.nblk, blk = blockIdx.x % a.nblk;
     const long long nvox = (long long)a.Xt * a.Yt * a.Zt;
-    long long v = (long long)blk * 256 + tid;
-    const bool ok = v < nvox;
-    long long vv = ok ? v : 0;
-    int z = (int)(vv % a.Zt);
-    long long t = vv / a.Zt;
-    int y = (int)(t % a.Yt), x = (int)(t / a.Yt);
-    const int gx = a.ox[b], gy = a.oy[b], gz = a.oz[b];
+    const int py = a.Yt + 2, pz = a.Zt + 2;
+    const __half* nb = a.norm + (long long)b * (a.Xt + 2) * py * pz;
 
-    float acc[32];
+    // A operand: lane holds W[cout = l&31][tap = 2m + h], m = 0..13 (tap 27 = 0)
+    float wa[14];
+    int toff[14];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) acc[c] = wsm[27 * 32 + c];
+    for (int m = 0; m < 14; ++m) {
+        int tap = 2 * m + h;
+        wa[m] = tap < 27 ? a.weight[tap * 32 + col] : 0.0f;
+        int tt = tap < 27 ? tap : 0;
+        int dx = tt / 9, dy = (tt / 3) % 3, dz = tt % 3;
+        toff[m] = (dx * py + dy) * pz + dz;
+    }
+    f32x16 binit;
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
+    for (int q = 0; q < 4; ++q) {
+        f32x4v bv = *reinterpret_cast<const f32x4v*>(a.bias + 8 * q + 4 * h);
+        binit[4 * q] = bv[0];
+        binit[4 * q + 1] = bv[1];
+        binit[4 * q + 2] = bv[2];
+        binit[4 * q + 3] = bv[3];
+    }
+    float gsum[4] = {0, 0, 0, 0}, gsq[4] = {0, 0, 0, 0};
+    for (int t = 0; t < kStemTilesPerWave; ++t) {
+        long long v = (long long)blk * kStemVoxPerBlock + (w * kStemTilesPerWave + t) * 32 + col;
+        bool ok = v < nvox;
+        long long vv = ok ? v : 0;
+        int z = (int)(vv % a.Zt);
+        long long r = vv / a.Zt;
+        int y = (int)(r % a.Yt), x = (int)(r / a.Yt);
+        const __half* p = nb + ((long long)x * py + y) * pz + z;  // tap (0,0,0) of the padded tile
+        float bv[14];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int m = 0; m < 14; ++m) bv[m] = __half2float(p[toff[m]]);
+        if (h == 1) bv[13] = 0.0f;  // tap 27 does not exist
+        f32x16 acc = binit;
 #pragma unroll
-            for (int dz = 0; dz < 3; ++dz) {
-                int xx = x + dx - 1, yy = y + dy - 1, zz = z + dz - 1;
-                float n = 0.0f;  // conv zero padding applies to the NORMALISED tile
-                if (xx >= 0 && xx < a.Xt && yy >= 0 && yy < a.Yt && zz >= 0 && zz < a.Zt) {
-                    float raw = __half2float(
-                        a.image[((long long)(gx + xx) * a.Y + (gy + yy)) * a.Z + (gz + zz)]);
-                    // eval.py:139  crop.sub(mean).div(std) on an fp16 tensor: each op rounds to fp16
-                    float s = __half2float(__float2half_rn(raw - a.mean));
-                    n = __half2float(__float2half_rn(s / a.stdv));
-                }
-                const float* wt = wsm + ((dx * 3 + dy) * 3 + dz) * 32;
+        for (int m = 0; m < 14; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[m], bv[m], acc, 0, 0, 0);
+        if (ok) {
+            __half* op = a.out + ((long long)b * nvox + v) * 32;
 #pragma unroll
-                for (int c = 0; c < 32; ++c) acc[c] = fmaf(wt[c], n, acc[c]);
+            for (int q = 0; q < 4; ++q) {
+                float v0 = acc[4 * q], v1 = acc[4 * q + 1], v2 = acc[4 * q + 2], v3 = acc[4 * q + 3];
+                half4v hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+                *reinterpret_cast<half4v*>(op + 8 * q + 4 * h) = hv;
+                gsum[q] += (v0 + v1) + (v2 + v3);
+                gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
             }
-    if (ok) {
-        half8* op = reinterpret_cast<half8*>(a.out + ((long long)b * nvox + v) * 32);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            half8 hv;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) hv[j] = (_Float16)acc[8 * k + j];
-            op[k] = hv;
         }
     }
     if (a.partial) {
-        const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float s = 0.0f, ss = 0.0f;
-            if (ok) {
+        for (int q = 0; q < 4; ++q) {
+            float s = gsum[q], ss = gsq[q];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float u = acc[4 * q + j];
-                    s += u;
-                    ss += u * u;
-                }
-            }
-#pragma unroll
-            for (int m = 32; m > 0; m >>= 1) {
+            for (int m = 16; m > 0; m >>= 1) {
                 s += __shfl_xor(s, m);
                 ss += __shfl_xor(ss, m);
             }
-            if (lane == 0) {
-                red[(w * 8 + q) * 2] = s;
-                red[(w * 8 + q) * 2 + 1] = ss;
+            if (col == 0) {
+                int quad = 2 * q + h;
+                red[(w * 8 + quad) * 2] = s;
+                red[(w * 8 + quad) * 2 + 1] = ss;
             }
         }
         __syncthreads();
@@ -233,16 +267,23 @@ __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
 extern "C" {
 
 int sk_conv3d_stem_num_blocks(int X, int Y, int Z) {
-    return (int)(((long long)X * Y * Z + 255) / 256);
+    return (int)(((long long)X * Y * Z + kStemVoxPerBlock - 1) / kStemVoxPerBlock);
+}
+
+size_t sk_conv3d_stem_workspace_bytes(int B, int Xt, int Yt, int Zt) {
+    return (size_t)B * (Xt + 2) * (Yt + 2) * (Zt + 2) * sizeof(__half);
 }
 
 int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origins_host, int B, int Xt,
                    int Yt, int Zt, float mean, float stdv, const float* weight, const float* bias,
-                   void* out, int cout, float* gn_partial, void* stream) {
-    SK_CHECK_ARG(image && origins_host && weight && bias && out, "sk_conv3d_stem: NULL pointer");
+                   void* out, int cout, float* gn_partial, void* workspace, size_t workspace_bytes,
+                   void* stream) {
+    SK_CHECK_ARG(image && origins_host && weight && bias && out && workspace, "sk_conv3d_stem: NULL pointer");
     SK_CHECK_ARG(cout == 32, "sk_conv3d_stem: cout must be 32");
     SK_CHECK_ARG(B >= 1 && B <= 16, "sk_conv3d_stem: batch must be in [1,16]");
     SK_CHECK_ARG(stdv != 0.0f, "sk_conv3d_stem: std must be non-zero");
+    SK_CHECK_ARG(workspace_bytes >= sk_conv3d_stem_workspace_bytes(B, Xt, Yt, Zt),
+                 "sk_conv3d_stem: workspace too small");
     StemArgs a{};
     a.image = (const __half*)image;
     a.X = X;
@@ -265,9 +306,13 @@ int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origin
     a.stdv = stdv;
     a.weight = weight;
     a.bias = bias;
+    a.norm = (__half*)workspace;
     a.out = (__half*)out;
     a.partial = gn_partial;
     a.nblk = sk_conv3d_stem_num_blocks(Xt, Yt, Zt);
+    long long np = (long long)(Xt + 2) * (Yt + 2) * (Zt + 2);
+    dim3 g1(sk::cdiv(np, 256), B);
+    stem_norm_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(a);
     stem_kernel<<<(unsigned)(a.nblk * B), 256, 0, (hipStream_t)stream>>>(a);
     SK_CHECK_LAUNCH();
     return SK_OK;

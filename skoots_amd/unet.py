@@ -172,9 +172,12 @@ class HipUNet:
         nblk = _ffi.lib.sk_conv3d_stem_num_blocks(xt, yt, zt)
         partial = self._buf("partial", (B * nblk * (layer.cout // 4) * 2,), torch.float32)
         org = (C.c_int32 * (3 * B))(*[int(v) for o in origins for v in o])
+        ws_bytes = _ffi.lib.sk_conv3d_stem_workspace_bytes(B, xt, yt, zt)
+        ws = self._buf("stem_ws", (ws_bytes,), torch.uint8)
         _ffi.check(_ffi.lib.sk_conv3d_stem(_ffi.ptr(image), X, Y, Z, org, B, xt, yt, zt, mean, std,
                                            _ffi.ptr(layer.weight), _ffi.ptr(layer.bias), _ffi.ptr(out),
-                                           layer.cout, _ffi.ptr(partial), _ffi.stream_ptr(self.device)))
+                                           layer.cout, _ffi.ptr(partial), _ffi.ptr(ws), ws_bytes,
+                                           _ffi.stream_ptr(self.device)))
         self._norm_act(layer, out, partial, nblk)
         return out
 
