@@ -342,7 +342,7 @@ def scatter_tile(vectors: np.ndarray, skeleton: np.ndarray, vec: Tensor, skel: T
 
 
 def stage1(image: Tensor, model, mean, std, tile=TILE, overlap=TILE_OVERLAP,
-           inject=None) -> Tuple[np.ndarray, np.ndarray]:
+           inject=None, budget_s: float = None, progress: dict = None) -> Tuple[np.ndarray, np.ndarray]:
     """eval.py:126-176.  ``image`` (1, X, Y, Z); ``model`` maps (1,1,w,h,d) fp32 ->
     (1,5,w,h,d).  ``inject(out, origin, eff)`` may replace the network output
     (used to feed synthetic fields to the post-model stages).
@@ -351,7 +351,13 @@ def stage1(image: Tensor, model, mean, std, tile=TILE, overlap=TILE_OVERLAP,
     vectors = np.zeros((3, X, Y, Z), dtype=np.float16)  # eval.py:103
     skeleton = np.zeros((1, X, Y, Z), dtype=np.uint8)  # eval.py:102
     origins, eff = crop_origins((X, Y, Z), list(tile), overlap)
-    for (x, y, z) in origins:
+    import time as _time
+    t0 = _time.perf_counter()
+    for k, (x, y, z) in enumerate(origins):
+        if budget_s is not None and k > 0 and _time.perf_counter() - t0 > budget_s:
+            break  # bench.py's bounded CPU-baseline sample: the caller extrapolates
+        if progress is not None:
+            progress.update(done=k + 1, total=len(origins), seconds=_time.perf_counter() - t0)
         crop = image[:, x : x + eff[0], y : y + eff[1], z : z + eff[2]].unsqueeze(0)
         crop = crop.sub(mean).div(std)  # eval.py:139
         out = model(crop.float())
@@ -359,6 +365,8 @@ def stage1(image: Tensor, model, mean, std, tile=TILE, overlap=TILE_OVERLAP,
             out = inject(out, (x, y, z), eff)
         vec, skel = gate_dilate(out)
         scatter_tile(vectors, skeleton, vec, skel, (x, y, z), eff, overlap)
+        if progress is not None:
+            progress.update(done=k + 1, total=len(origins), seconds=_time.perf_counter() - t0)
     return vectors, skeleton
 
 
