@@ -73,15 +73,23 @@ __device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Wave layout inside a workgroup: NT = COUT/32 cout tiles.  The 4 waves form NT groups
+// along cout x (4/NT) groups along the voxel columns; a wave owns ONE cout tile and
+// P = NT column tiles (32 voxels each) of the 128-voxel patch.  So a wave streams only its
+// own cout tile's weights (weight-fragment reuse = XS*P MFMAs per 1 KiB fragment) and the
+// activation fragment of a column tile is read once per wave that needs it.
 template <int COUT, int XS>
-__global__ void __launch_bounds__(256) conv3_kernel(Conv3Args a) {
+__global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     constexpr int NT = COUT / 32;
+    constexpr int P = NT;            // column tiles per wave
     constexpr int R = XS + 2;
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w % NT;           // cout tile of this wave
+    const int wm = w / NT;           // voxel group of this wave
     const int col = lane & 31, h = lane >> 5;
 
     int blk = blockIdx.x;
@@ -94,21 +102,24 @@ __global__ void __launch_bounds__(256) conv3_kernel(Conv3Args a) {
 
     // ---- patch geometry ------------------------------------------------------------
     const int pitch = a.pitch;
-    int off, ybase, zbase;      // region position q -> (y, z): P = q + off; y = ybase + P/pitch; z = zbase + P%pitch
-    int vy, vz;                 // this lane's output voxel
-    int q_row;                  // its position in the region
-    bool vvalid;
+    int off, ybase, zbase;      // region position q -> (y, z): Pq = q + off; y = ybase + Pq/pitch; z = zbase + Pq%pitch
+    int q_row[P];               // region position of this lane's voxel in column tile p
+    long long out_vox[P];       // in-plane voxel index of the output
+    bool vvalid[P];
     if (a.mode == 0) {
         int v0 = patch * kPatch;
         int y0 = v0 / a.Zt, z0 = v0 - y0 * a.Zt;
         off = z0;
         ybase = y0 - 1;
         zbase = -1;
-        int v = v0 + 32 * w + col;
-        vy = v / a.Zt;
-        vz = v - vy * a.Zt;
-        vvalid = v < a.Yt * a.Zt;
-        q_row = (vy + 1) * pitch + (vz + 1) - (y0 * pitch + z0);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int v = v0 + 32 * (wm * P + p) + col;
+            int vy = v / a.Zt, vz = v - vy * a.Zt;
+            vvalid[p] = v < a.Yt * a.Zt;
+            q_row[p] = (vy + 1) * pitch + (vz + 1) - (y0 * pitch + z0);
+            out_vox[p] = (long long)vy * a.Zt + vz;
+        }
     } else {
         const int TY = kPatch / a.TZ;
         int yg = patch / a.nzc, zc = patch - yg * a.nzc;
@@ -116,14 +127,16 @@ __global__ void __launch_bounds__(256) conv3_kernel(Conv3Args a) {
         off = 0;
         ybase = y0 - 1;
         zbase = zc0 - 1;
-        int vl = 32 * w + col;
-        int yl = vl / a.TZ, zl = vl - yl * a.TZ;
-        vy = y0 + yl;
-        vz = zc0 + zl;
-        vvalid = vy < a.Yt && vz < a.Zt;
-        q_row = (yl + 1) * pitch + (zl + 1);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int vl = 32 * (wm * P + p) + col;
+            int yl = vl / a.TZ, zl = vl - yl * a.TZ;
+            int vy = y0 + yl, vz = zc0 + zl;
+            vvalid[p] = vy < a.Yt && vz < a.Zt;
+            q_row[p] = (yl + 1) * pitch + (zl + 1);
+            out_vox[p] = (long long)vy * a.Zt + vz;
+        }
     }
-    const long long out_vox = ((long long)vy * a.Zt + vz);  // in-plane voxel index of the output
 
     // ---- DMA bookkeeping: this lane's slots of a plane --------------------------------
     const int ndma = a.nposp / 16;  // wave-instructions per plane
@@ -133,8 +146,8 @@ __global__ void __launch_bounds__(256) conv3_kernel(Conv3Args a) {
         int t = w + 4 * k;
         int slot = 64 * t + lane;
         int q = slot >> 2, c = slot & 3;
-        int P = q + off;
-        int y = ybase + P / pitch, z = zbase + P % pitch;
+        int Pq = q + off;
+        int y = ybase + Pq / pitch, z = zbase + Pq % pitch;
         bool ok = (t < ndma) && y >= 0 && y < a.Yt && z >= 0 && z < a.Zt;
         d_vox[k] = ok ? y * a.Zt + z : -1;
         d_up[k] = ok ? (y >> 1) * a.src[1].Zs + (z >> 1) : -1;
@@ -142,12 +155,10 @@ __global__ void __launch_bounds__(256) conv3_kernel(Conv3Args a) {
     }
 
     // ---- accumulators + GroupNorm partials ----------------------------------------------
-    f32x16 acc[XS][NT];
-    float gsum[NT][4], gsq[NT][4];
+    f32x16 acc[P][XS];
+    float gsum[4], gsq[4];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) gsum[nt][q] = gsq[nt][q] = 0.0f;
+    for (int q = 0; q < 4; ++q) gsum[q] = gsq[q] = 0.0f;
 
     const int xa = xc * a.XC;
     const int xb = min(xa + a.XC, a.Xt);
@@ -156,23 +167,23 @@ __global__ void __launch_bounds__(256) conv3_kernel(Conv3Args a) {
     const long long out_plane = (long long)a.Yt * a.Zt * COUT * 2;
     char* outb = a.out + (long long)b * a.Xt * out_plane;
 
+    // bias as the initial accumulator: row (cout) = 32*wn + (r&3) + 8(r>>2) + 4h
+    f32x16 binit;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + 32 * wn + 8 * q + 4 * h);
+        binit[4 * q + 0] = bv[0];
+        binit[4 * q + 1] = bv[1];
+        binit[4 * q + 2] = bv[2];
+        binit[4 * q + 3] = bv[3];
+    }
+
     int step = 0;
     for (int x0 = xa; x0 < xb; x0 += XS, ++step) {
-        // bias as the initial accumulator: row (cout) = 32nt + (r&3) + 8(r>>2) + 4h
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            f32x16 init;
+        for (int p = 0; p < P; ++p)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + 32 * nt + 8 * q + 4 * h);
-                init[4 * q + 0] = bv[0];
-                init[4 * q + 1] = bv[1];
-                init[4 * q + 2] = bv[2];
-                init[4 * q + 3] = bv[3];
-            }
-#pragma unroll
-            for (int o = 0; o < XS; ++o) acc[o][nt] = init;
-        }
+            for (int o = 0; o < XS; ++o) acc[p][o] = binit;
 
         for (int ch = 0; ch < a.nchunks; ++ch) {
             // ---------------- stage the input planes of this (step, chunk) ------------------
@@ -200,62 +211,71 @@ __global__ void __launch_bounds__(256) conv3_kernel(Conv3Args a) {
                     }
                 }
             }
+            // weight fragments of the first tap row, issued behind the DMA so they fly together
+            // fragment index: (((ch*9 + dydz)*2 + ks)*3 + d)*NT + nt
+            const char* wch = a.wpk + ((long long)ch * (9 * 2 * 3 * NT) + wn) * 1024 + lane * 16;
+            half8 a0[3], a1[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wch + (d * NT) * 1024);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
 
             // ---------------- MFMA over the 27 taps of this chunk ---------------------------
-            const char* wch = a.wpk + (long long)ch * (9 * 2 * 3 * NT) * 1024 + lane * 16;
-#pragma unroll 1
-            for (int dydz = 0; dydz < 9; ++dydz) {
-                const int dy = dydz / 3 - 1, dz = dydz % 3 - 1;
-                const int q = q_row + dy * pitch + dz;
-                const int f = (q >> 2) & 3;
+            int pslot[R];
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    half8 afr[3][NT];
+            for (int i = 0; i < R; ++i) pslot[i] = (ring ? (step * XS + i) % R : i) * plane_bytes;
+
+            auto compute = [&](int dydz, int ks, const half8 (&afr)[3]) {
+                const int tapoff = (dydz / 3 - 1) * pitch + (dydz % 3 - 1);
 #pragma unroll
-                    for (int d = 0; d < 3; ++d)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            afr[d][nt] = *reinterpret_cast<const half8*>(
-                                wch + (((dydz * 2 + ks) * 3 + d) * NT + nt) * 1024);
-                    const int addr = (q * 4 + ((ks * 2 + h) ^ f)) * 16;
+                for (int p = 0; p < P; ++p) {
+                    const int q = q_row[p] + tapoff;
+                    const int addr = (q * 4 + ((ks * 2 + h) ^ ((q >> 2) & 3))) * 16;
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
-                        const int slotp = ring ? (step * XS + i) % R : i;
-                        const half8 bfr = *reinterpret_cast<const half8*>(lds + slotp * plane_bytes + addr);
+                        const half8 bfr = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
 #pragma unroll
                         for (int d = 0; d < 3; ++d) {
                             const int o = i - d;  // x_in = x_out + (d - 1)
-                            if (o >= 0 && o < XS) {
-#pragma unroll
-                                for (int nt = 0; nt < NT; ++nt)
-                                    acc[o][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                        afr[d][nt], bfr, acc[o][nt], 0, 0, 0);
-                            }
+                            if (o >= 0 && o < XS)
+                                acc[p][o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[d], bfr, acc[p][o], 0, 0, 0);
                         }
                     }
                 }
+            };
+#pragma unroll 1
+            for (int dydz = 0; dydz < 9; ++dydz) {
+                const char* wrow = wch + (long long)(dydz * 2) * (3 * NT) * 1024;
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    a1[d] = *reinterpret_cast<const half8*>(wrow + ((3 + d) * NT) * 1024);
+                compute(dydz, 0, a0);
+                if (dydz < 8) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                        a0[d] = *reinterpret_cast<const half8*>(wrow + ((6 + d) * NT) * 1024);
+                }
+                compute(dydz, 1, a1);
             }
         }
 
         // ---------------- epilogue: raw fp16 store + GroupNorm partial sums ------------------
 #pragma unroll
-        for (int o = 0; o < XS; ++o) {
-            const int x = x0 + o;
-            const bool ok = vvalid && x < xb;
-            char* op = outb + (long long)x * out_plane + out_vox * (COUT * 2);
+        for (int p = 0; p < P; ++p) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+            for (int o = 0; o < XS; ++o) {
+                const int x = x0 + o;
+                const bool ok = vvalid[p] && x < xb;
+                char* op = outb + (long long)x * out_plane + out_vox[p] * (COUT * 2);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float v0 = acc[o][nt][4 * q], v1 = acc[o][nt][4 * q + 1];
-                    float v2 = acc[o][nt][4 * q + 2], v3 = acc[o][nt][4 * q + 3];
+                    float v0 = acc[p][o][4 * q], v1 = acc[p][o][4 * q + 1];
+                    float v2 = acc[p][o][4 * q + 2], v3 = acc[p][o][4 * q + 3];
                     if (ok) {
                         half4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-                        *reinterpret_cast<half4*>(op + (32 * nt + 8 * q + 4 * h) * 2) = hv;
-                        gsum[nt][q] += (v0 + v1) + (v2 + v3);
-                        gsq[nt][q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                        *reinterpret_cast<half4*>(op + (32 * wn + 8 * q + 4 * h) * 2) = hv;
+                        gsum[q] += (v0 + v1) + (v2 + v3);
+                        gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
                     }
                 }
             }
@@ -265,26 +285,27 @@ __global__ void __launch_bounds__(256) conv3_kernel(Conv3Args a) {
     // ---- block-level reduction of the GroupNorm partials ------------------------------------
     if (a.partial) {
         __syncthreads();
-        float* red = reinterpret_cast<float*>(lds);  // [4 waves][NT*8 quads][2]
+        float* red = reinterpret_cast<float*>(lds);  // [4 waves][8 quads of the wave's cout tile][2]
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int q = 0; q < 4; ++q) {
+            float s = gsum[q], ss = gsq[q];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float s = gsum[nt][q], ss = gsq[nt][q];
-#pragma unroll
-                for (int m = 16; m > 0; m >>= 1) {
-                    s += __shfl_xor(s, m);
-                    ss += __shfl_xor(ss, m);
-                }
-                if (col == 0) {
-                    int quad = 8 * nt + 2 * q + h;  // channel quad = cout / 4
-                    red[(w * (NT * 8) + quad) * 2 + 0] = s;
-                    red[(w * (NT * 8) + quad) * 2 + 1] = ss;
-                }
+            for (int m = 16; m > 0; m >>= 1) {
+                s += __shfl_xor(s, m);
+                ss += __shfl_xor(ss, m);
             }
+            if (col == 0) {
+                red[(w * 8 + 2 * q + h) * 2 + 0] = s;
+                red[(w * 8 + 2 * q + h) * 2 + 1] = ss;
+            }
+        }
         __syncthreads();
-        if (tid < NT * 8 * 2) {
-            float t = red[tid] + red[NT * 16 + tid] + red[2 * NT * 16 + tid] + red[3 * NT * 16 + tid];
+        if (tid < NT * 16) {
+            // channel quad Q = cout/4 = 8*nt + k ; waves with wn == nt: w = wm*NT + nt
+            const int nt = tid / 16, k2 = tid % 16;
+            float t = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 4 / NT; ++g) t += red[(g * NT + nt) * 16 + k2];
             a.partial[((long long)b * nblk + block_in_batch) * (NT * 16) + tid] = t;
         }
     }
@@ -421,7 +442,7 @@ struct Plan {
     size_t lds;
 };
 
-int conv3_xs(int cout) { return cout == 128 ? 2 : 4; }
+int conv3_xs(int cout) { return cout == 128 ? 2 : 4; }  // keeps P*XS*16 accumulators <= 128
 
 int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
     p.xs = conv3_xs(cout);
