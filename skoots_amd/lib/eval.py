@@ -176,3 +176,108 @@ def eval_volume(image: Tensor, model, scale, mean=None, std=None, n: int = FOLLO
     if timings is not None:
         timings.update(sv.timings)
     return res
+
+
+# ----------------------------------------------------------------------------------------
+# File-level entry point: same signature and side effects as skoots.lib.eval.eval
+# ----------------------------------------------------------------------------------------
+def _read_image(path: str) -> np.ndarray:
+    """[Z, X, Y(, C)] array from a multi-page TIFF (Pillow) or a .npy file (eval.py:61)."""
+    if path.endswith(".npy"):
+        return np.load(path)
+    from PIL import Image
+    pages = []
+    with Image.open(path) as im:
+        for i in range(getattr(im, "n_frames", 1)):
+            im.seek(i)
+            pages.append(np.array(im))
+    return np.stack(pages, axis=0)
+
+
+def _write_mask_tif(path: str, mask_zxy: np.ndarray) -> None:
+    """(Z, X, Y) integer stack -> multi-page TIFF, zlib/deflate compressed (eval.py:309-310)."""
+    from PIL import Image
+    arr = mask_zxy.astype(np.uint16) if mask_zxy.max() < 65536 else mask_zxy.astype(np.int32)
+    pages = [Image.fromarray(p) for p in arr]
+    pages[0].save(path, save_all=True, append_images=pages[1:], compression="tiff_adobe_deflate")
+
+
+def _cfg_get(cfg, section: str, key: str, default=None):
+    sec = cfg[section] if isinstance(cfg, dict) else getattr(cfg, section)
+    return sec.get(key, default) if isinstance(sec, dict) else getattr(sec, key, default)
+
+
+@torch.inference_mode()
+def eval(image_path: str, checkpoint_path: str, used_cached_data: bool = False) -> None:
+    """Evaluates SKOOTS on an arbitrary image (drop-in for ``skoots.lib.eval.eval``).
+
+    Writes next to the image, with the reference's names: ``<base>_skoots_skeleton`` (1,X,Y,Z) u1
+    and ``<base>_skoots_vectors`` (3,X,Y,Z) f2 (``.npy``: zarr is not in this image),
+    ``<base>_skoots_benchmark.txt`` and ``<base>_instance_mask.tif`` (Z,X,Y), and prints DONE.
+
+    ``checkpoint_path``: ``torch.save``d dict with ``cfg`` (dict/attribute config holding
+    ``SKOOTS.VECTOR_SCALING`` and ``MODEL.*``), ``model_state_dict`` and optionally
+    ``dataset_mean`` / ``dataset_std`` (eval.py:51-55, 87-88, 99, 117-118).
+    """
+    from .. import unet
+    start = time.time()
+    logging.info(f"Loading model file: {checkpoint_path}")
+    checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    if "cfg" not in checkpoint:
+        raise RuntimeError("Attempting to evaluate skoots on a legacy model file.")  # eval.py:55
+    cfg = checkpoint["cfg"]
+    if not torch.cuda.is_available():
+        raise RuntimeError("skoots_amd.eval needs an MI355X: there is no CPU path")
+    device = torch.device("cuda", torch.cuda.current_device())
+    base = os.path.splitext(image_path)[0]
+
+    logging.info(f"Loading image from file: {image_path}")
+    image = _read_image(image_path)  # [Z, X, Y(, C)]
+    image = image[..., np.newaxis] if image.ndim == 3 else image
+    image = image.transpose(-1, 1, 2, 0)
+    image = image[[2], ...] if image.shape[0] > 3 else image  # eval.py:64 -> [C=1, X, Y, Z]
+    c, x, y, z = image.shape
+    logging.info(f"Loaded an image with shape: {(c, x, y, z)}, dtype: {image.dtype}")
+    img16 = torch.from_numpy(np.ascontiguousarray(image[0]).astype(np.float32)).to(torch.float16)  # eval.py:80
+    mean = checkpoint["dataset_mean"] if "dataset_mean" in checkpoint else img16.mean()  # eval.py:87
+    std = checkpoint["dataset_std"] if "dataset_std" in checkpoint else img16.std()  # eval.py:88
+    scale = [int(v) for v in _cfg_get(cfg, "SKOOTS", "VECTOR_SCALING")]  # eval.py:99
+
+    logging.info("Constructing SKOOTS model")
+    model = unet.cfg_to_model(cfg, device, checkpoint["model_state_dict"])
+    skel_path, vec_path = base + "_skoots_skeleton.npy", base + "_skoots_vectors.npy"
+
+    benchmark_start = time.time()
+    dev_img = img16.to(device)
+    if used_cached_data and os.path.exists(skel_path) and os.path.exists(vec_path):  # eval.py:105 (os.exists bug fixed)
+        from ..parallel import ShardedVolume  # noqa: F401
+        state = VolumeState((x, y, z), device)
+        state.skeleton.copy_(torch.from_numpy(np.load(skel_path)[0]).to(device))
+        vp = torch.from_numpy(np.load(vec_path)).to(device)
+        _ffi.check(_ffi.lib.sk_vec_interleave(_ffi.ptr(vp), _ffi.ptr(state.vec4), x * y * z,
+                                              _ffi.stream_ptr(device)))
+        state.label()
+        state.assign(scale)
+        state.renumber()
+        inst, vectors, skeleton = state.instance, vp, state.skeleton
+    else:
+        res = eval_volume(dev_img, model, scale, mean=float(mean), std=float(std))
+        inst, skeleton = res["instance_mask"], res["skeleton"]
+        vectors = res["state"].vectors_planar()
+    torch.cuda.synchronize(device)
+    dt = time.time() - benchmark_start
+
+    np.save(skel_path, skeleton.cpu().numpy()[np.newaxis])
+    np.save(vec_path, vectors.cpu().numpy())
+    logging.info("writing benchmark information")
+    with open(base + "_skoots_benchmark.txt", "w") as f:  # eval.py:286-295
+        f.write("SKOOTS Segmentation Benchmark:\n")
+        f.write("------------------------------\n")
+        f.write(f"Time: {dt} seconds\n")
+        f.write(f"Memory (current/max): ({torch.cuda.memory_allocated(device)}, "
+                f"{torch.cuda.max_memory_allocated(device)})\n\n")
+    print("DONE")
+    logging.info(f"saving to tif file at {base}_instance_mask.tif")
+    _write_mask_tif(base + "_instance_mask.tif", inst.cpu().numpy().transpose(2, 0, 1))
+    elapsed = time.time() - start
+    logging.info(f"DONE: Process took {elapsed} seconds, {elapsed / 60} minutes, {elapsed / (60 ** 2)}, hours")
