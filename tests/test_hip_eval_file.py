@@ -1,0 +1,54 @@
+"""File-level drop-in: skoots_amd.lib.eval.eval(image_path, checkpoint_path) writes the
+reference's side-effect files (skoots/lib/eval.py:102-103, 286-295, 309-310)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_eval_writes_reference_outputs(tmp_path):
+    from oracle import unet_spec
+    from skoots_amd.lib.eval import eval as sk_eval
+    ref = unet_spec.build()
+    with torch.no_grad():  # open both gates everywhere: prob ~ 0.95, skeleton ~ 0.9
+        ref.heads.weight[3:5].mul_(0.05)
+        ref.heads.bias[3] = 2.2
+        ref.heads.bias[4] = 3.0
+    gen = torch.Generator().manual_seed(0)
+    Z, X, Y = 24, 132, 128
+    img = torch.randint(0, 256, (Z, X, Y), generator=gen, dtype=torch.uint8).numpy()
+    ipath = str(tmp_path / "vol.npy")
+    np.save(ipath, img)
+    cpath = str(tmp_path / "model.trch")
+    cfg = {"SKOOTS": {"VECTOR_SCALING": (60, 60, 12)},
+           "MODEL": {"DIMS": [32, 64, 128, 64, 32], "DEPTHS": [2, 2, 2, 2, 2], "IN_CHANNELS": 1}}
+    torch.save({"cfg": cfg, "model_state_dict": ref.state_dict(), "dataset_mean": 127.0, "dataset_std": 70.0}, cpath)
+
+    sk_eval(ipath, cpath)
+    base = str(tmp_path / "vol")
+    skel = np.load(base + "_skoots_skeleton.npy")
+    vec = np.load(base + "_skoots_vectors.npy")
+    assert skel.shape == (1, X, Y, Z) and skel.dtype == np.uint8
+    assert vec.shape == (3, X, Y, Z) and vec.dtype == np.float16
+    assert "Time:" in open(base + "_skoots_benchmark.txt").read()
+    from PIL import Image
+    with Image.open(base + "_instance_mask.tif") as im:
+        assert im.n_frames == Z
+        pages = []
+        for i in range(Z):
+            im.seek(i)
+            pages.append(np.array(im))
+    mask = np.stack(pages).transpose(1, 2, 0)  # (Z,X,Y) -> (X,Y,Z)
+    # known answer: one connected skeleton inside the written frame, zero frame outside
+    frame = np.zeros((X, Y, Z), bool)
+    frame[50:X - 50, 50:Y - 50, 5:Z - 5] = True
+    assert (skel[0][frame] == 1).all() and (skel[0][~frame] == 0).all()
+    assert (mask[frame] == 1).all() and (mask[~frame] == 0).all()
+    assert np.abs(vec[:, frame].astype(np.float32)).max() > 0 and not vec[:, ~frame].any()
+
+    with pytest.raises(RuntimeError, match="legacy model file"):
+        torch.save({"model_state_dict": ref.state_dict()}, cpath)
+        sk_eval(ipath, cpath)
