@@ -15,8 +15,8 @@ def test_eval_writes_reference_outputs(tmp_path):
     ref = unet_spec.build()
     with torch.no_grad():  # open both gates everywhere: prob ~ 0.95, skeleton ~ 0.9
         ref.heads.weight[3:5].mul_(0.05)
-        ref.heads.weight[0:3].mul_(1e-3)  # |vector| * scale << 0.5 voxel: every voxel maps to itself
-        ref.heads.bias[0:3] = 1e-3
+        ref.heads.weight[0:3].mul_(1e-5)  # 10 hops x |vector| x scale << 0.5 voxel: every voxel maps to itself
+        ref.heads.bias[0:3] = 1e-5
         ref.heads.bias[3] = 2.2
         ref.heads.bias[4] = 3.0
     gen = torch.Generator().manual_seed(0)
