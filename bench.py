@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--shape", type=str, default="", help="override X,Y,Z (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inject", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="tile batches in flight (HIP streams)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -175,7 +176,7 @@ def main():
 
     def step(prof=None):
         return sv.run(image, model, SCALE, mean, std, tile_batch=args.tile_batch, inject=inject,
-                      conv_profile=prof)
+                      conv_profile=prof, streams=args.streams)
 
     def barrier():
         if world > 1:
@@ -212,7 +213,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{X}x{Y}x{Z} fp16 volume, 300x300x20 tiles (margin 50,50,5), "
                                    f"U-Net dims [32,64,128,64,32] depths [2,2,2,2,2], N=10 follow, "
-                                   f"Z-sharded x{world}", "tile_batch": args.tile_batch,
+                                   f"Z-sharded x{world}", "tile_batch": args.tile_batch, "streams": args.streams,
                        "instances": int(res.get("n_instances", -1)), "blobs_injected": n_blobs,
                        "stage_ms": {k: round(v / (args.steps + args.warmup) * 1e3, 2)
                                     for k, v in sv.timings.items()}},

@@ -87,12 +87,14 @@ int sk_follow_assign(const void* vec4, const void* labels, int label_dtype, int3
 
 /* eval.py:145-176 for one tile.  out5: network output of the tile, (5, w, h, d)
  * planar, fp16 or fp32 (thresholds follow torch's scalar casting for that dtype).
- * Writes the tile interior [ov, size-ov) into the volume arrays at origin+ov:
+ * Writes the tile-local box [box_lo, box_hi) (host ints[3]; the tile interior, or the part
+ * of it this tile writes LAST in the reference's scatter order, so that tiles can be
+ * scattered in any order / concurrently) into the volume arrays at origin + box:
  * vec4 (X,Y,Z,4) fp16 and/or vec_planar (3,X,Y,Z) fp16 (either may be NULL),
  * skeleton (X,Y,Z) uint8 in {0,1}.  Dilation = 3x3x3 max then 3x3x1 max twice,
  * zero padded at the tile faces (morphology.py:155-199). */
 int sk_gate_dilate_scatter(const void* out5, int out_dtype, int w, int h, int d,
-                           int ox, int oy, int oz, int ovx, int ovy, int ovz,
+                           int ox, int oy, int oz, const int* box_lo, const int* box_hi,
                            void* vec4, void* vec_planar, uint8_t* skeleton,
                            int X, int Y, int Z, float prob_thr, float skel_thr, void* stream);
 

@@ -18,7 +18,8 @@ namespace {
 struct GateGeom {
     int w, h, d;          // tile extents
     int ox, oy, oz;       // tile origin in the volume
-    int ovx, ovy, ovz;    // margins
+    int lx, ly, lz;       // write box (tile-local, inside the interior): [l, h)
+    int hx, hy, hz;
     int X, Y, Z;          // volume extents
     int px, py;           // interior patch handled per block
     float prob_thr, skel_thr;
@@ -35,17 +36,17 @@ __device__ __forceinline__ float ld<float>(const float* p, long long i) {
     return p[i];
 }
 
-constexpr int RX = 3, RY = 3, RZ = 1;  // 1+1+1 in x,y ; 1 in z  (eval.py:152-157)
+constexpr int RX = 3, RY = 3;  // 1+1+1 in x,y (eval.py:152-157); z radius 1 is hard-wired in phase 2
 
 template <typename T>
 __global__ void __launch_bounds__(256)
 gate_dilate_scatter_kernel(const T* __restrict__ out5, GateGeom g, uint2* __restrict__ vec4,
                            __half* __restrict__ vec_planar, uint8_t* __restrict__ skeleton) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int iw = g.w - 2 * g.ovx, ih = g.h - 2 * g.ovy;  // interior extents
+    const int iw = g.hx - g.lx;  // write-box extent
     const int nbx = (iw + g.px - 1) / g.px;
     const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
-    const int x0 = g.ovx + bx * g.px, y0 = g.ovy + by * g.py;  // tile-local patch origin
+    const int x0 = g.lx + bx * g.px, y0 = g.ly + by * g.py;  // tile-local patch origin
     const int sx = g.px + 2 * RX, sy = g.py + 2 * RY;          // staged columns
     const int d = g.d;
     unsigned char* m0 = smem;                      // [sx][sy][d]
@@ -90,14 +91,14 @@ gate_dilate_scatter_kernel(const T* __restrict__ out5, GateGeom g, uint2* __rest
     }
     __syncthreads();
     // phase 4: x dilation (radius 3) + scatter of the interior
-    const int iz0 = g.ovz, iz1 = d - g.ovz;
+    const int iz0 = g.lz, iz1 = g.hz;
     const int idp = iz1 - iz0;
     for (int i = tid; i < g.px * g.py * idp; i += nth) {
         int zz = i % idp;
         int c = i / idp;
         int ly = c % g.py, lx = c / g.py;
         int tx = x0 + lx, ty = y0 + ly, tz = iz0 + zz;
-        if (tx >= g.w - g.ovx || ty >= g.h - g.ovy) continue;
+        if (tx >= g.hx || ty >= g.hy) continue;
         unsigned char m = 0;
 #pragma unroll
         for (int k = 0; k <= 2 * RX; ++k) m |= m0[((size_t)(lx + k) * g.py + ly) * d + tz];
@@ -168,27 +169,30 @@ __global__ void __launch_bounds__(256) max_filter_kernel(const float* __restrict
 extern "C" {
 
 int sk_gate_dilate_scatter(const void* out5, int out_dtype, int w, int h, int d, int ox, int oy,
-                           int oz, int ovx, int ovy, int ovz, void* vec4, void* vec_planar,
+                           int oz, const int* box_lo, const int* box_hi, void* vec4, void* vec_planar,
                            uint8_t* skeleton, int X, int Y, int Z, float prob_thr, float skel_thr,
                            void* stream) {
-    SK_CHECK_ARG(out5 && skeleton, "sk_gate_dilate_scatter: NULL pointer");
+    SK_CHECK_ARG(out5 && skeleton && box_lo && box_hi, "sk_gate_dilate_scatter: NULL pointer");
     SK_CHECK_ARG(out_dtype == SK_F16 || out_dtype == SK_F32,
                  "sk_gate_dilate_scatter: out dtype must be fp16 or fp32");
     SK_CHECK_ARG(w > 0 && h > 0 && d > 0, "sk_gate_dilate_scatter: bad tile extents");
-    SK_CHECK_ARG(ovx > 0 && ovy > 0 && ovz > 0 && w > 2 * ovx && h > 2 * ovy && d > 2 * ovz,
-                 "sk_gate_dilate_scatter: margins (%d,%d,%d) must be positive and smaller than half "
-                 "the tile (%d,%d,%d)", ovx, ovy, ovz, w, h, d);
+    SK_CHECK_ARG(0 <= box_lo[0] && box_lo[0] < box_hi[0] && box_hi[0] <= w && 0 <= box_lo[1] &&
+                     box_lo[1] < box_hi[1] && box_hi[1] <= h && 0 <= box_lo[2] && box_lo[2] < box_hi[2] &&
+                     box_hi[2] <= d,
+                 "sk_gate_dilate_scatter: write box [%d:%d,%d:%d,%d:%d) must be a non-empty box inside the "
+                 "tile (%d,%d,%d)", box_lo[0], box_hi[0], box_lo[1], box_hi[1], box_lo[2], box_hi[2], w, h, d);
     SK_CHECK_ARG(ox >= 0 && oy >= 0 && oz >= 0 && ox + w <= X && oy + h <= Y && oz + d <= Z,
                  "sk_gate_dilate_scatter: tile [%d+%d,%d+%d,%d+%d) outside volume (%d,%d,%d)", ox, w,
                  oy, h, oz, d, X, Y, Z);
-    GateGeom g{w, h, d, ox, oy, oz, ovx, ovy, ovz, X, Y, Z, 16, 16, prob_thr, skel_thr};
+    GateGeom g{w, h, d, ox, oy, oz, box_lo[0], box_lo[1], box_lo[2], box_hi[0], box_hi[1], box_hi[2],
+               X, Y, Z, 16, 16, prob_thr, skel_thr};
     size_t lds = 2ull * (g.px + 2 * RX) * (g.py + 2 * RY) * d;
     if (lds > 64 * 1024) {
         g.px = g.py = 8;
         lds = 2ull * (g.px + 2 * RX) * (g.py + 2 * RY) * d;
     }
     SK_CHECK_ARG(lds <= 96 * 1024, "sk_gate_dilate_scatter: tile depth %d too large", d);
-    int iw = w - 2 * ovx, ih = h - 2 * ovy;
+    int iw = g.hx - g.lx, ih = g.hy - g.ly;
     unsigned grid = ((iw + g.px - 1) / g.px) * ((ih + g.py - 1) / g.py);
     if (out_dtype == SK_F16) {
         if (lds > 48 * 1024)

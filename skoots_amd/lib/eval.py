@@ -14,6 +14,7 @@ renumber (:304-306).
 """
 from __future__ import annotations
 
+import ctypes as C
 import logging
 import os
 import time
@@ -69,17 +70,31 @@ class VolumeState:
         self.instance: Optional[Tensor] = None
 
     # -- stage 1 tail ------------------------------------------------------------------
-    def scatter_tile(self, out5: Tensor, origin: Sequence[int], overlap=TILE_OVERLAP) -> None:
+    def scatter_tile(self, out5: Tensor, origin: Sequence[int], overlap=TILE_OVERLAP,
+                     owners: Optional[Sequence[np.ndarray]] = None) -> None:
         """Gate + dilate + threshold + interior scatter of one tile's network output
-        (5, w, h, d) fp16/fp32 (eval.py:145-176); ``origin`` in GLOBAL coordinates."""
+        (5, w, h, d) fp16/fp32 (eval.py:145-176); ``origin`` in GLOBAL coordinates.
+
+        ``owners`` (per-axis ``cropper.owner_table``): restrict the write to the part of the
+        interior this tile writes LAST in the reference's order, so that tiles may be
+        scattered in any order (or concurrently on several streams) with the same result."""
         _ffi.require_gpu(out5, "out5")
         assert out5.ndim == 4 and out5.shape[0] == 5
         _, w, h, d = out5.shape
         X, Y, zl = self.local_shape
+        lo = [int(o) for o in overlap]
+        hi = [int(s - o) for s, o in zip((w, h, d), overlap)]
+        if owners is not None:
+            for ax in range(3):
+                own = np.nonzero(owners[ax] == origin[ax])[0]
+                if own.size == 0:
+                    return  # every voxel of this tile's interior is overwritten by later tiles
+                lo[ax], hi[ax] = int(own[0]) - origin[ax], int(own[-1]) + 1 - origin[ax]
         pthr, sthr = thresholds_for(out5.dtype)
+        i3 = C.c_int32 * 3
         _ffi.check(_ffi.lib.sk_gate_dilate_scatter(
             _ffi.ptr(out5), _ffi.dtype_code(out5), w, h, d, origin[0], origin[1],
-            origin[2] - self.window[0], overlap[0], overlap[1], overlap[2], _ffi.ptr(self.vec4),
+            origin[2] - self.window[0], i3(*lo), i3(*hi), _ffi.ptr(self.vec4),
             _ffi.ptr(self.vec_planar), _ffi.ptr(self.skeleton), X, Y, zl, pthr, sthr,
             _ffi.stream_ptr(self.device)))
 

@@ -142,6 +142,13 @@ class ShardedVolume:
         self.slab, self.window = self.slabs[rank], self.windows[rank]
         self.timings: Dict[str, float] = {}
 
+    def _side_stream(self, i: int):
+        if not hasattr(self, "_streams"):
+            self._streams = {}
+        if i not in self._streams:
+            self._streams[i] = torch.cuda.Stream(self.device)
+        return self._streams[i]
+
     def _tick(self, name: str, t0: float) -> None:
         torch.cuda.synchronize(self.device)
         self.timings[name] = self.timings.get(name, 0.0) + time.perf_counter() - t0
@@ -149,7 +156,7 @@ class ShardedVolume:
     def run(self, image: Tensor, model, scale, mean: float, std: float, n: int = 10,
             decay: float = 1.0, tile=(300, 300, 20), tile_overlap=(50, 50, 5), tile_batch: int = 4,
             inject: Optional[Callable] = None, keep_planar_vectors: bool = False,
-            conv_profile=None) -> Dict[str, object]:
+            conv_profile=None, streams: int = 1) -> Dict[str, object]:
         """``image``: this rank's window of the fp16 volume, shape (X, Y, window planes)."""
         from . import _ffi
         from .lib.eval import ASSIGN_CROP, ASSIGN_OVERLAP, VolumeState
@@ -167,19 +174,32 @@ class ShardedVolume:
         origins, eff = tiles_for_slab(self.shape, tile, tile_overlap, self.slab)
         for (_, _, oz) in origins:
             assert wlo <= oz and oz + eff[2] <= whi, "tile outside the rank's window: increase the halo"
-        if model is not None and conv_profile is not None:
-            model.profile = conv_profile
-        for i in range(0, len(origins), tile_batch):
+        owners = [cropper.owner_table(dm, c, o) for dm, c, o in zip(self.shape, eff, tile_overlap)]
+        n_streams = max(1, int(streams)) if model is not None else 1
+        ctxs = [model] + [model.clone_context() for _ in range(n_streams - 1)] if model is not None else [None]
+        for c in ctxs:
+            if c is not None:
+                c.profile = conv_profile
+        main = torch.cuda.current_stream(dev)
+        lanes = [main] + [self._side_stream(i) for i in range(n_streams - 1)]
+        for s_ in lanes[1:]:
+            s_.wait_stream(main)
+        for bi, i in enumerate(range(0, len(origins), tile_batch)):
             batch = origins[i:i + tile_batch]
             local = [(x, y, z - wlo) for (x, y, z) in batch]
-            out5 = model.forward_tiles(image, local, eff, mean, std) if model is not None else None
-            for b, org in enumerate(batch):
-                o = out5[b] if out5 is not None else None
-                if inject is not None:
-                    o = inject(o, (org[0], org[1], org[2] - wlo), eff)
-                state.scatter_tile(o, org, tile_overlap)
-        if model is not None:
-            model.profile = None
+            k = bi % n_streams
+            with torch.cuda.stream(lanes[k]):
+                out5 = ctxs[k].forward_tiles(image, local, eff, mean, std) if model is not None else None
+                for b, org in enumerate(batch):
+                    o = out5[b] if out5 is not None else None
+                    if inject is not None:
+                        o = inject(o, (org[0], org[1], org[2] - wlo), eff)
+                    state.scatter_tile(o, org, tile_overlap, owners=owners)
+        for s_ in lanes[1:]:
+            main.wait_stream(s_)
+        for c in ctxs:
+            if c is not None:
+                c.profile = None
         self._tick("stage1", t0)
 
         # ---- stage 2 --------------------------------------------------------------------

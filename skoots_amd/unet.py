@@ -59,14 +59,19 @@ class ConvProfile:
     the stream the kernels are launched on; bench.py turns it into the roofline figure."""
 
     def __init__(self):
-        self.events = []  # (start, end, flops)
+        self.events = []  # (start, end, flops, layer name)
+
+    def named(self):
+        if self.events:
+            self.events[-1][1].synchronize()
+        return list(self.events)
 
     def totals(self):
         if not self.events:
             return 0.0, 0.0, 0
         self.events[-1][1].synchronize()
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.events)
-        return ms, sum(f for _, _, f in self.events), len(self.events)
+        ms = sum(e[0].elapsed_time(e[1]) for e in self.events)
+        return ms, sum(e[2] for e in self.events), len(self.events)
 
 
 class HipUNet:
@@ -103,6 +108,16 @@ class HipUNet:
         self._bufs: Dict[Tuple, Tensor] = {}
         self.last_features: Dict[str, Tensor] = {}
         self.profile: Optional[ConvProfile] = None
+
+    def clone_context(self) -> "HipUNet":
+        """Same weights, separate activation buffers: lets two tile batches be in flight on two
+        HIP streams (the HBM-bound GN/heads kernels of one overlap the MFMA-bound convs of the other)."""
+        import copy
+        other = copy.copy(self)
+        other._bufs = {}
+        other.last_features = {}
+        other.profile = None
+        return other
 
     # -- reference-compatible construction ---------------------------------------------
     @classmethod
@@ -158,7 +173,7 @@ class HipUNet:
                                       _ffi.ptr(partial), _ffi.ptr(self.zeros), _ffi.stream_ptr(self.device)))
         if timed:
             e1.record(torch.cuda.current_stream(self.device))
-            self.profile.events.append((e0, e1, layer.flops_per_out_voxel * B * ox * oy * oz))
+            self.profile.events.append((e0, e1, layer.flops_per_out_voxel * B * ox * oy * oz, layer.name))
         if activate:
             self._norm_act(layer, out, partial, nblk)
         return out
