@@ -28,6 +28,8 @@
 //     accumulates per-channel-quad (sum, sumsq) of the fp32 accumulators for the
 //     GroupNorm that follows; per-block partials are reduced in a fixed order by
 //     sk_groupnorm_finalize (deterministic, no float atomics).
+#include <stdlib.h>
+
 #include <vector>
 
 #include "common.h"
@@ -43,6 +45,8 @@ constexpr int kChunk = 32;       // input channels per LDS image
 constexpr int kPosBytes = 64;    // kChunk * sizeof(fp16)
 constexpr int kPatch = 128;      // voxels per (y,z) patch = 4 waves x 32 columns
 constexpr int kMaxDma = 4;       // DMA wave-instructions per plane per wave (nposp <= 256)
+constexpr int kPadStride = 64;   // bytes per voxel in the epilogue transpose pad (16-B chunks XOR-swizzled)
+constexpr int kPadBytes = 32 * kPadStride;
 
 struct SrcDev {
     const char* data;
@@ -66,6 +70,7 @@ struct Conv3Args {
     int mode;           // 0: linear (y,z) ranges (small Zt), 1: TY x TZ rectangles
     int TZ, nzc;
     int pitch, nposp;
+    int ablate;         // timing experiments only (SK_CONV_ABLATE): 1 skip DMA, 2 reuse first weights, 4 skip stores
 };
 
 __device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
@@ -104,7 +109,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     const int pitch = a.pitch;
     int off, ybase, zbase;      // region position q -> (y, z): Pq = q + off; y = ybase + Pq/pitch; z = zbase + Pq%pitch
     int q_row[P];               // region position of this lane's voxel in column tile p
-    long long out_vox[P];       // in-plane voxel index of the output
+    long long out_vox0[P];      // in-plane voxel index of column 0 of tile p (the 32 columns are contiguous)
+    long long tile_nvox[P];     // columns with out_vox0 + c < tile_nvox are inside the tile
     bool vvalid[P];
     if (a.mode == 0) {
         int v0 = patch * kPatch;
@@ -118,7 +124,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             int vy = v / a.Zt, vz = v - vy * a.Zt;
             vvalid[p] = v < a.Yt * a.Zt;
             q_row[p] = (vy + 1) * pitch + (vz + 1) - (y0 * pitch + z0);
-            out_vox[p] = (long long)vy * a.Zt + vz;
+            out_vox0[p] = v0 + 32 * (wm * P + p);
+            tile_nvox[p] = (long long)a.Yt * a.Zt;
         }
     } else {
         const int TY = kPatch / a.TZ;
@@ -134,7 +141,10 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             int vy = y0 + yl, vz = zc0 + zl;
             vvalid[p] = vy < a.Yt && vz < a.Zt;
             q_row[p] = (yl + 1) * pitch + (zl + 1);
-            out_vox[p] = (long long)vy * a.Zt + vz;
+            // a column tile is one 32-voxel z segment of one line (TZ == 32)
+            const int ty = y0 + (32 * (wm * P + p)) / a.TZ;
+            out_vox0[p] = (long long)ty * a.Zt + zc0;
+            tile_nvox[p] = ty < a.Yt ? (long long)ty * a.Zt + a.Zt : 0;
         }
     }
 
@@ -192,7 +202,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             const int choff = (ch - (si ? a.c0chunks : 0)) * kChunk * 2;  // byte offset of the chunk
             const int first_new = (ring && step > 0) ? 2 : 0;  // planes 0,1 survive in the ring
             __syncthreads();  // every wave is done reading the planes about to be overwritten
-            for (int i = first_new; i < R; ++i) {
+            for (int i = (a.ablate & 1) ? R : first_new; i < R; ++i) {
                 const int x = x0 - 1 + i;
                 const int slotp = ring ? (step * XS + i) % R : i;
                 const bool xok = x >= 0 && x < a.Xt;
@@ -219,6 +229,24 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wch + (d * NT) * 1024);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if (a.ablate & 8) {  // timing experiment: in-LDS affine + SiLU pass over the new planes
+                for (int i = first_new; i < R; ++i) {
+                    const int slotp = ring ? (step * XS + i) % R : i;
+                    char* lbase = lds + slotp * plane_bytes;
+                    for (int sidx = tid; sidx < a.nposp * 4; sidx += 256) {
+                        half8 v = *reinterpret_cast<half8*>(lbase + sidx * 16);
+                        half8 r;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float y = fmaf(1.0f + 0.001f * j, (float)v[j], 0.01f * j);
+                            float e = __builtin_amdgcn_exp2f(-1.442695f * y);
+                            r[j] = (_Float16)(y * __builtin_amdgcn_rcpf(1.0f + e));
+                        }
+                        *reinterpret_cast<half8*>(lbase + sidx * 16) = r;
+                    }
+                }
+                __syncthreads();
+            }
 
             // ---------------- MFMA over the 27 taps of this chunk ---------------------------
             int pslot[R];
@@ -243,9 +271,12 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                     }
                 }
             };
+            // hipcc schedules the ds_read / MFMA interleave of a (dydz, ks) body itself (pinning
+            // it with sched_barrier measured 8 % slower); the weight fragments of the next body
+            // are requested one body ahead.
 #pragma unroll 1
             for (int dydz = 0; dydz < 9; ++dydz) {
-                const char* wrow = wch + (long long)(dydz * 2) * (3 * NT) * 1024;
+                const char* wrow = wch + (long long)(((a.ablate & 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
                     a1[d] = *reinterpret_cast<const half8*>(wrow + ((3 + d) * NT) * 1024);
@@ -260,22 +291,39 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
         }
 
         // ---------------- epilogue: raw fp16 store + GroupNorm partial sums ------------------
+        // The accumulator tile is [cout rows in registers][voxel columns on lanes]; the output
+        // is channels-last.  Each wave transposes its 32x32 tile through a private 2 KiB LDS
+        // pad (16-B chunks XOR-swizzled) so that every lane stores 16 contiguous bytes and one store
+        // instruction writes 1 KiB of whole 64-B voxel lines (4 lanes per line).
+        char* pad = lds + R * plane_bytes + w * kPadBytes;
+        const int rv = lane >> 2, rc = lane & 3;  // read-back: voxel (0..15), 16-byte chunk
 #pragma unroll
         for (int p = 0; p < P; ++p) {
+            const long long tile_vox0 = out_vox0[p];  // in-plane index of the tile's first voxel
 #pragma unroll
             for (int o = 0; o < XS; ++o) {
                 const int x = x0 + o;
                 const bool ok = vvalid[p] && x < xb;
-                char* op = outb + (long long)x * out_plane + out_vox[p] * (COUT * 2);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v0 = acc[p][o][4 * q], v1 = acc[p][o][4 * q + 1];
                     float v2 = acc[p][o][4 * q + 2], v3 = acc[p][o][4 * q + 3];
+                    half4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+                    *reinterpret_cast<half4*>(pad + col * kPadStride + ((q ^ ((col >> 1) & 3)) * 16) + 8 * h) = hv;
                     if (ok) {
-                        half4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-                        *reinterpret_cast<half4*>(op + (32 * wn + 8 * q + 4 * h) * 2) = hv;
                         gsum[q] += (v0 + v1) + (v2 + v3);
                         gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                    }
+                }
+                if (x < xb && !(a.ablate & 4)) {
+                    char* op = outb + (long long)x * out_plane + tile_vox0 * (COUT * 2) + wn * 64;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int vv = rv + 16 * hh;
+                        const half8 line = *reinterpret_cast<const half8*>(
+                            pad + vv * kPadStride + ((rc ^ ((vv >> 1) & 3)) * 16));
+                        if (tile_vox0 + vv < tile_nvox[p])
+                            *reinterpret_cast<half8*>(op + (long long)vv * (COUT * 2) + rc * 16) = line;
                     }
                 }
             }
@@ -479,7 +527,7 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
         p.nposp = ((TY + 2) * p.pitch + 15) / 16 * 16;
     }
     if (p.nposp > 64 * kMaxDma) return -1;
-    p.lds = (size_t)(p.xs + 2) * p.nposp * kPosBytes;
+    p.lds = (size_t)(p.xs + 2) * p.nposp * kPosBytes + 4 * kPadBytes;
     // x-chunks: enough workgroups to fill 256 CUs x 2 several times over
     int target = 256 * 2 * 6;
     int nxc = (target + p.npatch * B - 1) / (p.npatch * B);
@@ -608,6 +656,10 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
         a.nzc = p.nzc;
         a.pitch = p.pitch;
         a.nposp = p.nposp;
+        {
+            const char* e = getenv("SK_CONV_ABLATE");
+            a.ablate = e ? atoi(e) : 0;
+        }
         if (cout == 32) return launch_conv3<32, 4>(a, p, stream);
         if (cout == 64) return launch_conv3<64, 4>(a, p, stream);
         return launch_conv3<128, 2>(a, p, stream);
