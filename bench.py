@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--tile-batch", type=int, default=4)
+    ap.add_argument("--tile-batch", type=int, default=8)
     ap.add_argument("--shape", type=str, default="", help="override X,Y,Z (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inject", action="store_true")

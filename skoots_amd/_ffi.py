@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libskoots_hip.so")
+LIB_PATH = os.environ.get("SKOOTS_HIP_LIB") or os.path.join(_HERE, "libskoots_hip.so")  # override: A/B kernel builds
 
 SK_F16, SK_F32, SK_I16, SK_I32, SK_U8 = 0, 1, 2, 3, 4
 
