@@ -34,14 +34,21 @@ def _seam_planes(origins) -> Tuple[List[int], List[int], List[int]]:
     return seams
 
 
-def label_skeleton(skeleton_u8: Tensor, crop=FLOOD_CROP) -> Tensor:
-    """(X, Y, Z) uint8 binary skeleton on the GPU -> (X, Y, Z) int32 labels."""
+def label_skeleton(skeleton_u8: Tensor, crop=FLOOD_CROP, reference_ids: bool = True) -> Tensor:
+    """(X, Y, Z) uint8 binary skeleton on the GPU -> (X, Y, Z) int32 labels.
+
+    ``reference_ids=True`` reproduces the reference's label VALUES (its 1000x1000x200 crop grid
+    re-labels the overlap of clamped crops, 8x at 1024x1024x256).  ``False`` labels the whole
+    volume as one crop: same partition, ids 3..K+2 in raster order -- what the eval pipeline
+    needs, since stage 3 + renumber only consume the partition."""
     _ffi.require_gpu(skeleton_u8, "skeleton")
     assert skeleton_u8.dtype == torch.uint8 and skeleton_u8.ndim == 3
     X, Y, Z = skeleton_u8.shape
     dev = skeleton_u8.device
     st = _ffi.stream_ptr(dev)
     crop_l = list(crop)
+    if not reference_ids and X * Y * Z < 2 ** 31 - 4096:
+        crop_l = [X, Y, Z]
     origins = cropper.crop_origins((X, Y, Z), crop_l, (0, 0, 0))
     w, h, d = crop_l
     labels = torch.empty((X, Y, Z), dtype=torch.int32, device=dev)

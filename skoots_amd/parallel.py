@@ -124,7 +124,8 @@ def exchange_halo(arr: Tensor, slabs, windows, rank: int, comm: Comm) -> None:
     sends, recvs = halo_plan(slabs, windows, rank)
     w0 = windows[rank][0]
     out = [(q, arr[:, :, lo - w0:hi - w0]) for q, lo, hi in sends]
-    like = [(q, torch.empty_like(arr[:, :, lo - w0:hi - w0])) for q, lo, hi in recvs]
+    like = [(q, torch.empty((arr.shape[0], arr.shape[1], hi - lo) + tuple(arr.shape[3:]), dtype=arr.dtype,
+                            device=arr.device)) for q, lo, hi in recvs]
     got = comm.exchange(out, like)
     for (q, lo, hi), t in zip(recvs, got):
         arr[:, :, lo - w0:hi - w0] = t
@@ -205,7 +206,7 @@ class ShardedVolume:
         # ---- stage 2 --------------------------------------------------------------------
         t0 = time.perf_counter()
         if self.world == 1:
-            labels = label_skeleton(state.skeleton)
+            labels = label_skeleton(state.skeleton, reference_ids=False)
             n_labels_hint = None
         else:
             labels, n_labels_hint = label_slab(state.skeleton, self.shape, self.slab, self.window,
