@@ -279,11 +279,13 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
 #pragma unroll 1
             for (int dydz = 0; dydz < 9; ++dydz) {
                 const char* wrow = wch + (long long)(((a.ablate & 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
+                if (!(a.ablate & 32) || dydz == 0) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d)
-                    a1[d] = *reinterpret_cast<const half8*>(wrow + ((3 + d) * NT) * 1024);
+                    for (int d = 0; d < 3; ++d)
+                        a1[d] = *reinterpret_cast<const half8*>(wrow + ((3 + d) * NT) * 1024);
+                }
                 compute(dydz, 0, a0);
-                if (dydz < 8) {
+                if (dydz < 8 && !(a.ablate & 32)) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
                         a0[d] = *reinterpret_cast<const half8*>(wrow + ((6 + d) * NT) * 1024);
