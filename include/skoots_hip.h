@@ -169,9 +169,11 @@ int sk_renumber(int32_t* labels, int64_t n, int max_label, void* workspace,
  * ------------------------------------------------------------------------ */
 
 typedef struct sk_conv_src {
-    const void* data;   /* (B, sx, sy, sz, c) fp16 channels-last, activated                 */
-    int c;              /* channels of this source (multiple of 32 for ksize 3)            */
-    int upsample;       /* 1: source is half resolution, read at (x>>1, y>>1, z>>1)        */
+    const void* data;    /* (B, sx, sy, sz, c) fp16 channels-last                            */
+    const float* affine; /* NULL: data is activated.  (B, 2, c) fp32: data is a RAW conv output, */
+                         /* silu(a*x + b) is applied on load (ksize 1 / 2 only)               */
+    int c;               /* channels of this source (multiple of 32 for ksize 3)            */
+    int upsample;        /* 1: source is half resolution, read at (x>>1, y>>1, z>>1)        */
 } sk_conv_src;
 
 /* Implicit-GEMM 3-D convolution on the matrix cores (v_mfma_f32_32x32x16_f16).
@@ -215,11 +217,12 @@ int sk_groupnorm_finalize(const float* gn_partial, int B, int nblocks, int group
 /* Fused GroupNorm affine + SiLU, in place on (B, voxels, C) fp16. */
 int sk_groupnorm_silu(void* x, const float* affine, int B, int64_t voxels, int C, void* stream);
 
-/* Heads: 1x1x1 conv C->5 on the activated features, tanh on [0:3], sigmoid on [3:5];
- * out5 (B, 5, voxels) planar fp16 = the reference's output layout (eval.py:145-147).
+/* Heads: 1x1x1 conv C->5, tanh on [0:3], sigmoid on [3:5]; out5 (B, 5, voxels) planar fp16 =
+ * the reference's output layout (eval.py:145-147).  x: (B, voxels, C) fp16, activated if
+ * affine == NULL, else RAW with affine (B, 2, C) applied (+ SiLU) on load.
  * weight (5, C) fp32, bias (5). */
-int sk_heads(const void* x, const float* weight, const float* bias, void* out5, int B,
-             int64_t voxels, int C, void* stream);
+int sk_heads(const void* x, const float* affine, const float* weight, const float* bias, void* out5,
+             int B, int64_t voxels, int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -41,7 +41,7 @@ ip = C.POINTER(C.c_int32)
 
 
 class ConvSrc(C.Structure):
-    _fields_ = [("data", vp), ("c", i32), ("upsample", i32)]
+    _fields_ = [("data", vp), ("affine", vp), ("c", i32), ("upsample", i32)]
 
 
 _SIGS = {
@@ -73,7 +73,7 @@ _SIGS = {
     "sk_conv3d_stem_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "sk_groupnorm_finalize": (i32, [vp, i32, i32, i32, i32, i64, vp, vp, f32, vp, vp]),
     "sk_groupnorm_silu": (i32, [vp, vp, i32, i64, i32, vp]),
-    "sk_heads": (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
+    "sk_heads": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, vp]),
 }
 
 EXPORTS = tuple(_SIGS)

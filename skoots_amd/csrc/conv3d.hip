@@ -642,6 +642,7 @@ __global__ void __launch_bounds__(kPipeThreads) conv3p_kernel(Conv3Args a) {
 // ------------------------------------------------------------------------------------------
 struct GatherArgs {
     const char* in;
+    const float* affine;    // (B, 2, Cin) fp32 or NULL: input is RAW, apply silu(a*x + b) on load
     const char* wpk;
     const float* bias;
     char* out;
@@ -700,10 +701,26 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
             for (int nt = 0; nt < NT; ++nt)
                 afr[nt] = *reinterpret_cast<const half8*>(
                     a.wpk + ((long long)(tap * nks + ks) * NT + nt) * 1024 + lane * 16);
+            float ga[8], gb[8];
+            if (a.affine) {  // this lane's 8 input channels of the K step
+                const float* ap = a.affine + (long long)b * 2 * a.Cin + ks * 16 + 8 * h;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    ga[j] = ap[j];
+                    gb[j] = ap[a.Cin + j];
+                }
+            }
 #pragma unroll
             for (int p = 0; p < PV; ++p) {
                 half8 bfr = *reinterpret_cast<const half8*>(
                     inb + ((vin[p] + toff) * a.Cin + ks * 16 + 8 * h) * 2);
+                if (a.affine) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float y = fmaf(ga[j], (float)bfr[j], gb[j]);
+                        bfr[j] = (_Float16)(y * (1.0f / (1.0f + __expf(-y))));
+                    }
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[nt], bfr, acc[p][nt], 0, 0, 0);
@@ -915,6 +932,9 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
         for (int i = 0; i < n_src; ++i) {
             SK_CHECK_ARG(srcs[i].data && srcs[i].c > 0 && srcs[i].c % kChunk == 0,
                          "sk_conv3d: source %d must have a multiple of 32 channels", i);
+            SK_CHECK_ARG(srcs[i].affine == nullptr,
+                         "sk_conv3d: ksize 3 stages its input by LDS-DMA and needs ACTIVATED sources "
+                         "(affine must be NULL)");
             SK_CHECK_ARG(i == 1 || !srcs[i].upsample, "sk_conv3d: only the second source may be upsampled");
             int up = srcs[i].upsample ? 1 : 0;
             SK_CHECK_ARG(!up || (ox % 2 == 0 && oy % 2 == 0 && oz % 2 == 0),
@@ -965,6 +985,7 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
     SK_CHECK_ARG(srcs[0].c % 16 == 0, "sk_conv3d: cin must be a multiple of 16");
     GatherArgs g{};
     g.in = (const char*)srcs[0].data;
+    g.affine = srcs[0].affine;
     g.wpk = (const char*)weight;
     g.bias = bias;
     g.out = (char*)out;

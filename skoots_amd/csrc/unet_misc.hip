@@ -223,7 +223,8 @@ __global__ void __launch_bounds__(256) gn_silu_kernel(__half* __restrict__ x,
 
 // ------------------------------------------------------------------------------ heads
 struct HeadArgs {
-    const __half* x;     // (B, n, C) fp16 activated
+    const __half* x;     // (B, n, C) fp16 (activated, or raw when affine != NULL)
+    const float* affine; // (B, 2, C) or NULL
     const float* weight; // (5, C)
     const float* bias;   // (5)
     __half* out5;        // (B, 5, n)
@@ -234,10 +235,12 @@ struct HeadArgs {
 template <int C>
 __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
     __shared__ float wsm[5 * C + 8];
+    __shared__ float asm_[2 * C];
+    const int b = blockIdx.y;
     for (int i = threadIdx.x; i < 5 * C; i += 256) wsm[i] = a.weight[i];
     if (threadIdx.x < 5) wsm[5 * C + threadIdx.x] = a.bias[threadIdx.x];
+    if (a.affine && threadIdx.x < 2 * C) asm_[threadIdx.x] = a.affine[(long long)b * 2 * C + threadIdx.x];
     __syncthreads();
-    const int b = blockIdx.y;
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n) return;
     const half8* p = reinterpret_cast<const half8*>(a.x + ((long long)b * a.n + i) * C);
@@ -250,6 +253,11 @@ __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float f = (float)v[j];
+            if (a.affine) {
+                float y = fmaf(asm_[c8 * 8 + j], f, asm_[C + c8 * 8 + j]);
+                // the activated value is rounded to fp16 exactly as the in-place pass would store it
+                f = (float)(_Float16)(y * (1.0f / (1.0f + __expf(-y))));
+            }
 #pragma unroll
             for (int k = 0; k < 5; ++k) o[k] = fmaf(wsm[k * C + c8 * 8 + j], f, o[k]);
         }
@@ -342,11 +350,11 @@ int sk_groupnorm_silu(void* x, const float* affine, int B, int64_t voxels, int C
     return SK_OK;
 }
 
-int sk_heads(const void* x, const float* weight, const float* bias, void* out5, int B, int64_t voxels,
-             int C, void* stream) {
+int sk_heads(const void* x, const float* affine, const float* weight, const float* bias, void* out5, int B,
+             int64_t voxels, int C, void* stream) {
     SK_CHECK_ARG(x && weight && bias && out5, "sk_heads: NULL pointer");
     SK_CHECK_ARG(C == 32, "sk_heads: C must be 32");
-    HeadArgs a{(const __half*)x, weight, bias, (__half*)out5, voxels, C};
+    HeadArgs a{(const __half*)x, affine, weight, bias, (__half*)out5, voxels, C};
     dim3 grid(sk::cdiv(voxels, 256), B);
     heads_kernel<32><<<grid, 256, 0, (hipStream_t)stream>>>(a);
     SK_CHECK_LAUNCH();

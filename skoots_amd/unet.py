@@ -108,6 +108,8 @@ class HipUNet:
         self._bufs: Dict[Tuple, Tensor] = {}
         self.last_features: Dict[str, Tensor] = {}
         self.profile: Optional[ConvProfile] = None
+        import os
+        self.defer_activation = os.environ.get("SK_DEFER_ACT", "1") != "0"  # A/B switch
 
     def clone_context(self) -> "HipUNet":
         """Same weights, separate activation buffers: lets two tile batches be in flight on two
@@ -137,7 +139,10 @@ class HipUNet:
         return t
 
     # -- layer launchers ---------------------------------------------------------------
-    def _norm_act(self, layer: _ConvLayer, x: Tensor, partial: Tensor, nblk: int) -> None:
+    def _norm_act(self, layer: _ConvLayer, x: Tensor, partial: Tensor, nblk: int, apply: bool = True) -> Tensor:
+        """GroupNorm statistics -> per-channel affine; ``apply`` runs the fused affine + SiLU pass in
+        place.  With ``apply=False`` the tensor stays RAW and the (single) consumer applies the affine
+        on load (gather GEMM / heads: every element is read exactly once there)."""
         B = x.shape[0]
         vox = x.shape[1] * x.shape[2] * x.shape[3]
         aff = self._buf("affine_" + layer.name, (B, 2, layer.cout), torch.float32)
@@ -145,10 +150,14 @@ class HipUNet:
         _ffi.check(_ffi.lib.sk_groupnorm_finalize(_ffi.ptr(partial), B, nblk, GN_GROUPS, layer.cout, vox,
                                                   _ffi.ptr(layer.gamma), _ffi.ptr(layer.beta), GN_EPS,
                                                   _ffi.ptr(aff), st))
-        _ffi.check(_ffi.lib.sk_groupnorm_silu(_ffi.ptr(x), _ffi.ptr(aff), B, vox, layer.cout, st))
+        if apply:
+            _ffi.check(_ffi.lib.sk_groupnorm_silu(_ffi.ptr(x), _ffi.ptr(aff), B, vox, layer.cout, st))
+        return aff
 
-    def _conv(self, layer: _ConvLayer, srcs: List[Tuple[Tensor, int]], out_shape: Tuple[int, int, int],
-              tag: str, activate: bool = True) -> Tensor:
+    def _conv(self, layer: _ConvLayer, srcs: List[Tuple], out_shape: Tuple[int, int, int],
+              tag: str, activate: bool = True):
+        """srcs: [(tensor, upsample flag[, affine])].  Returns the activated output, or
+        (raw output, affine) when ``activate`` is False."""
         B = srcs[0][0].shape[0]
         ox, oy, oz = out_shape
         out = self._buf(tag, (B, ox, oy, oz, layer.cout))
@@ -158,8 +167,10 @@ class HipUNet:
         partial = self._buf("partial", (B * nblk * (layer.cout // 4) * 2,), torch.float32)
         arr = (_ffi.ConvSrc * len(srcs))()
         cin = 0
-        for i, (t, up) in enumerate(srcs):
+        for i, src in enumerate(srcs):
+            t, up = src[0], src[1]
             arr[i].data = t.data_ptr()
+            arr[i].affine = src[2].data_ptr() if len(src) > 2 and src[2] is not None else None
             arr[i].c = t.shape[-1]
             arr[i].upsample = up
             cin += t.shape[-1]
@@ -174,9 +185,8 @@ class HipUNet:
         if timed:
             e1.record(torch.cuda.current_stream(self.device))
             self.profile.events.append((e0, e1, layer.flops_per_out_voxel * B * ox * oy * oz, layer.name))
-        if activate:
-            self._norm_act(layer, out, partial, nblk)
-        return out
+        aff = self._norm_act(layer, out, partial, nblk, apply=activate)
+        return out if activate else (out, aff)
 
     def _stem(self, layer: _ConvLayer, image: Tensor, origins, tile, mean: float, std: float,
               tag: str = "L0a") -> Tensor:
@@ -232,27 +242,37 @@ class HipUNet:
         a = self._conv(self.down1, [(s1, 0)], L2, "L2a")
         keep("down1", a)
         tags = ["L2b", "L2a"]
+        aff = None
         for i, layer in enumerate(self.mid):
-            a = self._conv(layer, [(a, 0)], L2, tags[i % 2])
+            last = self.defer_activation and i == len(self.mid) - 1  # only red1 (1x1x1, gather GEMM) reads it: activate on load
+            a = self._conv(layer, [(a, 0)], L2, tags[i % 2], activate=not last)
+            if last:
+                a, aff = a
             keep(layer.name, a)
-        r1 = self._conv(self.red1, [(a, 0)], L2, "L2r")
+        r1 = self._conv(self.red1, [(a, 0, aff)], L2, "L2r")
         keep("red1", r1)
         tags = ["L1a", "L1b"]
-        a = self._conv(self.dec1[0], [(s1, 0), (r1, 1)], L1, tags[0])
-        keep("dec1.0", a)
-        for i, layer in enumerate(self.dec1[1:]):
-            a = self._conv(layer, [(a, 0)], L1, tags[(i + 1) % 2])
+        aff = None
+        for i, layer in enumerate(self.dec1):
+            last = self.defer_activation and i == len(self.dec1) - 1  # consumed only by red0
+            src = [(s1, 0), (r1, 1)] if i == 0 else [(a, 0)]
+            a = self._conv(layer, src, L1, tags[i % 2], activate=not last)
+            if last:
+                a, aff = a
             keep(layer.name, a)
-        r0 = self._conv(self.red0, [(a, 0)], L1, "L1r")
+        r0 = self._conv(self.red0, [(a, 0, aff)], L1, "L1r")
         keep("red0", r0)
         tags = ["L0a", "L0b"]
-        a = self._conv(self.dec0[0], [(s0, 0), (r0, 1)], L0, tags[0])
-        keep("dec0.0", a)
-        for i, layer in enumerate(self.dec0[1:]):
-            a = self._conv(layer, [(a, 0)], L0, tags[(i + 1) % 2])
+        aff = None
+        for i, layer in enumerate(self.dec0):
+            last = self.defer_activation and i == len(self.dec0) - 1  # consumed only by the heads
+            src = [(s0, 0), (r0, 1)] if i == 0 else [(a, 0)]
+            a = self._conv(layer, src, L0, tags[i % 2], activate=not last)
+            if last:
+                a, aff = a
             keep(layer.name, a)
         out5 = self._buf("out5", (B, 5, xt, yt, zt))
-        _ffi.check(_ffi.lib.sk_heads(_ffi.ptr(a), _ffi.ptr(self.head_w), _ffi.ptr(self.head_b),
+        _ffi.check(_ffi.lib.sk_heads(_ffi.ptr(a), _ffi.ptr(aff), _ffi.ptr(self.head_w), _ffi.ptr(self.head_b),
                                      _ffi.ptr(out5), B, xt * yt * zt, a.shape[-1],
                                      _ffi.stream_ptr(self.device)))
         return out5
@@ -345,6 +365,7 @@ def conv3d(srcs: List[Tuple[Tensor, int]], packed_weight: Tensor, bias: Tensor, 
     for i, (t, up) in enumerate(srcs):
         _ffi.require_gpu(t, "src")
         arr[i].data = t.data_ptr()
+        arr[i].affine = None
         arr[i].c = t.shape[-1]
         arr[i].upsample = up
     _ffi.check(_ffi.lib.sk_conv3d(arr, len(srcs), _ffi.ptr(packed_weight), _ffi.ptr(bias), _ffi.ptr(out), B,
