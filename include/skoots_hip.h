@@ -196,15 +196,22 @@ int sk_conv3d_num_blocks(int B, int ox, int oy, int oz, int cout, int ksize);
 int64_t sk_conv3d_pack_weight_host(const float* w_host, int cout, int cin, int ksize,
                                    void* dst_host);
 
-/* Stem: first conv of the network (Cin = 1).  Reads B tiles of extent (Xt,Yt,Zt) at
- * origins_host[3*b..] straight from the (X,Y,Z) fp16 image volume, normalises
- * (x - mean)/std in fp16 arithmetic exactly as eval.py:139 into a zero-framed workspace,
- * then conv3 on the exact-fp32 matrix instruction -> out (B, Xt, Yt, Zt, 32) fp16 raw +
- * gn partials (B, stem_num_blocks, 8, 2).  weight (27, 32) fp32 [tap=(dx*3+dy)*3+dz][cout]. */
+/* Stem: first conv of the network (Cin = 1), fused with its GroupNorm + SiLU by running the
+ * (cheap) conv twice instead of writing a raw tensor and re-reading it.
+ * sk_conv3d_stem: cuts B tiles of extent (Xt,Yt,Zt) at origins_host[3*b..] out of the (X,Y,Z)
+ *   fp16 image volume, normalises (x - mean)/std in fp16 arithmetic exactly as eval.py:139 into
+ *   the zero-framed workspace, runs the conv (weights split into fp16 hi + lo, exact products,
+ *   fp32 accumulation) and writes ONLY the GroupNorm partials (B, stem_num_blocks, 8, 2).
+ * sk_conv3d_stem_apply (after sk_groupnorm_finalize): recomputes the conv from the same
+ *   workspace, applies the affine (B, 2, 32) + SiLU and stores out (B, Xt, Yt, Zt, 32) fp16
+ *   ACTIVATED.  weight (27, 32) fp32 [tap=(dx*3+dy)*3+dz][cout]. */
 int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origins_host, int B,
                    int Xt, int Yt, int Zt, float mean, float std, const float* weight,
-                   const float* bias, void* out, int cout, float* gn_partial, void* workspace,
+                   const float* bias, int cout, float* gn_partial, void* workspace,
                    size_t workspace_bytes, void* stream);
+int sk_conv3d_stem_apply(int B, int Xt, int Yt, int Zt, const float* weight, const float* bias,
+                         const float* affine, void* out, int cout, const void* workspace,
+                         void* stream);
 int sk_conv3d_stem_num_blocks(int X, int Y, int Z);
 size_t sk_conv3d_stem_workspace_bytes(int B, int Xt, int Yt, int Zt);
 

@@ -67,8 +67,8 @@ _SIGS = {
     "sk_conv3d": (i32, [C.POINTER(ConvSrc), i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "sk_conv3d_num_blocks": (i32, [i32, i32, i32, i32, i32, i32]),
     "sk_conv3d_pack_weight_host": (i64, [fp, i32, i32, i32, vp]),
-    "sk_conv3d_stem": (i32, [vp, i32, i32, i32, ip, i32, i32, i32, i32, f32, f32, vp, vp, vp, i32, vp, vp, sz,
-                             vp]),
+    "sk_conv3d_stem": (i32, [vp, i32, i32, i32, ip, i32, i32, i32, i32, f32, f32, vp, vp, i32, vp, vp, sz, vp]),
+    "sk_conv3d_stem_apply": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
     "sk_conv3d_stem_num_blocks": (i32, [i32, i32, i32]),
     "sk_conv3d_stem_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "sk_groupnorm_finalize": (i32, [vp, i32, i32, i32, i32, i64, vp, vp, f32, vp, vp]),

@@ -718,7 +718,7 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         float y = fmaf(ga[j], (float)bfr[j], gb[j]);
-                        bfr[j] = (_Float16)(y * (1.0f / (1.0f + __expf(-y))));
+                        bfr[j] = (_Float16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));
                     }
                 }
 #pragma unroll

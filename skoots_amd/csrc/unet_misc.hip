@@ -12,12 +12,11 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------------------ stem
-// Two launches.  (1) normalise: the B tiles are cut out of the fp16 volume, normalised with
-// the reference's fp16 arithmetic (eval.py:139: fp16 sub, fp16 div) and written with an
-// explicit one-voxel ZERO frame -- conv zero padding applies to the normalised tile.
-// (2) conv: D[cout][voxel] = W[cout][tap] * patch[tap][voxel] on the exact-fp32 matrix
-// instruction v_mfma_f32_32x32x2_f32 (K = 2 taps per instruction, 14 instructions for the
-// 27 taps + one zero): fp32 weights, fp32 products -- the stem keeps full precision.
+// (1) normalise: the B tiles are cut out of the fp16 volume, normalised with the reference's
+// fp16 arithmetic (eval.py:139: fp16 sub, fp16 div) and written with an explicit one-voxel
+// ZERO frame -- conv zero padding applies to the normalised tile.
+// (2)+(3) conv: D[cout][voxel] = W[cout][tap] * patch[tap][voxel] on v_mfma_f32_32x32x16_f16,
+// run twice (statistics, then apply): see stem_kernel.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
@@ -31,8 +30,9 @@ struct StemArgs {
     const float* weight;   // (27, 32) fp32: [tap = (dx*3+dy)*3+dz][cout]
     const float* bias;     // (32)
     __half* norm;          // workspace (B, Xt+2, Yt+2, Zt+2) fp16
-    __half* out;           // (B, Xt, Yt, Zt, 32) fp16 raw
-    float* partial;        // (B, nblk, 8, 2)
+    __half* out;           // (B, Xt, Yt, Zt, 32) fp16 ACTIVATED (apply pass)
+    float* partial;        // (B, nblk, 8, 2)     (stats pass)
+    const float* affine;   // (B, 2, 32)           (apply pass)
     int nblk;
 };
 
@@ -59,6 +59,13 @@ __global__ void __launch_bounds__(256) stem_norm_kernel(StemArgs a) {
     a.norm[(long long)b * n + i] = __float2half_rn(v);
 }
 
+// One conv pass over the zero-framed normalised tile.  STATS: accumulate the GroupNorm partial
+// sums of the fp32 results, store nothing.  !STATS: recompute the same fp32 results, apply the
+// GroupNorm affine + SiLU and store the ACTIVATED tensor.  Recomputing is cheaper than a raw
+// write + read-modify-write pass: the conv is 4 MFMAs per 32 voxels, the tensor is 64 B/voxel.
+// Weights are split w = hi + lo (two fp16 values, 22 significant bits) and the input is exactly
+// fp16, so the products are exact and the sums match an fp32 conv to ~1e-7 relative.
+template <bool STATS>
 __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
     __shared__ float red[4 * 16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -68,25 +75,34 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
     const int py = a.Yt + 2, pz = a.Zt + 2;
     const __half* nb = a.norm + (long long)b * (a.Xt + 2) * py * pz;
 
-    // A operand: lane holds W[cout = l&31][tap = 2m + h], m = 0..13 (tap 27 = 0)
-    float wa[14];
-    int toff[14];
+    // A operands: lane holds W[cout = l&31][tap = 16m + 8h + j], j = 0..7, m = 0,1 (tap >= 27: 0)
+    half8 whi[2], wlo[2];
+    int toff[2][8];
 #pragma unroll
-    for (int m = 0; m < 14; ++m) {
-        int tap = 2 * m + h;
-        wa[m] = tap < 27 ? a.weight[tap * 32 + col] : 0.0f;
-        int tt = tap < 27 ? tap : 0;
-        int dx = tt / 9, dy = (tt / 3) % 3, dz = tt % 3;
-        toff[m] = (dx * py + dy) * pz + dz;
-    }
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int tap = 16 * m + 8 * h + j;
+            float wv = tap < 27 ? a.weight[tap * 32 + col] : 0.0f;
+            _Float16 hi = (_Float16)wv;
+            whi[m][j] = hi;
+            wlo[m][j] = (_Float16)(wv - (float)hi);
+            int tt = tap < 27 ? tap : 0;  // any valid address: its weight is zero
+            toff[m][j] = ((tt / 9) * py + (tt / 3) % 3) * pz + tt % 3;
+        }
     f32x16 binit;
+    float ga[16], gb[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         f32x4v bv = *reinterpret_cast<const f32x4v*>(a.bias + 8 * q + 4 * h);
-        binit[4 * q] = bv[0];
-        binit[4 * q + 1] = bv[1];
-        binit[4 * q + 2] = bv[2];
-        binit[4 * q + 3] = bv[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            binit[4 * q + j] = bv[j];
+            if (!STATS) {
+                ga[4 * q + j] = a.affine[(long long)b * 64 + 8 * q + 4 * h + j];
+                gb[4 * q + j] = a.affine[(long long)b * 64 + 32 + 8 * q + 4 * h + j];
+            }
+        }
     }
     float gsum[4] = {0, 0, 0, 0}, gsq[4] = {0, 0, 0, 0};
     for (int t = 0; t < kStemTilesPerWave; ++t) {
@@ -96,27 +112,42 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
         int z = (int)(vv % a.Zt);
         long long r = vv / a.Zt;
         int y = (int)(r % a.Yt), x = (int)(r / a.Yt);
-        const __half* p = nb + ((long long)x * py + y) * pz + z;  // tap (0,0,0) of the padded tile
-        float bv[14];
+        const _Float16* p = reinterpret_cast<const _Float16*>(nb) + ((long long)x * py + y) * pz + z;
+        half8 b0, b1;
 #pragma unroll
-        for (int m = 0; m < 14; ++m) bv[m] = __half2float(p[toff[m]]);
-        if (h == 1) bv[13] = 0.0f;  // tap 27 does not exist
+        for (int j = 0; j < 8; ++j) {
+            b0[j] = p[toff[0][j]];
+            b1[j] = p[toff[1][j]];
+        }
         f32x16 acc = binit;
-#pragma unroll
-        for (int m = 0; m < 14; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[m], bv[m], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[0], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[1], b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], b1, acc, 0, 0, 0);
         if (ok) {
-            __half* op = a.out + ((long long)b * nvox + v) * 32;
+            if (STATS) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v0 = acc[4 * q], v1 = acc[4 * q + 1], v2 = acc[4 * q + 2], v3 = acc[4 * q + 3];
-                half4v hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-                *reinterpret_cast<half4v*>(op + 8 * q + 4 * h) = hv;
-                gsum[q] += (v0 + v1) + (v2 + v3);
-                gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                for (int q = 0; q < 4; ++q) {
+                    float v0 = acc[4 * q], v1 = acc[4 * q + 1], v2 = acc[4 * q + 2], v3 = acc[4 * q + 3];
+                    gsum[q] += (v0 + v1) + (v2 + v3);
+                    gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                }
+            } else {
+                __half* op = a.out + ((long long)b * nvox + v) * 32;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    half4v hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float yv = fmaf(ga[4 * q + j], acc[4 * q + j], gb[4 * q + j]);
+                        hv[j] = (_Float16)(yv * __builtin_amdgcn_rcpf(1.0f + __expf(-yv)));
+                    }
+                    *reinterpret_cast<half4v*>(op + 8 * q + 4 * h) = hv;
+                }
             }
         }
     }
-    if (a.partial) {
+    if (STATS) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float s = gsum[q], ss = gsq[q];
@@ -214,7 +245,7 @@ __global__ void __launch_bounds__(256) gn_silu_kernel(__half* __restrict__ x,
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float y = fmaf(ga[j], (float)v[j], gb[j]);
-            float sg = 1.0f / (1.0f + __expf(-y));
+            float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
             r[j] = (_Float16)(y * sg);
         }
         p[i] = r;
@@ -256,7 +287,7 @@ __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
             if (a.affine) {
                 float y = fmaf(asm_[c8 * 8 + j], f, asm_[C + c8 * 8 + j]);
                 // the activated value is rounded to fp16 exactly as the in-place pass would store it
-                f = (float)(_Float16)(y * (1.0f / (1.0f + __expf(-y))));
+                f = (float)(_Float16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));
             }
 #pragma unroll
             for (int k = 0; k < 5; ++k) o[k] = fmaf(wsm[k * C + c8 * 8 + j], f, o[k]);
@@ -282,17 +313,15 @@ size_t sk_conv3d_stem_workspace_bytes(int B, int Xt, int Yt, int Zt) {
     return (size_t)B * (Xt + 2) * (Yt + 2) * (Zt + 2) * sizeof(__half);
 }
 
-int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origins_host, int B, int Xt,
-                   int Yt, int Zt, float mean, float stdv, const float* weight, const float* bias,
-                   void* out, int cout, float* gn_partial, void* workspace, size_t workspace_bytes,
-                   void* stream) {
-    SK_CHECK_ARG(image && origins_host && weight && bias && out && workspace, "sk_conv3d_stem: NULL pointer");
+static int fill_stem_args(StemArgs& a, const void* image, int X, int Y, int Z, const int32_t* origins_host,
+                          int B, int Xt, int Yt, int Zt, float mean, float stdv, const float* weight,
+                          const float* bias, int cout, void* workspace, size_t workspace_bytes) {
+    SK_CHECK_ARG(image && origins_host && weight && bias && workspace, "sk_conv3d_stem: NULL pointer");
     SK_CHECK_ARG(cout == 32, "sk_conv3d_stem: cout must be 32");
     SK_CHECK_ARG(B >= 1 && B <= 16, "sk_conv3d_stem: batch must be in [1,16]");
     SK_CHECK_ARG(stdv != 0.0f, "sk_conv3d_stem: std must be non-zero");
     SK_CHECK_ARG(workspace_bytes >= sk_conv3d_stem_workspace_bytes(B, Xt, Yt, Zt),
                  "sk_conv3d_stem: workspace too small");
-    StemArgs a{};
     a.image = (const __half*)image;
     a.X = X;
     a.Y = Y;
@@ -315,13 +344,43 @@ int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origin
     a.weight = weight;
     a.bias = bias;
     a.norm = (__half*)workspace;
-    a.out = (__half*)out;
-    a.partial = gn_partial;
     a.nblk = sk_conv3d_stem_num_blocks(Xt, Yt, Zt);
+    return SK_OK;
+}
+
+int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origins_host, int B, int Xt,
+                   int Yt, int Zt, float mean, float stdv, const float* weight, const float* bias,
+                   int cout, float* gn_partial, void* workspace, size_t workspace_bytes, void* stream) {
+    SK_CHECK_ARG(gn_partial, "sk_conv3d_stem: gn_partial is NULL");
+    StemArgs a{};
+    int rc = fill_stem_args(a, image, X, Y, Z, origins_host, B, Xt, Yt, Zt, mean, stdv, weight, bias, cout,
+                            workspace, workspace_bytes);
+    if (rc) return rc;
+    a.partial = gn_partial;
     long long np = (long long)(Xt + 2) * (Yt + 2) * (Zt + 2);
     dim3 g1(sk::cdiv(np, 256), B);
     stem_norm_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(a);
-    stem_kernel<<<(unsigned)(a.nblk * B), 256, 0, (hipStream_t)stream>>>(a);
+    stem_kernel<true><<<(unsigned)(a.nblk * B), 256, 0, (hipStream_t)stream>>>(a);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_conv3d_stem_apply(int B, int Xt, int Yt, int Zt, const float* weight, const float* bias,
+                         const float* affine, void* out, int cout, const void* workspace, void* stream) {
+    SK_CHECK_ARG(weight && bias && affine && out && workspace, "sk_conv3d_stem_apply: NULL pointer");
+    SK_CHECK_ARG(cout == 32 && B >= 1 && B <= 16, "sk_conv3d_stem_apply: bad cout / batch");
+    StemArgs a{};
+    a.B = B;
+    a.Xt = Xt;
+    a.Yt = Yt;
+    a.Zt = Zt;
+    a.weight = weight;
+    a.bias = bias;
+    a.affine = affine;
+    a.norm = (__half*)workspace;
+    a.out = (__half*)out;
+    a.nblk = sk_conv3d_stem_num_blocks(Xt, Yt, Zt);
+    stem_kernel<false><<<(unsigned)(a.nblk * B), 256, 0, (hipStream_t)stream>>>(a);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }

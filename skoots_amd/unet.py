@@ -190,6 +190,8 @@ class HipUNet:
 
     def _stem(self, layer: _ConvLayer, image: Tensor, origins, tile, mean: float, std: float,
               tag: str = "L0a") -> Tensor:
+        """First block (Cin = 1): normalise + conv statistics, GroupNorm finalize, then the conv again
+        with the affine + SiLU fused into its epilogue: the raw tensor is never written."""
         B = len(origins)
         X, Y, Z = image.shape
         xt, yt, zt = tile
@@ -199,11 +201,13 @@ class HipUNet:
         org = (C.c_int32 * (3 * B))(*[int(v) for o in origins for v in o])
         ws_bytes = _ffi.lib.sk_conv3d_stem_workspace_bytes(B, xt, yt, zt)
         ws = self._buf("stem_ws", (ws_bytes,), torch.uint8)
+        st = _ffi.stream_ptr(self.device)
         _ffi.check(_ffi.lib.sk_conv3d_stem(_ffi.ptr(image), X, Y, Z, org, B, xt, yt, zt, mean, std,
-                                           _ffi.ptr(layer.weight), _ffi.ptr(layer.bias), _ffi.ptr(out),
-                                           layer.cout, _ffi.ptr(partial), _ffi.ptr(ws), ws_bytes,
-                                           _ffi.stream_ptr(self.device)))
-        self._norm_act(layer, out, partial, nblk)
+                                           _ffi.ptr(layer.weight), _ffi.ptr(layer.bias), layer.cout,
+                                           _ffi.ptr(partial), _ffi.ptr(ws), ws_bytes, st))
+        aff = self._norm_act(layer, out, partial, nblk, apply=False)
+        _ffi.check(_ffi.lib.sk_conv3d_stem_apply(B, xt, yt, zt, _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
+                                                 _ffi.ptr(aff), _ffi.ptr(out), layer.cout, _ffi.ptr(ws), st))
         return out
 
     # -- forward -----------------------------------------------------------------------
