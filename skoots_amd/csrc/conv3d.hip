@@ -837,6 +837,7 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
     if (nxc > max_nxc) nxc = max_nxc;
     if (nxc < 1) nxc = 1;
     int XC = (Xt + nxc - 1) / nxc;
+    if (const char* e = getenv("SK_CONV_XC")) XC = atoi(e);  // tuning experiments
     XC = (XC + p.xs - 1) / p.xs * p.xs;
     p.XC = XC;
     p.nxc = (Xt + XC - 1) / XC;

@@ -263,42 +263,77 @@ struct HeadArgs {
     int C;
 };
 
+// out5[k][voxel] = act_k( W[k][:] . silu(affine(x[voxel][:])) + bias[k] ) as a 32x32x16 MFMA with
+// 5 useful rows: per 32 voxels a wave loads 2 x 16 B per lane, activates 16 values per lane and
+// issues 4 MFMAs (weights split hi + lo: exact products, the logits keep fp32 precision).
 template <int C>
 __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
-    __shared__ float wsm[5 * C + 8];
-    __shared__ float asm_[2 * C];
+    static_assert(C == 32, "two K steps of 16");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int col = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < 5 * C; i += 256) wsm[i] = a.weight[i];
-    if (threadIdx.x < 5) wsm[5 * C + threadIdx.x] = a.bias[threadIdx.x];
-    if (a.affine && threadIdx.x < 2 * C) asm_[threadIdx.x] = a.affine[(long long)b * 2 * C + threadIdx.x];
-    __syncthreads();
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
-    const half8* p = reinterpret_cast<const half8*>(a.x + ((long long)b * a.n + i) * C);
-    float o[5];
+    // A operands: lane holds W[row = col][cin = 16 ks + 8h + j] (rows >= 5 are zero)
+    half8 whi[2], wlo[2];
+    float ga[2][8], gb[2][8];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) o[k] = wsm[5 * C + k];
-#pragma unroll
-    for (int c8 = 0; c8 < C / 8; ++c8) {
-        half8 v = p[c8];
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float f = (float)v[j];
-            if (a.affine) {
-                float y = fmaf(asm_[c8 * 8 + j], f, asm_[C + c8 * 8 + j]);
-                // the activated value is rounded to fp16 exactly as the in-place pass would store it
-                f = (float)(_Float16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));
-            }
+            const int c = 16 * ks + 8 * h + j;
+            float wv = col < 5 ? a.weight[col * C + c] : 0.0f;
+            _Float16 hi = (_Float16)wv;
+            whi[ks][j] = hi;
+            wlo[ks][j] = (_Float16)(wv - (float)hi);
+            ga[ks][j] = a.affine ? a.affine[(long long)b * 2 * C + c] : 1.0f;
+            gb[ks][j] = a.affine ? a.affine[(long long)b * 2 * C + C + c] : 0.0f;
+        }
+    f32x16 binit;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) o[k] = fmaf(wsm[k * C + c8 * 8 + j], f, o[k]);
+    for (int r = 0; r < 16; ++r) binit[r] = 0.0f;
+    if (h == 0) {
+        binit[0] = a.bias[0];
+        binit[1] = a.bias[1];
+        binit[2] = a.bias[2];
+        binit[3] = a.bias[3];
+    } else {
+        binit[0] = a.bias[4];  // row 4 = register 0 of the upper half-wave
+    }
+    const __half* xb = a.x + (long long)b * a.n * C;
+    __half* ob = a.out5 + (long long)b * 5 * a.n;
+    const long long ntiles = (a.n + 31) / 32;
+    for (long long t = (long long)blockIdx.x * 4 + (tid >> 6); t < ntiles; t += (long long)gridDim.x * 4) {
+        const long long v = t * 32 + col;
+        const bool ok = v < a.n;
+        const half8* p = reinterpret_cast<const half8*>(xb + (ok ? v : 0) * C);
+        half8 bf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 raw = p[2 * ks + h];
+            if (a.affine) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float y = fmaf(ga[ks][j], (float)raw[j], gb[ks][j]);
+                    raw[j] = (_Float16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));
+                }
+            }
+            bf[ks] = raw;
+        }
+        f32x16 acc = binit;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[0], bf[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[1], bf[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], bf[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], bf[1], acc, 0, 0, 0);
+        if (ok) {
+            if (h == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)  // tanh(x) = 1 - 2 / (1 + e^{2x})
+                    ob[k * a.n + v] = __float2half_rn(1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * acc[k])));
+                ob[3 * a.n + v] = __float2half_rn(__builtin_amdgcn_rcpf(1.0f + __expf(-acc[3])));
+            } else {
+                ob[4 * a.n + v] = __float2half_rn(__builtin_amdgcn_rcpf(1.0f + __expf(-acc[0])));
+            }
         }
     }
-    __half* ob = a.out5 + (long long)b * 5 * a.n + i;
-    ob[0] = __float2half_rn(tanhf(o[0]));
-    ob[a.n] = __float2half_rn(tanhf(o[1]));
-    ob[2 * a.n] = __float2half_rn(tanhf(o[2]));
-    ob[3 * a.n] = __float2half_rn(1.0f / (1.0f + expf(-o[3])));
-    ob[4 * a.n] = __float2half_rn(1.0f / (1.0f + expf(-o[4])));
 }
 
 }  // namespace
@@ -414,7 +449,7 @@ int sk_heads(const void* x, const float* affine, const float* weight, const floa
     SK_CHECK_ARG(x && weight && bias && out5, "sk_heads: NULL pointer");
     SK_CHECK_ARG(C == 32, "sk_heads: C must be 32");
     HeadArgs a{(const __half*)x, affine, weight, bias, (__half*)out5, voxels, C};
-    dim3 grid(sk::cdiv(voxels, 256), B);
+    dim3 grid(sk::stream_grid((voxels + 31) / 32, 4, 4), B);
     heads_kernel<32><<<grid, 256, 0, (hipStream_t)stream>>>(a);
     SK_CHECK_LAUNCH();
     return SK_OK;
