@@ -172,7 +172,7 @@ def main():
         if inject_vol is None:
             return out5
         x, y, z = origin
-        return inject_vol[:, x:x + eff[0], y:y + eff[1], z:z + eff[2]].contiguous()
+        return inject_vol[:, x:x + eff[0], y:y + eff[1], z:z + eff[2]]  # strided view: no copy
 
     def step(prof=None):
         return sv.run(image, model, SCALE, mean, std, tile_batch=args.tile_batch, inject=inject,

@@ -85,18 +85,22 @@ int sk_follow_assign(const void* vec4, const void* labels, int label_dtype, int3
  * Stage 1 tail: gate + dilate + threshold + interior scatter
  * ------------------------------------------------------------------------ */
 
-/* eval.py:145-176 for one tile.  out5: network output of the tile, (5, w, h, d)
- * planar, fp16 or fp32 (thresholds follow torch's scalar casting for that dtype).
- * Writes the tile-local box [box_lo, box_hi) (host ints[3]; the tile interior, or the part
- * of it this tile writes LAST in the reference's scatter order, so that tiles can be
- * scattered in any order / concurrently) into the volume arrays at origin + box:
- * vec4 (X,Y,Z,4) fp16 and/or vec_planar (3,X,Y,Z) fp16 (either may be NULL),
- * skeleton (X,Y,Z) uint8 in {0,1}.  Dilation = 3x3x3 max then 3x3x1 max twice,
- * zero padded at the tile faces (morphology.py:155-199). */
-int sk_gate_dilate_scatter(const void* out5, int out_dtype, int w, int h, int d,
-                           int ox, int oy, int oz, const int* box_lo, const int* box_hi,
-                           void* vec4, void* vec_planar, uint8_t* skeleton,
-                           int X, int Y, int Z, float prob_thr, float skel_thr, void* stream);
+/* eval.py:145-176 for a batch of n_tiles (<= 16) tiles in one launch.  out5 holds the 5-channel
+ * network outputs, fp16 or fp32 (thresholds follow torch's scalar casting for that dtype); tile i
+ * starts at element offset tile_offsets_host[i] and is addressed with the element strides
+ * (stride_c, stride_x, stride_y, 1), extent (w, h, d) -- a (B,5,w,h,d) batch or views into a
+ * larger (5,X,Y,Z) array alike.  For tile i the tile-local box [box_lo_host[3i..], box_hi_host[3i..])
+ * (the tile interior, or the part of it this tile writes LAST in the reference's scatter
+ * order, so that tiles can be scattered in any order / concurrently) is written into the
+ * volume arrays at origins_host[3i..] + box: vec4 (X,Y,Z,4) fp16 and/or vec_planar (3,X,Y,Z)
+ * fp16 (either may be NULL), skeleton (X,Y,Z) uint8 in {0,1}.  Dilation = 3x3x3 max then 3x3x1
+ * max twice, zero padded at the tile faces (morphology.py:155-199). */
+int sk_gate_dilate_scatter(const void* out5, int out_dtype, int n_tiles,
+                           const int64_t* tile_offsets_host, int64_t stride_c, int64_t stride_x,
+                           int64_t stride_y, int w, int h, int d, const int* origins_host,
+                           const int* box_lo_host, const int* box_hi_host, void* vec4,
+                           void* vec_planar, uint8_t* skeleton, int X, int Y, int Z,
+                           float prob_thr, float skel_thr, void* stream);
 
 /* skoots.lib.morphology.binary_dilation / binary_dilation_2d (morphology.py:155-199)
  * as library functions on a (w,h,d) fp32 map: max over a (2rx+1,2ry+1,2rz+1) window,

@@ -53,8 +53,8 @@ _SIGS = {
     "sk_index_skeleton_by_embed": (i32, [vp, i32, i32, i32, i32, vp, i64, vp, vp]),
     "sk_follow_assign": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, fp,
                                i32, i32, i32, vp]),
-    "sk_gate_dilate_scatter": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, ip, ip, vp, vp, vp,
-                                     i32, i32, i32, f32, f32, vp]),
+    "sk_gate_dilate_scatter": (i32, [vp, i32, i32, C.POINTER(C.c_int64), i64, i64, i64, i32, i32, i32, ip, ip, ip,
+                                     vp, vp, vp, i32, i32, i32, f32, f32, vp]),
     "sk_max_filter3d": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "sk_ccl_workspace_bytes": (sz, [i64]),
     "sk_ccl_crop": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp]),

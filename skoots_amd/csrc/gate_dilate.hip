@@ -15,14 +15,24 @@
 
 namespace {
 
-struct GateGeom {
-    int w, h, d;          // tile extents
+constexpr int kMaxTiles = 16;
+
+struct TileGeom {
+    long long off;        // element offset of this tile's (channel 0, 0, 0, 0) in out5
     int ox, oy, oz;       // tile origin in the volume
     int lx, ly, lz;       // write box (tile-local, inside the interior): [l, h)
     int hx, hy, hz;
+    int nbx, nblocks;     // patch grid of this tile
+};
+
+struct GateGeom {
+    int w, h, d;          // tile extents
+    long long sc, sx, sy; // element strides of out5: channel, x, y (z is contiguous)
     int X, Y, Z;          // volume extents
     int px, py;           // interior patch handled per block
     float prob_thr, skel_thr;
+    int ntiles;
+    TileGeom t[kMaxTiles];
 };
 
 template <typename T>
@@ -40,18 +50,19 @@ constexpr int RX = 3, RY = 3;  // 1+1+1 in x,y (eval.py:152-157); z radius 1 is 
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-gate_dilate_scatter_kernel(const T* __restrict__ out5, GateGeom g, uint2* __restrict__ vec4,
+gate_dilate_scatter_kernel(const T* __restrict__ out5_all, GateGeom g, uint2* __restrict__ vec4,
                            __half* __restrict__ vec_planar, uint8_t* __restrict__ skeleton) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int iw = g.hx - g.lx;  // write-box extent
-    const int nbx = (iw + g.px - 1) / g.px;
-    const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
-    const int x0 = g.lx + bx * g.px, y0 = g.ly + by * g.py;  // tile-local patch origin
+    const TileGeom tg = g.t[blockIdx.y];
+    if ((int)blockIdx.x >= tg.nblocks) return;  // grid.x is sized for the largest write box
+    const T* out5 = out5_all + tg.off;
+    const int bx = blockIdx.x % tg.nbx, by = blockIdx.x / tg.nbx;
+    const int x0 = tg.lx + bx * g.px, y0 = tg.ly + by * g.py;  // tile-local patch origin
     const int sx = g.px + 2 * RX, sy = g.py + 2 * RY;          // staged columns
     const int d = g.d;
     unsigned char* m0 = smem;                      // [sx][sy][d]
     unsigned char* m1 = smem + (size_t)sx * sy * d;  // [sx][sy][d]
-    const long long plane = (long long)g.w * g.h * d;
+    const long long plane = g.sc;
     const int tid = threadIdx.x, nth = blockDim.x;
 
     // phase 1: mask = skel > skel_thr && prob > prob_thr, zero outside the tile
@@ -62,7 +73,7 @@ gate_dilate_scatter_kernel(const T* __restrict__ out5, GateGeom g, uint2* __rest
         int tx = x0 - RX + lx, ty = y0 - RY + ly;
         unsigned char m = 0;
         if (tx >= 0 && tx < g.w && ty >= 0 && ty < g.h) {
-            long long o = ((long long)tx * g.h + ty) * d + z;
+            long long o = (long long)tx * g.sx + (long long)ty * g.sy + z;
             float skel = ld(out5, 3 * plane + o);
             float prob = ld(out5, 4 * plane + o);
             m = (prob > g.prob_thr && skel > g.skel_thr) ? 1 : 0;
@@ -91,21 +102,21 @@ gate_dilate_scatter_kernel(const T* __restrict__ out5, GateGeom g, uint2* __rest
     }
     __syncthreads();
     // phase 4: x dilation (radius 3) + scatter of the interior
-    const int iz0 = g.lz, iz1 = g.hz;
+    const int iz0 = tg.lz, iz1 = tg.hz;
     const int idp = iz1 - iz0;
     for (int i = tid; i < g.px * g.py * idp; i += nth) {
         int zz = i % idp;
         int c = i / idp;
         int ly = c % g.py, lx = c / g.py;
         int tx = x0 + lx, ty = y0 + ly, tz = iz0 + zz;
-        if (tx >= g.hx || ty >= g.hy) continue;
+        if (tx >= tg.hx || ty >= tg.hy) continue;
         unsigned char m = 0;
 #pragma unroll
         for (int k = 0; k <= 2 * RX; ++k) m |= m0[((size_t)(lx + k) * g.py + ly) * d + tz];
-        long long vo = ((long long)(g.ox + tx) * g.Y + (g.oy + ty)) * g.Z + (g.oz + tz);
+        long long vo = ((long long)(tg.ox + tx) * g.Y + (tg.oy + ty)) * g.Z + (tg.oz + tz);
         skeleton[vo] = m;
         // vectors: vec * (prob > thr), stored fp16 (eval.py:149,175)
-        long long o = ((long long)tx * g.h + ty) * d + tz;
+        long long o = (long long)tx * g.sx + (long long)ty * g.sy + tz;
         bool gate = ld(out5, 4 * plane + o) > g.prob_thr;
         float v0 = ld(out5, o), v1 = ld(out5, plane + o), v2 = ld(out5, 2 * plane + o);
         if (!gate) {
@@ -168,32 +179,67 @@ __global__ void __launch_bounds__(256) max_filter_kernel(const float* __restrict
 
 extern "C" {
 
-int sk_gate_dilate_scatter(const void* out5, int out_dtype, int w, int h, int d, int ox, int oy,
-                           int oz, const int* box_lo, const int* box_hi, void* vec4, void* vec_planar,
-                           uint8_t* skeleton, int X, int Y, int Z, float prob_thr, float skel_thr,
-                           void* stream) {
-    SK_CHECK_ARG(out5 && skeleton && box_lo && box_hi, "sk_gate_dilate_scatter: NULL pointer");
+int sk_gate_dilate_scatter(const void* out5, int out_dtype, int n_tiles, const int64_t* tile_offsets_host,
+                           int64_t stride_c, int64_t stride_x, int64_t stride_y, int w, int h, int d,
+                           const int* origins_host, const int* box_lo_host, const int* box_hi_host,
+                           void* vec4, void* vec_planar, uint8_t* skeleton, int X, int Y, int Z,
+                           float prob_thr, float skel_thr, void* stream) {
+    SK_CHECK_ARG(out5 && skeleton && tile_offsets_host && origins_host && box_lo_host && box_hi_host,
+                 "sk_gate_dilate_scatter: NULL pointer");
     SK_CHECK_ARG(out_dtype == SK_F16 || out_dtype == SK_F32,
                  "sk_gate_dilate_scatter: out dtype must be fp16 or fp32");
-    SK_CHECK_ARG(w > 0 && h > 0 && d > 0, "sk_gate_dilate_scatter: bad tile extents");
-    SK_CHECK_ARG(0 <= box_lo[0] && box_lo[0] < box_hi[0] && box_hi[0] <= w && 0 <= box_lo[1] &&
-                     box_lo[1] < box_hi[1] && box_hi[1] <= h && 0 <= box_lo[2] && box_lo[2] < box_hi[2] &&
-                     box_hi[2] <= d,
-                 "sk_gate_dilate_scatter: write box [%d:%d,%d:%d,%d:%d) must be a non-empty box inside the "
-                 "tile (%d,%d,%d)", box_lo[0], box_hi[0], box_lo[1], box_hi[1], box_lo[2], box_hi[2], w, h, d);
-    SK_CHECK_ARG(ox >= 0 && oy >= 0 && oz >= 0 && ox + w <= X && oy + h <= Y && oz + d <= Z,
-                 "sk_gate_dilate_scatter: tile [%d+%d,%d+%d,%d+%d) outside volume (%d,%d,%d)", ox, w,
-                 oy, h, oz, d, X, Y, Z);
-    GateGeom g{w, h, d, ox, oy, oz, box_lo[0], box_lo[1], box_lo[2], box_hi[0], box_hi[1], box_hi[2],
-               X, Y, Z, 16, 16, prob_thr, skel_thr};
+    SK_CHECK_ARG(n_tiles >= 1 && n_tiles <= kMaxTiles, "sk_gate_dilate_scatter: 1..%d tiles per call", kMaxTiles);
+    SK_CHECK_ARG(w > 0 && h > 0 && d > 0 && stride_y >= d && stride_x >= stride_y && stride_c > 0,
+                 "sk_gate_dilate_scatter: bad tile extents / strides");
+    GateGeom g{};
+    g.w = w;
+    g.h = h;
+    g.d = d;
+    g.sc = stride_c;
+    g.sx = stride_x;
+    g.sy = stride_y;
+    g.X = X;
+    g.Y = Y;
+    g.Z = Z;
+    g.px = g.py = 16;
+    g.prob_thr = prob_thr;
+    g.skel_thr = skel_thr;
+    g.ntiles = n_tiles;
     size_t lds = 2ull * (g.px + 2 * RX) * (g.py + 2 * RY) * d;
     if (lds > 64 * 1024) {
         g.px = g.py = 8;
         lds = 2ull * (g.px + 2 * RX) * (g.py + 2 * RY) * d;
     }
     SK_CHECK_ARG(lds <= 96 * 1024, "sk_gate_dilate_scatter: tile depth %d too large", d);
-    int iw = g.hx - g.lx, ih = g.hy - g.ly;
-    unsigned grid = ((iw + g.px - 1) / g.px) * ((ih + g.py - 1) / g.py);
+    int max_blocks = 0;
+    for (int i = 0; i < n_tiles; ++i) {
+        const int* lo = box_lo_host + 3 * i;
+        const int* hi = box_hi_host + 3 * i;
+        const int* org = origins_host + 3 * i;
+        SK_CHECK_ARG(0 <= lo[0] && lo[0] < hi[0] && hi[0] <= w && 0 <= lo[1] && lo[1] < hi[1] && hi[1] <= h &&
+                         0 <= lo[2] && lo[2] < hi[2] && hi[2] <= d,
+                     "sk_gate_dilate_scatter: write box [%d:%d,%d:%d,%d:%d) must be a non-empty box inside the "
+                     "tile (%d,%d,%d)", lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], w, h, d);
+        SK_CHECK_ARG(org[0] >= 0 && org[1] >= 0 && org[2] >= 0 && org[0] + w <= X && org[1] + h <= Y &&
+                         org[2] + d <= Z,
+                     "sk_gate_dilate_scatter: tile [%d+%d,%d+%d,%d+%d) outside volume (%d,%d,%d)", org[0], w,
+                     org[1], h, org[2], d, X, Y, Z);
+        TileGeom& t = g.t[i];
+        t.off = tile_offsets_host[i];
+        t.ox = org[0];
+        t.oy = org[1];
+        t.oz = org[2];
+        t.lx = lo[0];
+        t.ly = lo[1];
+        t.lz = lo[2];
+        t.hx = hi[0];
+        t.hy = hi[1];
+        t.hz = hi[2];
+        t.nbx = (hi[0] - lo[0] + g.px - 1) / g.px;
+        t.nblocks = t.nbx * ((hi[1] - lo[1] + g.py - 1) / g.py);
+        if (t.nblocks > max_blocks) max_blocks = t.nblocks;
+    }
+    dim3 grid(max_blocks, n_tiles);
     if (out_dtype == SK_F16) {
         if (lds > 48 * 1024)
             SK_CHECK_HIP(hipFuncSetAttribute((const void*)gate_dilate_scatter_kernel<__half>,

@@ -72,31 +72,60 @@ class VolumeState:
     # -- stage 1 tail ------------------------------------------------------------------
     def scatter_tile(self, out5: Tensor, origin: Sequence[int], overlap=TILE_OVERLAP,
                      owners: Optional[Sequence[np.ndarray]] = None) -> None:
-        """Gate + dilate + threshold + interior scatter of one tile's network output
-        (5, w, h, d) fp16/fp32 (eval.py:145-176); ``origin`` in GLOBAL coordinates.
+        """One-tile form of :meth:`scatter_tiles`; ``out5`` is (5, w, h, d)."""
+        self.scatter_tiles([out5], [origin], overlap, owners)
 
-        ``owners`` (per-axis ``cropper.owner_table``): restrict the write to the part of the
-        interior this tile writes LAST in the reference's order, so that tiles may be
-        scattered in any order (or concurrently on several streams) with the same result."""
-        _ffi.require_gpu(out5, "out5")
-        assert out5.ndim == 4 and out5.shape[0] == 5
-        _, w, h, d = out5.shape
+    def scatter_tiles(self, tiles: Sequence[Tensor], origins: Sequence[Sequence[int]], overlap=TILE_OVERLAP,
+                      owners: Optional[Sequence[np.ndarray]] = None) -> None:
+        """Gate + dilate + threshold + interior scatter (eval.py:145-176) of a batch of tile outputs in
+        one launch.  ``tiles``: (5, w, h, d) fp16/fp32 tensors that are views of ONE storage with
+        identical strides and a contiguous z axis (e.g. ``out5[b]`` of a (B,5,w,h,d) batch, or windows
+        of a (5,X,Y,Z) array); ``origins`` in GLOBAL coordinates.
+
+        ``owners`` (per-axis ``cropper.owner_table``): restrict each write to the part of the interior
+        the tile writes LAST in the reference's order, so that tiles may be scattered in any order
+        (or concurrently on several streams) with the same result."""
+        t0 = tiles[0]
+        _ffi.require_gpu(t0, "out5") if t0.is_contiguous() else None
+        if not t0.is_cuda:
+            raise RuntimeError("out5 must live on the MI355X; skoots_amd has no CPU fallback")
+        assert t0.ndim == 4 and t0.shape[0] == 5 and t0.stride(3) == 1
+        _, w, h, d = t0.shape
         X, Y, zl = self.local_shape
-        lo = [int(o) for o in overlap]
-        hi = [int(s - o) for s, o in zip((w, h, d), overlap)]
-        if owners is not None:
-            for ax in range(3):
-                own = np.nonzero(owners[ax] == origin[ax])[0]
-                if own.size == 0:
-                    return  # every voxel of this tile's interior is overwritten by later tiles
-                lo[ax], hi[ax] = int(own[0]) - origin[ax], int(own[-1]) + 1 - origin[ax]
-        pthr, sthr = thresholds_for(out5.dtype)
-        i3 = C.c_int32 * 3
-        _ffi.check(_ffi.lib.sk_gate_dilate_scatter(
-            _ffi.ptr(out5), _ffi.dtype_code(out5), w, h, d, origin[0], origin[1],
-            origin[2] - self.window[0], i3(*lo), i3(*hi), _ffi.ptr(self.vec4),
-            _ffi.ptr(self.vec_planar), _ffi.ptr(self.skeleton), X, Y, zl, pthr, sthr,
-            _ffi.stream_ptr(self.device)))
+        esz = t0.element_size()
+        base = min(t.data_ptr() for t in tiles)
+        offs, orgs, los, his = [], [], [], []
+        for t, origin in zip(tiles, origins):
+            assert t.shape == t0.shape and t.stride() == t0.stride() and t.dtype == t0.dtype
+            lo = [int(o) for o in overlap]
+            hi = [int(s - o) for s, o in zip((w, h, d), overlap)]
+            if owners is not None:
+                skip = False
+                for ax in range(3):
+                    own = np.nonzero(owners[ax] == origin[ax])[0]
+                    if own.size == 0:
+                        skip = True  # every voxel of this tile's interior is overwritten by later tiles
+                        break
+                    lo[ax], hi[ax] = int(own[0]) - origin[ax], int(own[-1]) + 1 - origin[ax]
+                if skip:
+                    continue
+            offs.append((t.data_ptr() - base) // esz)
+            orgs += [int(origin[0]), int(origin[1]), int(origin[2]) - self.window[0]]
+            los += lo
+            his += hi
+        n = len(offs)
+        if n == 0:
+            return
+        pthr, sthr = thresholds_for(t0.dtype)
+        for k in range(0, n, 16):
+            m = min(16, n - k)
+            _ffi.check(_ffi.lib.sk_gate_dilate_scatter(
+                C.c_void_p(base), _ffi.dtype_code(t0), m, (C.c_int64 * m)(*offs[k:k + m]),
+                t0.stride(0), t0.stride(1), t0.stride(2), w, h, d, (C.c_int32 * (3 * m))(*orgs[3 * k:3 * (k + m)]),
+                (C.c_int32 * (3 * m))(*los[3 * k:3 * (k + m)]), (C.c_int32 * (3 * m))(*his[3 * k:3 * (k + m)]),
+                _ffi.ptr(self.vec4), _ffi.ptr(self.vec_planar), _ffi.ptr(self.skeleton), X, Y, zl, pthr, sthr,
+                _ffi.stream_ptr(self.device)))
+        self._keep = tiles  # the views must outlive the launch
 
     # -- stage 2 -----------------------------------------------------------------------
     def label(self) -> Tensor:

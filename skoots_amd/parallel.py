@@ -191,11 +191,19 @@ class ShardedVolume:
             k = bi % n_streams
             with torch.cuda.stream(lanes[k]):
                 out5 = ctxs[k].forward_tiles(image, local, eff, mean, std) if model is not None else None
+                outs = []
                 for b, org in enumerate(batch):
                     o = out5[b] if out5 is not None else None
                     if inject is not None:
                         o = inject(o, (org[0], org[1], org[2] - wlo), eff)
-                    state.scatter_tile(o, org, tile_overlap, owners=owners)
+                    outs.append(o)
+                same = all(o.stride() == outs[0].stride() and o.dtype == outs[0].dtype and
+                           o.untyped_storage().data_ptr() == outs[0].untyped_storage().data_ptr() for o in outs)
+                if same and outs[0].stride(3) == 1:
+                    state.scatter_tiles(outs, batch, tile_overlap, owners=owners)  # one launch per batch
+                else:
+                    for o, org in zip(outs, batch):
+                        state.scatter_tile(o.contiguous(), org, tile_overlap, owners=owners)
         for s_ in lanes[1:]:
             main.wait_stream(s_)
         for c in ctxs:

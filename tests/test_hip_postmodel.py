@@ -229,7 +229,8 @@ def test_abi_errors(sk):
     with pytest.raises(ValueError, match="write box"):
         import ctypes
         i3 = ctypes.c_int32 * 3
-        ffi.check(lib.sk_gate_dilate_scatter(ffi.ptr(t), 0, 4, 4, 4, 0, 0, 0, i3(2, 2, 2), i3(2, 2, 2), None, None,
+        ffi.check(lib.sk_gate_dilate_scatter(ffi.ptr(t), 0, 1, (ctypes.c_int64 * 1)(0), 64, 16, 4, 4, 4, 4,
+                                             i3(0, 0, 0), i3(2, 2, 2), i3(2, 2, 2), None, None,
                                              ffi.ptr(t), 8, 8, 8, 0.8, 0.8, None))
     with pytest.raises(ValueError, match="outside volume"):
         ffi.check(lib.sk_ccl_crop(ffi.ptr(t), ffi.ptr(t), 4, 4, 4, 2, 0, 0, 4, 4, 4, ffi.ptr(t), 1 << 20,
