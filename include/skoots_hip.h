@@ -235,6 +235,16 @@ int sk_groupnorm_silu(void* x, const float* affine, int B, int64_t voxels, int C
 int sk_heads(const void* x, const float* affine, const float* weight, const float* bias, void* out5,
              int B, int64_t voxels, int C, void* stream);
 
+/* fp32 precision mode (parity reference of the fast path): the same layers with fp32 activations
+ * (B, x, y, z, C) and torch-layout fp32 weights (cout, cin, k, k, k) on the exact-fp32 matrix
+ * instruction.  Same source / upsample / concat semantics and GroupNorm partial layout as
+ * sk_conv3d (sources must be activated: affine == NULL); any cout when gn_partial is NULL. */
+int sk_conv3d_f32(const sk_conv_src* srcs, int n_src, const float* weight, const float* bias,
+                  float* out, int B, int ox, int oy, int oz, int cout, int ksize,
+                  float* gn_partial, void* stream);
+int sk_conv3d_f32_num_blocks(int ox, int oy, int oz);
+int sk_groupnorm_silu_f32(float* x, const float* affine, int B, int64_t voxels, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

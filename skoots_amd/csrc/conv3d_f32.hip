@@ -1,0 +1,199 @@
+// fp32 precision mode of the U-Net layers: the same graph (oracle/unet_spec.py) with fp32
+// activations and fp32 weights on the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32
+// (bitwise an fmaf chain, 1/16 of the fp16 MFMA rate).
+//
+// Purpose: parity.  BASELINE.json's north_star asks for embedding / probability tensors within
+// 1e-3 of the fp32 reference; fp16 MFMA operands alone move this network's outputs by up to
+// ~5e-3 (DESIGN.md "Numerics"), so the fast path can meet that bound only in the RMS sense.
+// This mode runs the identical tiling / normalisation / GroupNorm / heads plumbing with fp32
+// arithmetic and meets 1e-3 max-abs, which pins every difference of the fast path on operand
+// rounding.  It is a gather GEMM (no LDS staging): speed is not its job.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct SrcF32 {
+    const float* data;  // (B, xs, ys, zs, C) fp32 channels-last, activated
+    int C, up;
+    int Xs, Ys, Zs;
+};
+
+struct ConvF32Args {
+    SrcF32 src[2];
+    int nsrc;
+    const float* w;     // torch layout (cout, cin, k, k, k)
+    const float* bias;
+    float* out;         // (B, ox, oy, oz, cout)
+    float* partial;     // (B, nblk, cout/4, 2) or NULL
+    int B, ox, oy, oz, cout, cin, ksize;
+    int nblk;
+};
+
+// one wave = one 32-voxel column tile x one 32-cout row tile; block = 4 waves = 4 column tiles
+__global__ void __launch_bounds__(256) conv_f32_kernel(ConvF32Args a) {
+    __shared__ float red[4 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int nct = (a.cout + 31) / 32;
+    int blk = blockIdx.x;
+    const int ct = blk % nct;       // cout tile
+    blk /= nct;
+    const int b = blk / a.nblk, vb = blk % a.nblk;
+    const long long nvox = (long long)a.ox * a.oy * a.oz;
+    const long long v = ((long long)vb * 4 + w) * 32 + col;
+    const bool ok = v < nvox;
+    const long long vv = ok ? v : 0;
+    const int z = (int)(vv % a.oz);
+    const long long t = vv / a.oz;
+    const int y = (int)(t % a.oy), x = (int)(t / a.oy);
+    const int k = a.ksize, stride = (k == 3) ? 1 : k, padw = (k == 3) ? 1 : 0;
+    const int co = 32 * ct + col;   // this lane's A row (cout)
+
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = 32 * ct + 8 * q + 4 * h + j;
+            acc[4 * q + j] = c < a.cout ? a.bias[c] : 0.0f;
+        }
+    const int k3 = k * k * k;
+    int cbase = 0;
+    for (int s = 0; s < a.nsrc; ++s) {
+        const SrcF32 S = a.src[s];
+        const float* sb = S.data + (long long)b * S.Xs * S.Ys * S.Zs * S.C;
+        for (int tap = 0; tap < k3; ++tap) {
+            const int dx = tap / (k * k), dy = (tap / k) % k, dz = tap % k;
+            int xi = x * stride + dx - padw, yi = y * stride + dy - padw, zi = z * stride + dz - padw;
+            // bounds are those of the (virtual) full-resolution input
+            const int Xf = S.up ? S.Xs * 2 : S.Xs, Yf = S.up ? S.Ys * 2 : S.Ys, Zf = S.up ? S.Zs * 2 : S.Zs;
+            const bool inb = xi >= 0 && xi < Xf && yi >= 0 && yi < Yf && zi >= 0 && zi < Zf;
+            if (S.up) {
+                xi >>= 1;
+                yi >>= 1;
+                zi >>= 1;
+            }
+            const float* ip = sb + (((long long)xi * S.Ys + yi) * S.Zs + zi) * S.C;
+            for (int m = 0; m < (S.C + 1) / 2; ++m) {
+                const int ci = 2 * m + h;  // K index of this lane
+                const bool cok = ci < S.C;
+                float av = (cok && co < a.cout) ? a.w[((long long)co * a.cin + cbase + ci) * k3 + tap] : 0.0f;
+                float bv = (cok && inb && ok) ? ip[ci] : 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+        }
+        cbase += S.C;
+    }
+    float gs[4] = {0, 0, 0, 0}, gq[4] = {0, 0, 0, 0};
+    if (ok) {
+        float* op = a.out + ((long long)b * nvox + v) * a.cout;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int c = 32 * ct + 8 * q + 4 * h + j;
+                if (c < a.cout) {
+                    float r = acc[4 * q + j];
+                    op[c] = r;
+                    gs[q] += r;
+                    gq[q] += r * r;
+                }
+            }
+    }
+    if (a.partial) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float s = gs[q], ss = gq[q];
+#pragma unroll
+            for (int m = 16; m > 0; m >>= 1) {
+                s += __shfl_xor(s, m);
+                ss += __shfl_xor(ss, m);
+            }
+            if (col == 0) {
+                red[(w * 8 + 2 * q + h) * 2] = s;
+                red[(w * 8 + 2 * q + h) * 2 + 1] = ss;
+            }
+        }
+        __syncthreads();
+        if (tid < 16 && 8 * ct * 4 + (tid >> 1) * 4 < a.cout) {
+            float tsum = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+            const int nq = a.cout / 4;
+            a.partial[(((long long)b * a.nblk + vb) * nq + 8 * ct) * 2 + tid] = tsum;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) gn_silu_f32_kernel(float* __restrict__ x, const float* __restrict__ affine,
+                                                          int C, long long n_per_batch) {
+    const int b = blockIdx.y;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    float* p = x + (long long)b * n_per_batch;
+    for (; i < n_per_batch; i += stride) {
+        const int c = (int)(i % C);
+        float y = fmaf(affine[(long long)b * 2 * C + c], p[i], affine[(long long)b * 2 * C + C + c]);
+        p[i] = y / (1.0f + expf(-y));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sk_conv3d_f32_num_blocks(int ox, int oy, int oz) {
+    return (int)(((long long)ox * oy * oz + 127) / 128);
+}
+
+int sk_conv3d_f32(const sk_conv_src* srcs, int n_src, const float* weight, const float* bias, float* out,
+                  int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial, void* stream) {
+    SK_CHECK_ARG(srcs && weight && bias && out, "sk_conv3d_f32: NULL pointer");
+    SK_CHECK_ARG(n_src == 1 || n_src == 2, "sk_conv3d_f32: n_src must be 1 or 2");
+    SK_CHECK_ARG(ksize == 1 || ksize == 2 || ksize == 3, "sk_conv3d_f32: ksize must be 1, 2 or 3");
+    SK_CHECK_ARG(cout >= 1 && (gn_partial == nullptr || cout % 32 == 0),
+                 "sk_conv3d_f32: GroupNorm partials need cout %% 32 == 0");
+    ConvF32Args a{};
+    a.nsrc = n_src;
+    for (int i = 0; i < n_src; ++i) {
+        SK_CHECK_ARG(srcs[i].data && srcs[i].c > 0 && srcs[i].affine == nullptr, "sk_conv3d_f32: bad source %d", i);
+        int up = srcs[i].upsample ? 1 : 0;
+        SK_CHECK_ARG(!up || (ksize == 3 && ox % 2 == 0 && oy % 2 == 0 && oz % 2 == 0),
+                     "sk_conv3d_f32: upsampled source needs ksize 3 and even output extents");
+        a.src[i].data = (const float*)srcs[i].data;
+        a.src[i].C = srcs[i].c;
+        a.src[i].up = up;
+        int s = (ksize == 3) ? 1 : ksize;
+        a.src[i].Xs = up ? ox / 2 : ox * s;
+        a.src[i].Ys = up ? oy / 2 : oy * s;
+        a.src[i].Zs = up ? oz / 2 : oz * s;
+        a.cin += srcs[i].c;
+    }
+    a.w = weight;
+    a.bias = bias;
+    a.out = out;
+    a.partial = gn_partial;
+    a.B = B;
+    a.ox = ox;
+    a.oy = oy;
+    a.oz = oz;
+    a.cout = cout;
+    a.ksize = ksize;
+    a.nblk = sk_conv3d_f32_num_blocks(ox, oy, oz);
+    unsigned grid = (unsigned)(a.nblk * B * ((cout + 31) / 32));
+    conv_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_groupnorm_silu_f32(float* x, const float* affine, int B, int64_t voxels, int C, void* stream) {
+    SK_CHECK_ARG(x && affine && C > 0, "sk_groupnorm_silu_f32: bad arguments");
+    long long n = voxels * C;
+    dim3 grid(sk::stream_grid(n, 256, 4), B);
+    gn_silu_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, affine, C, n);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+}  // extern "C"

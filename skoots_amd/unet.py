@@ -31,6 +31,7 @@ class _ConvLayer:
 
     def __init__(self, prefix: str, sd: Dict[str, Tensor], device, ksize: int):
         w = sd[prefix + ".conv.weight"].detach().float().cpu().contiguous()
+        self.weight_f32 = w.to(device)  # torch layout, used by the fp32 precision mode
         self.cout, self.cin = int(w.shape[0]), int(w.shape[1])
         assert tuple(w.shape[2:]) == (ksize,) * 3, (prefix, tuple(w.shape))
         self.ksize = ksize
@@ -79,7 +80,12 @@ class HipUNet:
 
     def __init__(self, state_dict: Dict[str, Tensor], device="cuda:0",
                  dims: Sequence[int] = (32, 64, 128, 64, 32),
-                 depths: Sequence[int] = (2, 2, 2, 2, 2)):
+                 depths: Sequence[int] = (2, 2, 2, 2, 2), precision: str = "fp16"):
+        """``precision``: "fp16" (fast path: fp16 MFMA operands, fp32 accumulation) or "fp32" (every
+        layer on the exact-fp32 matrix instruction; the parity reference of the fast path)."""
+        if precision not in ("fp16", "fp32"):
+            raise ValueError("precision must be 'fp16' or 'fp32'")
+        self.precision = precision
         self.device = torch.device(device)
         self.dims, self.depths = tuple(dims), tuple(depths)
         d0, d1, d2, d3, d4 = self.dims
@@ -102,6 +108,7 @@ class HipUNet:
         self.dec0 = stack("dec0", depths[4])
         if self.enc0[0].cin != 1:
             raise ValueError("the stem kernel is built for IN_CHANNELS == 1")
+        self.head_w5 = sd["heads.weight"].detach().float().to(dev).contiguous()  # (5, C, 1, 1, 1)
         self.head_w = sd["heads.weight"].detach().float().reshape(5, d4).to(dev).contiguous()
         self.head_b = sd["heads.bias"].detach().float().to(dev).contiguous()
         self.zeros = torch.zeros(4096, dtype=torch.uint8, device=dev)
@@ -123,9 +130,9 @@ class HipUNet:
 
     # -- reference-compatible construction ---------------------------------------------
     @classmethod
-    def from_module(cls, module: torch.nn.Module, device="cuda:0") -> "HipUNet":
+    def from_module(cls, module: torch.nn.Module, device="cuda:0", precision: str = "fp16") -> "HipUNet":
         return cls(module.state_dict(), device, getattr(module, "dims", (32, 64, 128, 64, 32)),
-                   getattr(module, "depths", (2, 2, 2, 2, 2)))
+                   getattr(module, "depths", (2, 2, 2, 2, 2)), precision)
 
     # -- buffers -----------------------------------------------------------------------
     def _buf(self, tag: str, shape: Tuple[int, ...], dtype=torch.float16) -> Tensor:
@@ -220,6 +227,8 @@ class HipUNet:
         xt, yt, zt = (int(v) for v in tile)
         if xt % 4 or yt % 4 or zt % 4:
             raise ValueError(f"tile extents {tuple(tile)} must be multiples of 4 (two stride-2 levels)")
+        if self.precision == "fp32":
+            return self._forward_fp32(image, origins, (xt, yt, zt), float(mean), float(std))
         B = len(origins)
         L0, L1, L2 = (xt, yt, zt), (xt // 2, yt // 2, zt // 2), (xt // 4, yt // 4, zt // 4)
         feats = self.last_features = {}
@@ -280,6 +289,60 @@ class HipUNet:
                                      _ffi.ptr(out5), B, xt * yt * zt, a.shape[-1],
                                      _ffi.stream_ptr(self.device)))
         return out5
+
+    # -- fp32 precision mode ------------------------------------------------------------
+    def _conv_f32(self, layer, srcs, out_shape, weight=None, bias=None, cout=None, norm=True) -> Tensor:
+        B = srcs[0][0].shape[0]
+        ox, oy, oz = out_shape
+        cout = layer.cout if cout is None else cout
+        weight = layer.weight_f32 if weight is None else weight
+        bias = layer.bias if bias is None else bias
+        out = torch.empty((B, ox, oy, oz, cout), dtype=torch.float32, device=self.device)
+        nblk = _ffi.lib.sk_conv3d_f32_num_blocks(ox, oy, oz)
+        partial = torch.empty((B, nblk, cout // 4, 2), dtype=torch.float32, device=self.device) if norm else None
+        arr = (_ffi.ConvSrc * len(srcs))()
+        for i, (t, up) in enumerate(srcs):
+            arr[i].data = t.data_ptr()
+            arr[i].affine = None
+            arr[i].c = t.shape[-1]
+            arr[i].upsample = up
+        st = _ffi.stream_ptr(self.device)
+        _ffi.check(_ffi.lib.sk_conv3d_f32(arr, len(srcs), _ffi.ptr(weight), _ffi.ptr(bias), _ffi.ptr(out), B,
+                                          ox, oy, oz, cout, layer.ksize if layer is not None else 1,
+                                          _ffi.ptr(partial), st))
+        if norm:
+            aff = torch.empty((B, 2, cout), dtype=torch.float32, device=self.device)
+            vox = ox * oy * oz
+            _ffi.check(_ffi.lib.sk_groupnorm_finalize(_ffi.ptr(partial), B, nblk, GN_GROUPS, cout, vox,
+                                                      _ffi.ptr(layer.gamma), _ffi.ptr(layer.beta), GN_EPS,
+                                                      _ffi.ptr(aff), st))
+            _ffi.check(_ffi.lib.sk_groupnorm_silu_f32(_ffi.ptr(out), _ffi.ptr(aff), B, vox, cout, st))
+        return out
+
+    def _forward_fp32(self, image: Tensor, origins, tile, mean: float, std: float) -> Tensor:
+        xt, yt, zt = tile
+        L0, L1, L2 = tile, (xt // 2, yt // 2, zt // 2), (xt // 4, yt // 4, zt // 4)
+        crops = torch.stack([image[x:x + xt, y:y + yt, z:z + zt] for (x, y, z) in origins])
+        a = crops.sub(mean).div(std).float().unsqueeze(-1).contiguous()  # eval.py:139 (fp16 arithmetic)
+        for layer in self.enc0:
+            a = self._conv_f32(layer, [(a, 0)], L0)
+        s0 = a
+        a = self._conv_f32(self.down0, [(s0, 0)], L1)
+        for layer in self.enc1:
+            a = self._conv_f32(layer, [(a, 0)], L1)
+        s1 = a
+        a = self._conv_f32(self.down1, [(s1, 0)], L2)
+        for layer in self.mid:
+            a = self._conv_f32(layer, [(a, 0)], L2)
+        r1 = self._conv_f32(self.red1, [(a, 0)], L2)
+        for i, layer in enumerate(self.dec1):
+            a = self._conv_f32(layer, [(s1, 0), (r1, 1)] if i == 0 else [(a, 0)], L1)
+        r0 = self._conv_f32(self.red0, [(a, 0)], L1)
+        for i, layer in enumerate(self.dec0):
+            a = self._conv_f32(layer, [(s0, 0), (r0, 1)] if i == 0 else [(a, 0)], L0)
+        y = self._conv_f32(None, [(a, 0)], L0, weight=self.head_w5, bias=self.head_b, cout=5, norm=False)
+        y = y.permute(0, 4, 1, 2, 3)
+        return torch.cat([torch.tanh(y[:, 0:3]), torch.sigmoid(y[:, 3:5])], dim=1).contiguous()
 
     def flops_per_tile_voxel(self) -> float:
         """Algorithmic conv FLOPs per full-resolution tile voxel (2*Cin*Cout*k^3 / downsampling)."""

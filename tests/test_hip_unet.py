@@ -174,3 +174,61 @@ def test_network_vs_oracle(U, tile, origins):
               f"fp16-storage emulation vs fp32 rms {rms(emu):.2e} max {emu.max():.2e}")
         assert rms(e32) <= 1e-3 and e32.max().item() <= 1e-2
         assert rms(e32) <= 1.25 * rms(emu) + 1e-5
+
+
+@pytest.mark.parametrize("tile,origins", [((64, 64, 20), [(0, 0, 0)]), ((32, 48, 20), [(3, 1, 2), (10, 0, 0)])])
+def test_network_fp32_mode_vs_oracle(U, tile, origins):
+    """precision="fp32": the same tiling / normalisation / GroupNorm / heads plumbing on the exact-fp32
+    matrix instruction.  Max-abs <= 1e-3 against the fp32 oracle -- the tolerance BASELINE.json's
+    north_star states (measured ~1e-5) -- which pins every difference of the fp16 fast path on
+    operand rounding."""
+    from oracle import unet_spec
+    ref = unet_spec.build(101196)
+    hip = U.HipUNet.from_module(ref, DEV, precision="fp32")
+    gen = torch.Generator().manual_seed(tile[0])
+    shape = tuple(max(o[k] for o in origins) + tile[k] for k in range(3))
+    vol = torch.randint(0, 256, shape, generator=gen).to(torch.float16)
+    mean, std = float(vol.mean()), float(vol.std())
+    out5 = hip.forward_tiles(vol.to(DEV), origins, tile, mean, std).cpu()
+    assert out5.dtype == torch.float32
+    for b, (x, y, z) in enumerate(origins):
+        crop = vol[x:x + tile[0], y:y + tile[1], z:z + tile[2]][None, None].sub(mean).div(std).float()
+        with torch.no_grad():
+            want = ref(crop)[0]
+        err = (out5[b] - want).abs().max().item()
+        print(f"fp32 mode tile {b}: max abs err {err:.2e}")
+        assert err <= 1e-3
+
+
+def test_end_to_end_with_network_fp32_mode(U):
+    """Whole eval path WITH the network (no injected field) in fp32 mode against the CPU oracle on
+    the same volume: vectors within 1e-3 wherever both gates agree, and the thresholded skeleton /
+    final instance masks differ only where a probability sits within ~1e-5 of the 0.8 threshold."""
+    import numpy as np
+    from oracle import pipeline as O
+    from oracle import unet_spec
+    from skoots_amd.lib import eval as E
+    ref = unet_spec.build(7)
+    with torch.no_grad():  # open the semantic gate, put the skeleton map around its threshold
+        ref.heads.bias[4] = 3.0
+        ref.heads.bias[3] = 1.4
+        ref.heads.weight[0:3].mul_(0.15)
+    hip = U.HipUNet.from_module(ref, DEV, precision="fp32")
+    gen = torch.Generator().manual_seed(3)
+    shape = (140, 132, 34)
+    vol = torch.randint(0, 256, (1,) + shape, generator=gen).to(torch.float16)
+    with torch.no_grad():
+        want = O.eval_volume(vol, ref, (60, 60, 12))
+    got = E.eval_volume(vol.to(DEV), hip, (60, 60, 12), keep_planar_vectors=True)
+    sk_w, sk_g = want["skeleton"][0], got["skeleton"].cpu().numpy()
+    assert sk_w.sum() > 1000
+    assert (sk_w != sk_g).mean() < 1e-4
+    v_w, v_g = want["vectors"].astype(np.float32), got["state"].vec_planar.cpu().numpy().astype(np.float32)
+    both = (np.abs(v_w).sum(0) > 0) == (np.abs(v_g).sum(0) > 0)
+    assert both.mean() > 0.9999
+    assert np.abs(v_w - v_g)[:, both].max() <= 1e-3
+    if (sk_w == sk_g).all() and both.all():
+        # identical gates -> the integer stages must agree bit for bit
+        assert np.array_equal(got["instance_mask"].cpu().numpy(), want["instance_mask"])
+    else:
+        assert (got["instance_mask"].cpu().numpy() != want["instance_mask"]).mean() < 5e-3
