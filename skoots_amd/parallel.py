@@ -4,10 +4,10 @@ rehearsals in tests/).
 
 The reference is single device (skoots/lib/eval.py:57).  The path shards naturally:
 
-  stage 1  tiles are independent.  Rank r owns the planes [z_lo, z_hi) of the volume and
-           evaluates every tile (global 300x300x20 grid, unchanged) that is the last
-           writer of one of its planes; tiles straddling a slab boundary are evaluated by
-           both neighbours (no stage-1 collective; input halo comes with the image).
+  stage 1  tiles are independent.  Rank r owns the planes [z_lo, z_hi) of the volume; every
+           tile of the global 300x300x20 grid (unchanged) runs on exactly one rank, the owner
+           of the first plane it writes last; the few planes a slab-straddling tile writes
+           for the next rank are sent point to point (input halo comes with the image).
   stage 2  each rank labels its slab; the label planes either side of every slab
            boundary are exchanged, the (few) seam equivalences are all-gathered and
            every rank applies the same union to its slab.  The slabs are then
@@ -34,7 +34,7 @@ from torch import Tensor
 
 from .lib import cropper
 
-HALO = 64  # planes kept either side of the slab: >= 45 (stage-3 crop reach) and tile depth reach
+HALO = 48  # planes kept either side of the slab: >= 45 (stage-3 crop reach) and the tile depth reach
 
 
 def slab_bounds(Z: int, world: int) -> List[Tuple[int, int]]:
@@ -50,13 +50,40 @@ def window_of(slab: Tuple[int, int], Z: int, world: int, halo: int = HALO) -> Tu
 
 def tiles_for_slab(shape: Sequence[int], tile: Sequence[int], overlap: Sequence[int],
                    slab: Tuple[int, int]) -> Tuple[List[Tuple[int, int, int]], List[int]]:
-    """Distinct tile origins (reference order) that write at least one plane of ``slab``
-    last, plus the effective tile size (cropper.py:97-144 grid, eval.py:160-176 scatter)."""
+    """Distinct tile origins (reference order) this rank evaluates, plus the effective tile size
+    (cropper.py:97-144 grid, eval.py:160-176 scatter).  Every tile runs on exactly ONE rank: the
+    owner of the first plane the tile writes last.  The (<= 9) planes such a tile writes beyond
+    the slab are handed to the next rank by :func:`exchange_straddle`."""
     eff = list(tile)
     origins = cropper.distinct_origins(shape, eff, overlap)
     own_z = cropper.owner_table(shape[2], eff[2], overlap[2])
-    mine = set(int(v) for v in np.unique(own_z[slab[0]:slab[1]]) if v >= 0)
+    first_plane = {}
+    for z, oz in enumerate(own_z):
+        if oz >= 0 and int(oz) not in first_plane:
+            first_plane[int(oz)] = z
+    mine = {oz for oz, z in first_plane.items() if slab[0] <= z < slab[1]}
     return [o for o in origins if o[2] in mine], eff
+
+
+def straddle_extent(shape: Sequence[int], tile: Sequence[int], overlap: Sequence[int],
+                    slabs: List[Tuple[int, int]]) -> List[int]:
+    """e[r]: number of planes [slab_r.hi, slab_r.hi + e[r]) that rank r's tiles write for rank r+1."""
+    eff = list(tile)
+    cropper.clamp_crop_(eff, shape)
+    own_z = cropper.owner_table(shape[2], eff[2], overlap[2])
+    first_plane = {}
+    for z, oz in enumerate(own_z):
+        if oz >= 0 and int(oz) not in first_plane:
+            first_plane[int(oz)] = z
+    out = []
+    for (lo, hi) in slabs:
+        e = 0
+        for oz, z0 in first_plane.items():
+            if lo <= z0 < hi:
+                last = int(np.nonzero(own_z == oz)[0][-1])
+                e = max(e, last + 1 - hi)
+        out.append(max(e, 0))
+    return out
 
 
 def halo_plan(slabs: List[Tuple[int, int]], windows: List[Tuple[int, int]], rank: int):
@@ -129,6 +156,26 @@ def exchange_halo(arr: Tensor, slabs, windows, rank: int, comm: Comm) -> None:
     got = comm.exchange(out, like)
     for (q, lo, hi), t in zip(recvs, got):
         arr[:, :, lo - w0:hi - w0] = t
+
+
+def exchange_straddle(arrays: Sequence[Tensor], extents: List[int], slabs, windows, rank: int, comm: "Comm") -> None:
+    """Planes a rank's last tile wrote beyond its slab go to the next rank (which did not evaluate
+    that tile).  ``arrays``: window-shaped (X, Y, Zl, ...) tensors, updated in place."""
+    world = len(slabs)
+    w0 = windows[rank][0]
+    sends, like, dst = [], [], []
+    for arr in arrays:
+        if rank + 1 < world and extents[rank] > 0:
+            hi = slabs[rank][1]
+            sends.append((rank + 1, arr[:, :, hi - w0:hi + extents[rank] - w0]))
+        if rank > 0 and extents[rank - 1] > 0:
+            lo = slabs[rank][0]
+            view = arr[:, :, lo - w0:lo + extents[rank - 1] - w0]
+            like.append((rank - 1, torch.empty(tuple(view.shape), dtype=arr.dtype, device=arr.device)))
+            dst.append(view)
+    got = comm.exchange(sends, like)
+    for view, t in zip(dst, got):
+        view.copy_(t)
 
 
 class ShardedVolume:
@@ -209,6 +256,11 @@ class ShardedVolume:
         for c in ctxs:
             if c is not None:
                 c.profile = None
+        if self.world > 1:  # hand the planes of slab-straddling tiles to the next rank
+            ext = straddle_extent(self.shape, tile, tile_overlap, self.slabs)
+            for e, (lo, hi), (wl, wh) in zip(ext, self.slabs, self.windows):
+                assert hi + e <= wh, "a straddling tile writes outside its rank's window"
+            exchange_straddle([state.vec4, state.skeleton], ext, self.slabs, self.windows, self.rank, comm)
         self._tick("stage1", t0)
 
         # ---- stage 2 --------------------------------------------------------------------

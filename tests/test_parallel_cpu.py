@@ -31,24 +31,32 @@ def test_slabs_and_windows_cover_the_volume():
 
 
 @pytest.mark.parametrize("shape,world", [((1024, 1024, 256), 2), ((2048, 2048, 512), 8), ((640, 333, 250), 3)])
-def test_every_plane_gets_its_last_writer_tile(shape, world):
+def test_every_tile_runs_once_and_every_plane_is_delivered(shape, world):
     tile, ov = (300, 300, 20), (50, 50, 5)
     eff = list(tile)
     all_tiles = cropper.distinct_origins(shape, eff, ov)
     own_z = cropper.owner_table(shape[2], eff[2], ov[2])
     slabs = P.slab_bounds(shape[2], world)
+    ext = P.straddle_extent(shape, tile, ov, slabs)
     union = []
     for r in range(world):
         mine, eff_r = P.tiles_for_slab(shape, tile, ov, slabs[r])
         assert eff_r == eff
         zs = {o[2] for o in mine}
-        for z in range(*slabs[r]):
-            assert own_z[z] < 0 or own_z[z] in zs  # the last writer of every owned plane runs here
         w = P.window_of(slabs[r], shape[2], world)
         assert all(w[0] <= o[2] and o[2] + eff[2] <= w[1] for o in mine)  # tiles fit the window
         assert mine == [o for o in all_tiles if o[2] in zs]  # reference order preserved
+        # every owned plane is written by one of this rank's tiles or delivered by rank r-1
+        prev = {o[2] for o in P.tiles_for_slab(shape, tile, ov, slabs[r - 1])[0]} if r else set()
+        for z in range(*slabs[r]):
+            if own_z[z] < 0:
+                continue
+            if own_z[z] in zs:
+                continue
+            assert own_z[z] in prev and z < slabs[r][0] + ext[r - 1], (r, z)
+        assert slabs[r][1] + ext[r] <= w[1]
         union += mine
-    assert set(union) == set(all_tiles)
+    assert sorted(union) == sorted(all_tiles)  # each tile exactly once
 
 
 def _worker(rank, world, port, shape, q):
