@@ -228,12 +228,14 @@ int sk_groupnorm_finalize(const float* gn_partial, int B, int nblocks, int group
 /* Fused GroupNorm affine + SiLU, in place on (B, voxels, C) fp16. */
 int sk_groupnorm_silu(void* x, const float* affine, int B, int64_t voxels, int C, void* stream);
 
-/* Heads: 1x1x1 conv C->5, tanh on [0:3], sigmoid on [3:5]; out5 (B, 5, voxels) planar fp16 =
- * the reference's output layout (eval.py:145-147).  x: (B, voxels, C) fp16, activated if
- * affine == NULL, else RAW with affine (B, 2, C) applied (+ SiLU) on load.
- * weight (5, C) fp32, bias (5). */
+/* Heads: 1x1x1 conv C->5, tanh on [0:3], sigmoid on [3:5]; out5 (B, 5, X, Y, Z) planar fp16 =
+ * the reference's output layout (eval.py:145-147).  x: (B, X, Y, Z, C) fp16, activated if
+ * affine == NULL, else RAW with affine (B, 2, C) applied (+ SiLU) on load.  weight (5, C) fp32,
+ * bias (5).  box_lo/hi_host (int[3], tile-local, may be NULL = whole tile): only that box of every
+ * tile is evaluated and written -- the eval pipeline needs just the interior + dilation reach. */
 int sk_heads(const void* x, const float* affine, const float* weight, const float* bias, void* out5,
-             int B, int64_t voxels, int C, void* stream);
+             int B, int X, int Y, int Z, int C, const int* box_lo_host, const int* box_hi_host,
+             void* stream);
 
 /* fp32 precision mode (parity reference of the fast path): the same layers with fp32 activations
  * (B, x, y, z, C) and torch-layout fp32 weights (cout, cin, k, k, k) on the exact-fp32 matrix

@@ -259,8 +259,11 @@ struct HeadArgs {
     const float* weight; // (5, C)
     const float* bias;   // (5)
     __half* out5;        // (B, 5, n)
-    long long n;
+    long long n;         // voxels per tile = X*Y*Z
     int C;
+    int Y, Z;            // tile extents (X = n / (Y*Z))
+    int lx, ly, lz;      // only the box [l, h) of every tile is evaluated (the rest of out5 is not written)
+    int bx, by, bz;      // box extents
 };
 
 // out5[k][voxel] = act_k( W[k][:] . silu(affine(x[voxel][:])) + bias[k] ) as a 32x32x16 MFMA with
@@ -300,10 +303,15 @@ __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
     }
     const __half* xb = a.x + (long long)b * a.n * C;
     __half* ob = a.out5 + (long long)b * 5 * a.n;
-    const long long ntiles = (a.n + 31) / 32;
+    const long long nbox = (long long)a.bx * a.by * a.bz;
+    const long long ntiles = (nbox + 31) / 32;
     for (long long t = (long long)blockIdx.x * 4 + (tid >> 6); t < ntiles; t += (long long)gridDim.x * 4) {
-        const long long v = t * 32 + col;
-        const bool ok = v < a.n;
+        const long long i = t * 32 + col;
+        const bool ok = i < nbox;
+        const long long ii = ok ? i : 0;
+        const int z = (int)(ii % a.bz);
+        const long long r2 = ii / a.bz;
+        const long long v = ((long long)(a.lx + (int)(r2 / a.by)) * a.Y + (a.ly + (int)(r2 % a.by))) * a.Z + (a.lz + z);
         const half8* p = reinterpret_cast<const half8*>(xb + (ok ? v : 0) * C);
         half8 bf[2];
 #pragma unroll
@@ -445,10 +453,36 @@ int sk_groupnorm_silu(void* x, const float* affine, int B, int64_t voxels, int C
 }
 
 int sk_heads(const void* x, const float* affine, const float* weight, const float* bias, void* out5, int B,
-             int64_t voxels, int C, void* stream) {
+             int X, int Y, int Z, int C, const int* box_lo_host, const int* box_hi_host, void* stream) {
     SK_CHECK_ARG(x && weight && bias && out5, "sk_heads: NULL pointer");
     SK_CHECK_ARG(C == 32, "sk_heads: C must be 32");
-    HeadArgs a{(const __half*)x, affine, weight, bias, (__half*)out5, voxels, C};
+    SK_CHECK_ARG(X > 0 && Y > 0 && Z > 0, "sk_heads: bad extents");
+    HeadArgs a{};
+    a.x = (const __half*)x;
+    a.affine = affine;
+    a.weight = weight;
+    a.bias = bias;
+    a.out5 = (__half*)out5;
+    a.n = (long long)X * Y * Z;
+    a.C = C;
+    a.Y = Y;
+    a.Z = Z;
+    a.bx = X;
+    a.by = Y;
+    a.bz = Z;
+    if (box_lo_host && box_hi_host) {
+        SK_CHECK_ARG(0 <= box_lo_host[0] && box_lo_host[0] < box_hi_host[0] && box_hi_host[0] <= X &&
+                         0 <= box_lo_host[1] && box_lo_host[1] < box_hi_host[1] && box_hi_host[1] <= Y &&
+                         0 <= box_lo_host[2] && box_lo_host[2] < box_hi_host[2] && box_hi_host[2] <= Z,
+                     "sk_heads: box must be a non-empty box inside the tile");
+        a.lx = box_lo_host[0];
+        a.ly = box_lo_host[1];
+        a.lz = box_lo_host[2];
+        a.bx = box_hi_host[0] - a.lx;
+        a.by = box_hi_host[1] - a.ly;
+        a.bz = box_hi_host[2] - a.lz;
+    }
+    const long long voxels = (long long)a.bx * a.by * a.bz;
     dim3 grid(sk::stream_grid((voxels + 31) / 32, 4, 4), B);
     heads_kernel<32><<<grid, 256, 0, (hipStream_t)stream>>>(a);
     SK_CHECK_LAUNCH();

@@ -223,6 +223,10 @@ class ShardedVolume:
         for (_, _, oz) in origins:
             assert wlo <= oz and oz + eff[2] <= whi, "tile outside the rank's window: increase the halo"
         owners = [cropper.owner_table(dm, c, o) for dm, c, o in zip(self.shape, eff, tile_overlap)]
+        # the gate/dilate/scatter kernel reads a tile's output on its interior +- the dilation reach (3,3,1)
+        reach = (3, 3, 1)
+        out_box = ([max(0, o - r) for o, r in zip(tile_overlap, reach)],
+                   [min(s_, s_ - o + r) for s_, o, r in zip(eff, tile_overlap, reach)])
         n_streams = max(1, int(streams)) if model is not None else 1
         ctxs = [model] + [model.clone_context() for _ in range(n_streams - 1)] if model is not None else [None]
         for c in ctxs:
@@ -237,7 +241,8 @@ class ShardedVolume:
             local = [(x, y, z - wlo) for (x, y, z) in batch]
             k = bi % n_streams
             with torch.cuda.stream(lanes[k]):
-                out5 = ctxs[k].forward_tiles(image, local, eff, mean, std) if model is not None else None
+                out5 = (ctxs[k].forward_tiles(image, local, eff, mean, std, out_box=out_box)
+                        if model is not None else None)
                 outs = []
                 for b, org in enumerate(batch):
                     o = out5[b] if out5 is not None else None

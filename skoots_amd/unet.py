@@ -219,8 +219,10 @@ class HipUNet:
 
     # -- forward -----------------------------------------------------------------------
     def forward_tiles(self, image: Tensor, origins: Sequence[Sequence[int]], tile: Sequence[int],
-                      mean: float, std: float, keep_features: bool = False) -> Tensor:
-        """image (X, Y, Z) fp16 on the GPU; B tile origins; tile extents (w, h, d)."""
+                      mean: float, std: float, keep_features: bool = False, out_box=None) -> Tensor:
+        """image (X, Y, Z) fp16 on the GPU; B tile origins; tile extents (w, h, d).
+        ``out_box`` = (lo, hi) tile-local: only that box of the 5-channel output is evaluated (every
+        conv still covers the whole tile -- its GroupNorm statistics need it -- but the heads do not)."""
         _ffi.require_gpu(image, "image")
         if image.dtype != torch.float16 or image.ndim != 3:
             raise ValueError("image must be an (X, Y, Z) fp16 tensor")
@@ -285,8 +287,11 @@ class HipUNet:
                 a, aff = a
             keep(layer.name, a)
         out5 = self._buf("out5", (B, 5, xt, yt, zt))
+        i3 = C.c_int32 * 3
+        blo = i3(*[int(v) for v in out_box[0]]) if out_box is not None else None
+        bhi = i3(*[int(v) for v in out_box[1]]) if out_box is not None else None
         _ffi.check(_ffi.lib.sk_heads(_ffi.ptr(a), _ffi.ptr(aff), _ffi.ptr(self.head_w), _ffi.ptr(self.head_b),
-                                     _ffi.ptr(out5), B, xt * yt * zt, a.shape[-1],
+                                     _ffi.ptr(out5), B, xt, yt, zt, a.shape[-1], blo, bhi,
                                      _ffi.stream_ptr(self.device)))
         return out5
 
