@@ -20,7 +20,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
-struct __attribute__((packed, aligned(2))) Row4 { half4v v; };  // 8 bytes at a 2-byte aligned address
 
 struct StemArgs {
     const __half* image;   // (X, Y, Z) fp16 volume
@@ -39,7 +38,6 @@ struct StemArgs {
 
 constexpr int kStemTilesPerWave = 8;                       // 32-voxel column tiles per wave
 constexpr int kStemVoxPerBlock = 4 * 32 * kStemTilesPerWave;
-constexpr int kStemSlack = 32;                             // zeroed halves after the last padded tile
 
 __global__ void __launch_bounds__(256) stem_norm_kernel(StemArgs a) {
     const int b = blockIdx.y;
@@ -59,8 +57,6 @@ __global__ void __launch_bounds__(256) stem_norm_kernel(StemArgs a) {
         v = __half2float(__float2half_rn(s / a.stdv));
     }
     a.norm[(long long)b * n + i] = __float2half_rn(v);
-    // the row segments read one element past the last tile (x zero weight): keep it finite
-    if (b == a.B - 1 && i < kStemSlack) a.norm[(long long)a.B * n + i] = __float2half_rn(0.0f);
 }
 
 // One conv pass over the zero-framed normalised tile.  STATS: accumulate the GroupNorm partial
@@ -79,25 +75,20 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
     const int py = a.Yt + 2, pz = a.Zt + 2;
     const __half* nb = a.norm + (long long)b * (a.Xt + 2) * py * pz;
 
-    // K = 48 = 12 tap rows (dx,dy) x 4 consecutive z (rows >= 9 and the 4th z have zero weight), so
-    // that a lane's 8 K values of an MFMA step are two 8-byte row segments of the padded tile:
-    // k = 16 m + 8 h + j  ->  row = 4 m + 2 h + (j >> 2),  dz = j & 3
-    half8 whi[3], wlo[3];
-    int roff[3][2];
+    // A operands: lane holds W[cout = l&31][tap = 16m + 8h + j], j = 0..7, m = 0,1 (tap >= 27: 0)
+    half8 whi[2], wlo[2];
+    int toff[2][8];
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int row = 4 * m + 2 * h + (j >> 2), dz = j & 3;
-            const bool live = row < 9 && dz < 3;
-            float wv = live ? a.weight[(row * 3 + dz) * 32 + col] : 0.0f;
+            int tap = 16 * m + 8 * h + j;
+            float wv = tap < 27 ? a.weight[tap * 32 + col] : 0.0f;
             _Float16 hi = (_Float16)wv;
             whi[m][j] = hi;
             wlo[m][j] = (_Float16)(wv - (float)hi);
-            if ((j & 3) == 0) {
-                const int rr = row < 9 ? row : 0;  // any valid row: its weights are zero
-                roff[m][j >> 2] = ((rr / 3) * py + rr % 3) * pz;
-            }
+            int tt = tap < 27 ? tap : 0;  // any valid address: its weight is zero
+            toff[m][j] = ((tt / 9) * py + (tt / 3) % 3) * pz + tt % 3;
         }
     f32x16 binit;
     float ga[16], gb[16];
@@ -122,19 +113,17 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
         long long r = vv / a.Zt;
         int y = (int)(r % a.Yt), x = (int)(r / a.Yt);
         const _Float16* p = reinterpret_cast<const _Float16*>(nb) + ((long long)x * py + y) * pz + z;
-        half8 bf[3];
+        half8 b0, b1;
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            // two under-aligned 8-byte loads (2-byte aligned: gfx950 runs in unaligned access mode)
-            const half4v r0 = reinterpret_cast<const Row4*>(p + roff[m][0])->v;
-            const half4v r1 = reinterpret_cast<const Row4*>(p + roff[m][1])->v;
-            bf[m] = half8{r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+        for (int j = 0; j < 8; ++j) {
+            b0[j] = p[toff[0][j]];
+            b1[j] = p[toff[1][j]];
         }
         f32x16 acc = binit;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[m], bf[m], acc, 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < 3; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[m], bf[m], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[0], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[1], b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], b1, acc, 0, 0, 0);
         if (ok) {
             if (STATS) {
 #pragma unroll
@@ -182,36 +171,30 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
 
 // ------------------------------------------------------------------------------ GroupNorm
 // partial: (B, nblk, C/4, 2) fp32 -> affine (B, 2, C): a = gamma*rstd, b = beta - mean*a
-__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partial, int nblk,
-                                                          int groups, int C, double count,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps,
-                                                          float* __restrict__ affine) {
-    __shared__ double qs[64], qss[64];   // per channel quad (C/4 <= 32) x up to 2 halves
-    __shared__ double acc_s[256], acc_ss[256];
+constexpr int kFinThreads = 1024;
+
+__global__ void __launch_bounds__(kFinThreads) gn_finalize_kernel(const float* __restrict__ partial, int nblk,
+                                                                  int groups, int C, double count,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float eps,
+                                                                  float* __restrict__ affine) {
+    __shared__ double qv[64];            // per channel quad: (sum, sumsq) interleaved, C/4 <= 32
+    __shared__ double accv[kFinThreads];
     const int b = blockIdx.x;
-    const int nq = C / 4;
+    const int nv = C / 2;                // floats per partial row = (C/4) quads x 2
     const int tid = threadIdx.x;
-    // thread (q, lane-slice): slices of the block list, fixed order -> deterministic
-    const int q = tid % nq, sl = tid / nq, nsl = 256 / nq;
-    double s = 0.0, ss = 0.0;
-    if (sl < nsl)
-        for (int k = sl; k < nblk; k += nsl) {
-            const float* p = partial + (((long long)b * nblk + k) * nq + q) * 2;
-            s += (double)p[0];
-            ss += (double)p[1];
-        }
-    acc_s[tid] = s;
-    acc_ss[tid] = ss;
+    // thread (value, row-slice): consecutive threads read consecutive floats of a row (coalesced);
+    // every value is summed in a fixed order -> deterministic, independent of launch timing
+    const int val = tid % nv, sl = tid / nv, nsl = kFinThreads / nv;
+    double s = 0.0;
+    const float* base = partial + (long long)b * nblk * nv + val;
+    for (int k = sl; k < nblk; k += nsl) s += (double)base[(long long)k * nv];
+    accv[tid] = s;
     __syncthreads();
-    if (tid < nq) {
-        double a = 0.0, c = 0.0;
-        for (int k = 0; k < nsl; ++k) {
-            a += acc_s[k * nq + tid];
-            c += acc_ss[k * nq + tid];
-        }
-        qs[tid] = a;
-        qss[tid] = c;
+    if (tid < nv) {
+        double a = 0.0;
+        for (int k = 0; k < nsl; ++k) a += accv[k * nv + tid];
+        qv[tid] = a;
     }
     __syncthreads();
     if (tid < C) {
@@ -220,8 +203,8 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
         const int q0 = g * gs / 4, q1 = (g + 1) * gs / 4;
         double a = 0.0, c = 0.0;
         for (int k = q0; k < q1; ++k) {
-            a += qs[k];
-            c += qss[k];
+            a += qv[2 * k];
+            c += qv[2 * k + 1];
         }
         double n = count * gs;
         double mean = a / n;
@@ -364,7 +347,7 @@ int sk_conv3d_stem_num_blocks(int X, int Y, int Z) {
 }
 
 size_t sk_conv3d_stem_workspace_bytes(int B, int Xt, int Yt, int Zt) {
-    return ((size_t)B * (Xt + 2) * (Yt + 2) * (Zt + 2) + kStemSlack) * sizeof(__half);
+    return (size_t)B * (Xt + 2) * (Yt + 2) * (Zt + 2) * sizeof(__half);
 }
 
 static int fill_stem_args(StemArgs& a, const void* image, int X, int Y, int Z, const int32_t* origins_host,
@@ -445,8 +428,8 @@ int sk_groupnorm_finalize(const float* gn_partial, int B, int nblocks, int group
     SK_CHECK_ARG(gn_partial && gamma && beta && affine, "sk_groupnorm_finalize: NULL pointer");
     SK_CHECK_ARG(C % 4 == 0 && C <= 128 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0,
                  "sk_groupnorm_finalize: C=%d groups=%d unsupported", C, groups);
-    SK_CHECK_ARG(256 % (C / 4) == 0, "sk_groupnorm_finalize: C/4 must divide 256");
-    gn_finalize_kernel<<<B, 256, 0, (hipStream_t)stream>>>(gn_partial, nblocks, groups, C, (double)voxels,
+    SK_CHECK_ARG(kFinThreads % (C / 2) == 0, "sk_groupnorm_finalize: C/2 must divide %d", kFinThreads);
+    gn_finalize_kernel<<<B, kFinThreads, 0, (hipStream_t)stream>>>(gn_partial, nblocks, groups, C, (double)voxels,
                                                             gamma, beta, eps, affine);
     SK_CHECK_LAUNCH();
     return SK_OK;
