@@ -36,8 +36,6 @@ struct StemArgs {
     int nblk;
 };
 
-constexpr int kStemTilesPerWave = 8;                       // 32-voxel column tiles per wave
-constexpr int kStemVoxPerBlock = 4 * 32 * kStemTilesPerWave;
 
 __global__ void __launch_bounds__(256) stem_norm_kernel(StemArgs a) {
     const int b = blockIdx.y;
@@ -65,15 +63,34 @@ __global__ void __launch_bounds__(256) stem_norm_kernel(StemArgs a) {
 // write + read-modify-write pass: the conv is 4 MFMAs per 32 voxels, the tensor is 64 B/voxel.
 // Weights are split w = hi + lo (two fp16 values, 22 significant bits) and the input is exactly
 // fp16, so the products are exact and the sums match an fp32 conv to ~1e-7 relative.
+constexpr int kStemRows = 48;   // y rows of one x plane per workgroup
+
 template <bool STATS>
 __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
     __shared__ float red[4 * 16];
+    extern __shared__ __attribute__((aligned(16))) unsigned int stem_lds[];  // [3][rows+2][Zt+2] halves
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
-    const int b = blockIdx.x / a.nblk, blk = blockIdx.x % a.nblk;
+    const int nyc = (a.Yt + kStemRows - 1) / kStemRows;
+    int blk = blockIdx.x % a.nblk;
+    const int b = blockIdx.x / a.nblk;
+    const int x = blk / nyc, y0 = (blk % nyc) * kStemRows;
+    const int rows = min(kStemRows, a.Yt - y0);
     const long long nvox = (long long)a.Xt * a.Yt * a.Zt;
     const int py = a.Yt + 2, pz = a.Zt + 2;
     const __half* nb = a.norm + (long long)b * (a.Xt + 2) * py * pz;
+
+    // stage the three padded x planes' rows [y0, y0 + rows + 2): contiguous (rows+2)*pz halves each
+    const int seg_halves = (kStemRows + 2) * pz;          // LDS pitch per plane (halves, even)
+    const int seg_dw = (rows + 2) * pz / 2;               // dwords to copy (pz is even: Zt % 4 == 0)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const unsigned int* src = reinterpret_cast<const unsigned int*>(nb + ((long long)(x + dx) * py + y0) * pz);
+        unsigned int* dst = stem_lds + dx * (seg_halves / 2);
+        for (int i = tid; i < seg_dw; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const _Float16* ls = reinterpret_cast<const _Float16*>(stem_lds);
 
     // A operands: lane holds W[cout = l&31][tap = 16m + 8h + j], j = 0..7, m = 0,1 (tap >= 27: 0)
     half8 whi[2], wlo[2];
@@ -88,7 +105,7 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
             whi[m][j] = hi;
             wlo[m][j] = (_Float16)(wv - (float)hi);
             int tt = tap < 27 ? tap : 0;  // any valid address: its weight is zero
-            toff[m][j] = ((tt / 9) * py + (tt / 3) % 3) * pz + tt % 3;
+            toff[m][j] = (tt / 9) * seg_halves + ((tt / 3) % 3) * pz + tt % 3;
         }
     f32x16 binit;
     float ga[16], gb[16];
@@ -105,14 +122,14 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
         }
     }
     float gsum[4] = {0, 0, 0, 0}, gsq[4] = {0, 0, 0, 0};
-    for (int t = 0; t < kStemTilesPerWave; ++t) {
-        long long v = (long long)blk * kStemVoxPerBlock + (w * kStemTilesPerWave + t) * 32 + col;
-        bool ok = v < nvox;
-        long long vv = ok ? v : 0;
-        int z = (int)(vv % a.Zt);
-        long long r = vv / a.Zt;
-        int y = (int)(r % a.Yt), x = (int)(r / a.Yt);
-        const _Float16* p = reinterpret_cast<const _Float16*>(nb) + ((long long)x * py + y) * pz + z;
+    const int nloc = rows * a.Zt;                 // voxels of this workgroup
+    const int ntile = (nloc + 31) / 32;
+    for (int t = w; t < ntile; t += 4) {
+        const int i = t * 32 + col;
+        const bool ok = i < nloc;
+        const int ii = ok ? i : 0;
+        const int yl = ii / a.Zt, z = ii - yl * a.Zt;
+        const _Float16* p = ls + yl * pz + z;       // tap (0,0,0) in the staged planes
         half8 b0, b1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -133,6 +150,7 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
                     gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
                 }
             } else {
+                const long long v = ((long long)x * a.Yt + (y0 + yl)) * a.Zt + z;
                 __half* op = a.out + ((long long)b * nvox + v) * 32;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -343,8 +361,11 @@ __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
 extern "C" {
 
 int sk_conv3d_stem_num_blocks(int X, int Y, int Z) {
-    return (int)(((long long)X * Y * Z + kStemVoxPerBlock - 1) / kStemVoxPerBlock);
+    (void)Z;
+    return X * ((Y + kStemRows - 1) / kStemRows);
 }
+
+static size_t stem_lds_bytes(int Zt) { return (size_t)3 * (kStemRows + 2) * (Zt + 2) * sizeof(__half); }
 
 size_t sk_conv3d_stem_workspace_bytes(int B, int Xt, int Yt, int Zt) {
     return (size_t)B * (Xt + 2) * (Yt + 2) * (Zt + 2) * sizeof(__half);
@@ -397,7 +418,11 @@ int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origin
     long long np = (long long)(Xt + 2) * (Yt + 2) * (Zt + 2);
     dim3 g1(sk::cdiv(np, 256), B);
     stem_norm_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(a);
-    stem_kernel<true><<<(unsigned)(a.nblk * B), 256, 0, (hipStream_t)stream>>>(a);
+    SK_CHECK_ARG(Zt % 2 == 0 && stem_lds_bytes(Zt) <= 60 * 1024, "sk_conv3d_stem: tile depth %d unsupported", Zt);
+    if (stem_lds_bytes(Zt) > 40 * 1024)
+        SK_CHECK_HIP(hipFuncSetAttribute((const void*)stem_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)stem_lds_bytes(Zt)));
+    stem_kernel<true><<<(unsigned)(a.nblk * B), 256, stem_lds_bytes(Zt), (hipStream_t)stream>>>(a);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
@@ -417,7 +442,10 @@ int sk_conv3d_stem_apply(int B, int Xt, int Yt, int Zt, const float* weight, con
     a.norm = (__half*)workspace;
     a.out = (__half*)out;
     a.nblk = sk_conv3d_stem_num_blocks(Xt, Yt, Zt);
-    stem_kernel<false><<<(unsigned)(a.nblk * B), 256, 0, (hipStream_t)stream>>>(a);
+    if (stem_lds_bytes(Zt) > 40 * 1024)
+        SK_CHECK_HIP(hipFuncSetAttribute((const void*)stem_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)stem_lds_bytes(Zt)));
+    stem_kernel<false><<<(unsigned)(a.nblk * B), 256, stem_lds_bytes(Zt), (hipStream_t)stream>>>(a);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
