@@ -54,3 +54,36 @@ def test_eval_writes_reference_outputs(tmp_path):
     with pytest.raises(RuntimeError, match="legacy model file"):
         torch.save({"model_state_dict": ref.state_dict()}, cpath)
         sk_eval(ipath, cpath)
+
+
+def test_eval_used_cached_data(tmp_path):
+    """used_cached_data=True re-runs stages 2-3 from the arrays a previous call wrote (the reference's
+    os.exists bug at eval.py:105 made this path unreachable)."""
+    from oracle import unet_spec
+    from skoots_amd.lib.eval import eval as sk_eval
+    ref = unet_spec.build()
+    with torch.no_grad():
+        ref.heads.weight[3:5].mul_(0.05)
+        ref.heads.weight[0:3].mul_(1e-5)
+        ref.heads.bias[0:3] = 1e-5
+        ref.heads.bias[3] = 2.2
+        ref.heads.bias[4] = 3.0
+    Z, X, Y = 24, 132, 128
+    img = torch.randint(0, 256, (Z, X, Y), generator=torch.Generator().manual_seed(1), dtype=torch.uint8).numpy()
+    ipath, cpath = str(tmp_path / "v.npy"), str(tmp_path / "m.trch")
+    np.save(ipath, img)
+    cfg = {"SKOOTS": {"VECTOR_SCALING": (60, 60, 12)}, "MODEL": {"DIMS": [32, 64, 128, 64, 32], "DEPTHS": [2] * 5,
+                                                                 "IN_CHANNELS": 1}}
+    torch.save({"cfg": cfg, "model_state_dict": ref.state_dict()}, cpath)
+    sk_eval(ipath, cpath)
+    from PIL import Image
+    def read(p):
+        with Image.open(p) as im:
+            out = []
+            for i in range(im.n_frames):
+                im.seek(i)
+                out.append(np.array(im))
+        return np.stack(out)
+    first = read(str(tmp_path / "v_instance_mask.tif"))
+    sk_eval(ipath, cpath, used_cached_data=True)
+    assert np.array_equal(read(str(tmp_path / "v_instance_mask.tif")), first)

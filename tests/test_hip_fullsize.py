@@ -1,0 +1,61 @@
+"""BASELINE.json full-size checks (configs[2], 1024x1024x256) through size-independent properties:
+the oracle cannot finish this size in seconds, so the post-network stages are checked against the
+ANALYTIC answer of the lattice blob field (bench.py:device_blob_field): every blob whose skeleton
+core lies inside the written frame becomes exactly one instance, every gated voxel of such a blob
+carries that instance's id, ids are 1..K in first-appearance order, renumber is idempotent."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SHAPE = (1024, 1024, 256)
+
+
+def test_full_size_blob_field_known_answer():
+    import bench
+    from skoots_amd.lib import eval as E
+    from skoots_amd import _ffi
+    X, Y, Z = SHAPE
+    field, ncell = bench.device_blob_field(SHAPE, (0, Z), DEV)
+    assert ncell == 16 * 16 * 16
+
+    def inject(_, origin, eff):
+        x, y, z = origin
+        return field[:, x:x + eff[0], y:y + eff[1], z:z + eff[2]]
+
+    image = torch.zeros(SHAPE, dtype=torch.float16, device=DEV)
+    res = E.eval_volume(image, None, bench.SCALE, mean=0.0, std=1.0, inject=inject)
+    inst = res["instance_mask"]
+    k = res["n_instances"]
+    # analytic: 14 x 14 x 16 lattice cells keep their skeleton core inside the frame [50:974, 50:974, 5:251)
+    assert k == 14 * 14 * 16
+    assert int(inst.max()) == k
+    # ids are 1..K in order of first appearance (C order)
+    flat = inst.reshape(-1)
+    nz = torch.nonzero(flat).flatten()
+    vals = flat[nz]
+    first = torch.full((k + 1,), flat.numel(), dtype=torch.int64, device=DEV)
+    first.scatter_reduce_(0, vals.long(), nz, reduce="amin")
+    assert bool((first[1:-1] < first[2:]).all())
+    # every gated voxel (prob channel 0.95) of a cell maps to ONE id, and ids do not repeat across cells
+    gated = field[4] > 0.9
+    frame = torch.zeros(SHAPE, dtype=torch.bool, device=DEV)
+    frame[50:X - 50, 50:Y - 50, 5:Z - 5] = True
+    cell = ((torch.arange(X, device=DEV) // 64).view(-1, 1, 1) * 16 + (torch.arange(Y, device=DEV) // 64).view(1, -1, 1)) * 16 \
+        + (torch.arange(Z, device=DEV) // 16).view(1, 1, -1)
+    sel = gated & frame & (inst > 0)
+    c, i = cell[sel].long(), inst[sel].long()
+    lo = torch.full((ncell,), 2 ** 31, dtype=torch.int64, device=DEV).scatter_reduce_(0, c, i, reduce="amin")
+    hi = torch.zeros((ncell,), dtype=torch.int64, device=DEV).scatter_reduce_(0, c, i, reduce="amax")
+    live = hi > 0
+    assert int(live.sum()) == k and bool((lo[live] == hi[live]).all())
+    assert torch.unique(hi[live]).numel() == k
+    # gated voxels of the surviving cells inside the frame are all assigned
+    unassigned = gated & frame & (inst == 0)
+    assert not bool(live[cell[unassigned].long()].any())
+    # renumber is idempotent
+    st = res["state"]
+    before = st.instance.clone()
+    st.renumber()
+    assert torch.equal(st.instance, before)
