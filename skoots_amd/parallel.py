@@ -118,6 +118,10 @@ class Comm:
         if self.world == 1:
             return [t]
         src = self._out(t.contiguous())
+        if not self.staged:  # RCCL: one flat output buffer, no per-rank list copies
+            flat = torch.empty((self.world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+            dist.all_gather_into_tensor(flat, src)
+            return list(flat.unbind(0))
         outs = [torch.empty_like(src) for _ in range(self.world)]
         dist.all_gather(outs, src)
         return [o.to(t.device) for o in outs]
