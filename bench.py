@@ -121,6 +121,23 @@ def cpu_baseline(budget_s: float = 20.0):
                       f"renumber in full {t23:.1f} s"}
 
 
+def conv_hbm_traffic():
+    """HBM bytes per conv3 launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    in separate runs of the same launch shapes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).
+    bench.py cannot collect PMC counters itself; returns None when the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic_pmc.json")
+    try:
+        prof = json.load(open(path))
+    except OSError:
+        return None
+    tot, n = 0.0, 0
+    for k in prof["kernels"]:
+        if "conv3_kernel" in k["kernel"]:
+            tot += (k["fetch_MB_per_launch_x2_gfx950_correction"] + k["write_MB_per_launch"]) * k["launches"]
+            n += k["launches"]
+    return round(tot / n * 1024 * 1024) if n else None
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -224,7 +241,8 @@ def main():
                                     for k, v in sv.timings.items()}},
             "roofline": {"bound": "mfma", "kernel": "conv3_kernel<COUT,XS> (all 3x3x3 MFMA conv launches)",
                          "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(achieved / 2500.0, 4), "traffic": None,
+                         "frac": round(achieved / 2500.0, 4), "traffic": conv_hbm_traffic(),
+                         "traffic_unit": "bytes per launch (PMC, profiles/r01_conv_hbm_traffic_pmc.json)",
                          "launches": conv_launches, "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4)},
         }
         if not args.no_cpu_baseline and world == 1:
