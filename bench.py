@@ -171,7 +171,6 @@ def main():
             dist.init_process_group(backend)
 
     from skoots_amd import unet
-    from skoots_amd.lib import eval as E
     from skoots_amd.parallel import ShardedVolume
 
     shape = tuple(int(v) for v in args.shape.split(",")) if args.shape else workload_shape(world)

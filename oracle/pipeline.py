@@ -13,7 +13,7 @@ that float rounding (fp32 products, half-to-even ``round``) is bit-identical.
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, List, Sequence, Tuple
+from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 import torch

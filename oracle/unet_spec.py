@@ -32,7 +32,7 @@ tolerance for its outputs is 1e-3 absolute (BASELINE.json north_star).
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import Sequence
 
 import torch
 import torch.nn as nn

@@ -18,7 +18,7 @@ import ctypes as C
 import logging
 import os
 import time
-from typing import Callable, Dict, List, Optional, Sequence, Tuple
+from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
