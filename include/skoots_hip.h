@@ -247,6 +247,87 @@ int sk_conv3d_f32(const sk_conv_src* srcs, int n_src, const float* weight, const
 int sk_conv3d_f32_num_blocks(int ox, int oy, int oz);
 int sk_groupnorm_silu_f32(float* x, const float* affine, int B, int64_t voxels, int C, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * Training step (BASELINE.json configs[4]; skoots/train/engine.py:456-499): forward with saved
+ * tensors, fused Tversky losses, backward, AdamW.  fp32 on channels-last (B, x, y, z, C).
+ * The forward uses sk_conv3d_f32 + sk_groupnorm_finalize_stats + sk_train_gn_silu.
+ * ------------------------------------------------------------------------ */
+
+/* sk_groupnorm_finalize that also keeps stats (B, groups, 2) = (mean, rstd) for the backward. */
+int sk_groupnorm_finalize_stats(const float* gn_partial, int B, int nblocks, int groups, int C,
+                                int64_t voxels, const float* gamma, const float* beta, float eps,
+                                float* affine, float* stats, void* stream);
+
+/* z = silu(a*y + b), out of place (y, the raw conv output, is needed again by the backward). */
+int sk_train_gn_silu(const float* y, const float* affine, float* z, int B, int64_t voxels, int C,
+                     void* stream);
+
+/* Backward of GroupNorm(groups) + SiLU: dz -> dy (may alias dz), dgamma (C), dbeta (C).
+ * workspace: sk_train_gn_bwd_workspace_floats(B, voxels, C) floats. */
+int sk_train_gn_silu_bwd(const float* dz, const float* y, const float* affine, const float* stats,
+                         const float* gamma, int B, int64_t voxels, int C, int groups, float* dy,
+                         float* dgamma, float* dbeta, float* workspace, void* stream);
+int64_t sk_train_gn_bwd_workspace_floats(int B, int64_t voxels, int C);
+int sk_train_gn_bwd_num_blocks(int64_t voxels);
+
+/* Fused loss of the step (engine.py:465-493): logits (B, X*Y*Z, 5) = the head conv's raw output
+ * (tanh / sigmoid are applied inside); masks, skeleton_masks (B, X*Y*Z) fp32 (> 0 = foreground,
+ * engine.py:468-472); baked (B, 3, X*Y*Z) fp32.  Three Tversky terms (train/loss.py:157-209,
+ * per sample then batch mean) on: exp(-|E - baked|^2 / 2 sigma^2) with E = index + tanh(l)*scale
+ * (lib/embedding_to_prob.py:5-51, lib/vector_to_embedding.py:104-105), the probability map and the
+ * skeleton map.  loss_params_host (3, 4) = alpha, beta, eps, relative weight for (embed, prob,
+ * skeleton).  losses: DEVICE buffer of 16 floats; [0:4] = embed, prob, skeleton, weighted total.
+ * dlogits (B, X*Y*Z, 5) = d total / d logits, or NULL for the forward value only.
+ * workspace: sk_train_loss_workspace_floats(B, voxels) floats. */
+int sk_train_loss(const float* logits, const float* masks, const float* skeleton_masks,
+                  const float* baked, int B, int X, int Y, int Z, const float* vector_scale_host,
+                  const float* sigma_host, const float* loss_params_host, float* losses,
+                  float* dlogits, float* workspace, void* stream);
+int64_t sk_train_loss_workspace_floats(int B, int64_t voxels);
+int sk_train_loss_num_blocks(int64_t voxels);
+
+/* baked_embed_to_prob (lib/embedding_to_prob.py:5-51): embedding, baked (B, 3, voxels) fp32 ->
+ * out (B, voxels) = exp(sum_k (E_k - S_k)^2 / (-2 (sigma_k + eps)^2)). */
+int sk_baked_embed_to_prob(const float* embedding, const float* baked, float* out, int B,
+                           int64_t voxels, const float* sigma_host, float eps, void* stream);
+
+/* Stand-alone Tversky value (train/loss.py:95-212): predicted, ground_truth (B, voxels) fp32
+ * (ground_truth != 0 = foreground); loss = batch mean of 1 - (TP+eps)/(TP+alpha(FP+1e-10)+beta FN+eps).
+ * workspace: sk_train_loss_workspace_floats(B, voxels) floats. */
+int sk_train_tversky(const float* predicted, const float* ground_truth, int B, int64_t voxels,
+                     float alpha, float beta, float eps, float* loss, float* workspace,
+                     void* stream);
+
+/* Data gradient of a conv layer from dy (B, ox, oy, oz, cout) and the layer's own weight
+ * (cout, cin_total, k, k, k), read transposed / tap-flipped in place.
+ *   ksize 1, 3: dx (B, ox, oy, oz, cin_n) = gradient w.r.t. input channels [cin_lo, cin_lo+cin_n)
+ *               (one half of a concatenated input; an upsampled half is pooled afterwards with
+ *               sk_train_sumpool2).
+ *   ksize 2 (stride 2): dx (B, 2ox, 2oy, 2oz, cin_total); cin_lo = 0, cin_n = cin_total.
+ * accumulate != 0 adds into dx (a tensor with two consumers). */
+int sk_train_conv_dgrad(const float* dy, const float* weight, float* dx, int B, int ox, int oy,
+                        int oz, int cout, int cin_total, int cin_lo, int cin_n, int ksize,
+                        int accumulate, void* stream);
+
+/* Weight and bias gradient of a conv layer: srcs as in sk_conv3d_f32 (activated fp32 inputs, the
+ * second optionally nearest-upsampled), dy (B, ox, oy, oz, cout) -> dweight (cout, cin, k, k, k),
+ * dbias (cout) or NULL.  workspace: sk_train_conv_wgrad_workspace_floats(...) floats. */
+int sk_train_conv_wgrad(const sk_conv_src* srcs, int n_src, const float* dy, int B, int ox, int oy,
+                        int oz, int cout, int ksize, float* dweight, float* dbias,
+                        float* workspace, void* stream);
+int64_t sk_train_conv_wgrad_workspace_floats(int B, int ox, int oy, int oz, int cout, int cin,
+                                             int ksize);
+
+/* coarse (B, cx, cy, cz, C) = 2x2x2 block sums of fine (B, 2cx, 2cy, 2cz, C). */
+int sk_train_sumpool2(const float* fine, float* coarse, int B, int cx, int cy, int cz, int C,
+                      void* stream);
+
+/* One AdamW update (torch.optim.AdamW semantics; engine.py:281-285, config.py:96-101) over a
+ * flat parameter buffer; step counts from 1. */
+int sk_train_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,21 @@ _SIGS = {
     "sk_conv3d_f32": (i32, [C.POINTER(ConvSrc), i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "sk_conv3d_f32_num_blocks": (i32, [i32, i32, i32]),
     "sk_groupnorm_silu_f32": (i32, [vp, vp, i32, i64, i32, vp]),
+    "sk_groupnorm_finalize_stats": (i32, [vp, i32, i32, i32, i32, i64, vp, vp, C.c_float, vp, vp, vp]),
+    "sk_train_gn_silu": (i32, [vp, vp, vp, i32, i64, i32, vp]),
+    "sk_train_gn_silu_bwd": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
+    "sk_train_gn_bwd_workspace_floats": (i64, [i32, i64, i32]),
+    "sk_train_gn_bwd_num_blocks": (i32, [i64]),
+    "sk_train_loss": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, fp, fp, fp, vp, vp, vp, vp]),
+    "sk_baked_embed_to_prob": (i32, [vp, vp, vp, i32, i64, fp, C.c_float, vp]),
+    "sk_train_tversky": (i32, [vp, vp, i32, i64, C.c_float, C.c_float, C.c_float, vp, vp, vp]),
+    "sk_train_loss_workspace_floats": (i64, [i32, i64]),
+    "sk_train_loss_num_blocks": (i32, [i64]),
+    "sk_train_conv_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "sk_train_conv_wgrad": (i32, [C.POINTER(ConvSrc), i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "sk_train_conv_wgrad_workspace_floats": (i64, [i32, i32, i32, i32, i32, i32, i32]),
+    "sk_train_sumpool2": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "sk_train_adamw": (i32, [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]),
 }
 
 EXPORTS = tuple(_SIGS)

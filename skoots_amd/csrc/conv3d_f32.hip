@@ -30,6 +30,9 @@ struct ConvF32Args {
     float* partial;     // (B, nblk, cout/4, 2) or NULL
     int B, ox, oy, oz, cout, cin, ksize;
     int nblk;
+    // data-gradient mode (training): the conv is run with the layer's weight read transposed
+    // and tap-flipped in place, rows = original input channels [w_c_lo, w_c_lo + cout)
+    int transposed, w_cin_total, w_c_lo, accumulate;
 };
 
 // one wave = one 32-voxel column tile x one 32-cout row tile; block = 4 waves = 4 column tiles
@@ -58,7 +61,7 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(ConvF32Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int c = 32 * ct + 8 * q + 4 * h + j;
-            acc[4 * q + j] = c < a.cout ? a.bias[c] : 0.0f;
+            acc[4 * q + j] = (a.bias && c < a.cout) ? a.bias[c] : 0.0f;
         }
     const int k3 = k * k * k;
     int cbase = 0;
@@ -80,7 +83,10 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(ConvF32Args a) {
             for (int m = 0; m < (S.C + 1) / 2; ++m) {
                 const int ci = 2 * m + h;  // K index of this lane
                 const bool cok = ci < S.C;
-                float av = (cok && co < a.cout) ? a.w[((long long)co * a.cin + cbase + ci) * k3 + tap] : 0.0f;
+                const long long wi = a.transposed
+                                         ? ((long long)(cbase + ci) * a.w_cin_total + a.w_c_lo + co) * k3 + (k3 - 1 - tap)
+                                         : ((long long)co * a.cin + cbase + ci) * k3 + tap;
+                float av = (cok && co < a.cout) ? a.w[wi] : 0.0f;
                 float bv = (cok && inb && ok) ? ip[ci] : 0.0f;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
             }
@@ -97,6 +103,7 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(ConvF32Args a) {
                 int c = 32 * ct + 8 * q + 4 * h + j;
                 if (c < a.cout) {
                     float r = acc[4 * q + j];
+                    if (a.accumulate) r += op[c];
                     op[c] = r;
                     gs[q] += r;
                     gq[q] += r * r;
@@ -123,6 +130,61 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(ConvF32Args a) {
             const int nq = a.cout / 4;
             a.partial[(((long long)b * a.nblk + vb) * nq + 8 * ct) * 2 + tid] = tsum;
         }
+    }
+}
+
+// Data gradient of a k=2, stride-2 conv: dX[2c + p][ci] = sum_co W[co][ci][p] * dY[c][co].  The
+// weight tap depends on the parity p of the fine voxel, so a wave takes 32 fine voxels of ONE parity
+// class (blockIdx.y): column = coarse voxel, K = the layer's output channels.
+struct ConvT2Args {
+    const float* dy;   // (B, cx, cy, cz, K)
+    const float* w;    // (K, cin, 2, 2, 2)
+    float* dx;         // (B, 2cx, 2cy, 2cz, cin)
+    int B, cx, cy, cz, K, cin, nblk, accumulate;
+};
+
+__global__ void __launch_bounds__(256) conv_t2_f32_kernel(ConvT2Args a) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int nct = (a.cin + 31) / 32;
+    int blk = blockIdx.x;
+    const int ct = blk % nct;
+    blk /= nct;
+    const int b = blk / a.nblk, vb = blk % a.nblk;
+    const int p = blockIdx.y, px = p >> 2, py = (p >> 1) & 1, pz = p & 1;
+    const long long nvox = (long long)a.cx * a.cy * a.cz;
+    const long long v = ((long long)vb * 4 + w) * 32 + col;
+    const bool ok = v < nvox;
+    const long long vv = ok ? v : 0;
+    const int z = (int)(vv % a.cz);
+    const long long t = vv / a.cz;
+    const int y = (int)(t % a.cy), x = (int)(t / a.cy);
+    const int co = 32 * ct + col;  // A row: the layer's INPUT channel
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const float* ip = a.dy + ((long long)b * nvox + vv) * a.K;
+    for (int m = 0; m < (a.K + 1) / 2; ++m) {
+        const int k = 2 * m + h;
+        const bool kok = k < a.K;
+        float av = (kok && co < a.cin) ? a.w[((long long)k * a.cin + co) * 8 + p] : 0.0f;
+        float bv = (kok && ok) ? ip[k] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    if (ok) {
+        const long long fi = (((long long)b * 2 * a.cx + 2 * x + px) * 2 * a.cy + 2 * y + py) * 2 * a.cz + 2 * z + pz;
+        float* op = a.dx + fi * a.cin;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int c = 32 * ct + 8 * q + 4 * h + j;
+                if (c < a.cin) {
+                    float r = acc[4 * q + j];
+                    if (a.accumulate) r += op[c];
+                    op[c] = r;
+                }
+            }
     }
 }
 
@@ -182,6 +244,62 @@ int sk_conv3d_f32(const sk_conv_src* srcs, int n_src, const float* weight, const
     a.ksize = ksize;
     a.nblk = sk_conv3d_f32_num_blocks(ox, oy, oz);
     unsigned grid = (unsigned)(a.nblk * B * ((cout + 31) / 32));
+    conv_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_train_conv_dgrad(const float* dy, const float* weight, float* dx, int B, int ox, int oy, int oz,
+                        int cout, int cin_total, int cin_lo, int cin_n, int ksize, int accumulate, void* stream) {
+    SK_CHECK_ARG(dy && weight && dx, "sk_train_conv_dgrad: NULL pointer");
+    SK_CHECK_ARG(ksize == 1 || ksize == 2 || ksize == 3, "sk_train_conv_dgrad: ksize must be 1, 2 or 3");
+    SK_CHECK_ARG(cout >= 1 && cin_lo >= 0 && cin_n >= 1 && cin_lo + cin_n <= cin_total,
+                 "sk_train_conv_dgrad: bad channel range");
+    SK_CHECK_ARG(B >= 1 && ox >= 1 && oy >= 1 && oz >= 1, "sk_train_conv_dgrad: bad extents");
+    if (ksize == 2) {
+        SK_CHECK_ARG(cin_lo == 0 && cin_n == cin_total, "sk_train_conv_dgrad: ksize 2 takes the whole input");
+        ConvT2Args a{};
+        a.dy = dy;
+        a.w = weight;
+        a.dx = dx;
+        a.B = B;
+        a.cx = ox;
+        a.cy = oy;
+        a.cz = oz;
+        a.K = cout;
+        a.cin = cin_total;
+        a.nblk = sk_conv3d_f32_num_blocks(ox, oy, oz);
+        a.accumulate = accumulate ? 1 : 0;
+        dim3 grid((unsigned)(a.nblk * B * ((cin_total + 31) / 32)), 8);
+        conv_t2_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+        SK_CHECK_LAUNCH();
+        return SK_OK;
+    }
+    ConvF32Args a{};
+    a.nsrc = 1;
+    a.src[0].data = dy;
+    a.src[0].C = cout;
+    a.src[0].up = 0;
+    a.src[0].Xs = ox;
+    a.src[0].Ys = oy;
+    a.src[0].Zs = oz;
+    a.cin = cout;
+    a.w = weight;
+    a.bias = nullptr;
+    a.out = dx;
+    a.partial = nullptr;
+    a.B = B;
+    a.ox = ox;
+    a.oy = oy;
+    a.oz = oz;
+    a.cout = cin_n;
+    a.ksize = ksize;
+    a.nblk = sk_conv3d_f32_num_blocks(ox, oy, oz);
+    a.transposed = 1;
+    a.w_cin_total = cin_total;
+    a.w_c_lo = cin_lo;
+    a.accumulate = accumulate ? 1 : 0;
+    unsigned grid = (unsigned)(a.nblk * B * ((cin_n + 31) / 32));
     conv_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
     SK_CHECK_LAUNCH();
     return SK_OK;

@@ -1,0 +1,767 @@
+// Config-5 training step (BASELINE.json configs[4]; reference skoots/train/engine.py:456-499):
+// forward of the U-Net -> three Tversky losses (train/loss.py:157-209) on the probability map, the
+// skeleton map and the baked-skeleton embedding probability (lib/embedding_to_prob.py:5-51 over
+// lib/vector_to_embedding.py:79-105) -> backward -> AdamW.
+//
+// Everything here is fp32 on channels-last (B, voxels, C) tensors.  The forward reuses the fp32
+// layer kernels (conv3d_f32.hip); this file holds what only training needs:
+//   * out-of-place GroupNorm-affine + SiLU (the raw conv output is kept for the backward pass),
+//   * the GroupNorm + SiLU backward (one reduction pass, one apply pass),
+//   * the fused loss: one reduction pass over the logits for all three Tversky terms, one pass
+//     that writes d(loss)/d(logits),
+//   * the weight gradient of a conv as a voxel-reduction GEMM on v_mfma_f32_32x32x2_f32,
+//   * 2x2x2 sum pooling (backward of the nearest upsampling), AdamW.
+// All reductions are two-stage (per-block partials, then a fixed-order sum in double), so a step
+// is deterministic.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ inline float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm affine + SiLU, forward, out of place
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ affine,
+                                                          float* __restrict__ z, int C, long long n_per_batch) {
+    const int b = blockIdx.y;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    const float* p = y + (long long)b * n_per_batch;
+    float* q = z + (long long)b * n_per_batch;
+    for (; i < n_per_batch; i += stride) {
+        const int c = (int)(i % C);
+        float u = fmaf(affine[(long long)b * 2 * C + c], p[i], affine[(long long)b * 2 * C + C + c]);
+        q[i] = u / (1.0f + expf(-u));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm + SiLU backward.  z = silu(u), u = gamma*xh + beta, xh = (y - mean_g) * rstd_g.
+//   du = dz * silu'(u);  S1[b,c] = sum_v du,  S2[b,c] = sum_v du*xh
+//   dgamma = sum_b S2, dbeta = sum_b S1
+//   dy = rstd * (gamma*du - m1 - xh*m2),  m1 = sum_{c in g} gamma*S1 / n,  m2 = sum_{c in g} gamma*S2 / n
+// ------------------------------------------------------------------------------------------
+constexpr int kGnbVox = 2048;  // voxels per reduction block
+
+__device__ inline float silu_grad(float u) {
+    float s = sigmoid_(u);
+    return s * (1.0f + u * (1.0f - s));
+}
+
+__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                            const float* __restrict__ affine,
+                                                            const float* __restrict__ stats, int C, int groups,
+                                                            long long voxels, int nblk, float* __restrict__ partial) {
+    __shared__ float red[256 * 2];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int c = tid % C, row = tid / C, rows = 256 / C;
+    const int g = c / (C / groups);
+    const float a = affine[(long long)b * 2 * C + c], bb = affine[(long long)b * 2 * C + C + c];
+    const float mean = stats[((long long)b * groups + g) * 2], rstd = stats[((long long)b * groups + g) * 2 + 1];
+    const long long v0 = (long long)blockIdx.x * kGnbVox;
+    long long v1 = v0 + kGnbVox;
+    if (v1 > voxels) v1 = voxels;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (long long v = v0 + row; v < v1; v += rows) {
+        const long long i = ((long long)b * voxels + v) * C + c;
+        const float yv = y[i];
+        const float du = dz[i] * silu_grad(fmaf(a, yv, bb));
+        s1 += du;
+        s2 += du * ((yv - mean) * rstd);
+    }
+    red[tid * 2] = s1;
+    red[tid * 2 + 1] = s2;
+    __syncthreads();
+    if (tid < C) {
+        for (int r = 1; r < rows; ++r) {
+            s1 += red[(r * C + tid) * 2];
+            s2 += red[(r * C + tid) * 2 + 1];
+        }
+        float* o = partial + (((long long)b * nblk + blockIdx.x) * C + tid) * 2;
+        o[0] = s1;
+        o[1] = s2;
+    }
+}
+
+// one block; coef (B, C, 3) = rstd*gamma, rstd*m1, rstd*m2; dgamma/dbeta (C) overwritten
+__global__ void __launch_bounds__(1024) gn_bwd_finalize_kernel(const float* __restrict__ partial, int B, int nblk,
+                                                               int C, int groups, double voxels,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ stats,
+                                                               float* __restrict__ coef, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+    __shared__ double accv[1024];
+    __shared__ double sums[256];  // (C, 2)
+    __shared__ double gm[2 * 16];
+    const int tid = threadIdx.x;
+    const int nv = 2 * C;  // floats per partial row
+    const int val = tid % nv, sl = tid / nv, nsl = 1024 / nv;
+    double dg = 0.0, db = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double s = 0.0;
+        const float* base = partial + (long long)b * nblk * nv + val;
+        if (sl < nsl)
+            for (int k = sl; k < nblk; k += nsl) s += (double)base[(long long)k * nv];
+        accv[tid] = s;
+        __syncthreads();
+        if (tid < nv) {
+            double t = 0.0;
+            for (int k = 0; k < nsl; ++k) t += accv[k * nv + tid];
+            sums[tid] = t;
+        }
+        __syncthreads();
+        const int gs = C / groups;
+        if (tid < groups) {
+            double m1 = 0.0, m2 = 0.0;
+            for (int c = tid * gs; c < (tid + 1) * gs; ++c) {
+                m1 += (double)gamma[c] * sums[2 * c];
+                m2 += (double)gamma[c] * sums[2 * c + 1];
+            }
+            const double n = voxels * gs;
+            gm[2 * tid] = m1 / n;
+            gm[2 * tid + 1] = m2 / n;
+        }
+        __syncthreads();
+        if (tid < C) {
+            const int g = tid / gs;
+            const float rstd = stats[((long long)b * groups + g) * 2 + 1];
+            float* o = coef + ((long long)b * C + tid) * 3;
+            o[0] = rstd * gamma[tid];
+            o[1] = (float)((double)rstd * gm[2 * g]);
+            o[2] = (float)((double)rstd * gm[2 * g + 1]);
+            db += sums[2 * tid];
+            dg += sums[2 * tid + 1];
+        }
+        __syncthreads();
+    }
+    if (tid < C) {
+        dgamma[tid] = (float)dg;
+        dbeta[tid] = (float)db;
+    }
+}
+
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                           const float* __restrict__ affine,
+                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ coef, float* __restrict__ dy,
+                                                           int C, int groups, long long n_per_batch) {
+    const int b = blockIdx.y;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    const long long off = (long long)b * n_per_batch;
+    for (; i < n_per_batch; i += stride) {
+        const int c = (int)(i % C);
+        const int g = c / (C / groups);
+        const float a = affine[(long long)b * 2 * C + c], bb = affine[(long long)b * 2 * C + C + c];
+        const float mean = stats[((long long)b * groups + g) * 2], rstd = stats[((long long)b * groups + g) * 2 + 1];
+        const float* k = coef + ((long long)b * C + c) * 3;
+        const float yv = y[off + i];
+        const float du = dz[off + i] * silu_grad(fmaf(a, yv, bb));
+        dy[off + i] = k[0] * du - k[1] - ((yv - mean) * rstd) * k[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused loss.  logits (B, n, 5): [0:3] -> tanh = vectors, [3] -> sigmoid = skeleton, [4] -> sigmoid =
+// probability (engine.py:461-463).  E = index + v*scale (vector_to_embedding.py:104-105, N = 1),
+// pe = exp(sum_k (E_k - S_k)^2 / (-2 (sigma_k + 1e-16)^2))  (embedding_to_prob.py:38-49).
+// Per sample and per loss: TP = sum p*g, FPs = sum p*(1-g), FNs = sum (1-p)*g  (loss.py:189-193).
+// ------------------------------------------------------------------------------------------
+constexpr int kLossSums = 11;  // 3 losses x (TP, FPs, FNs) + foreground counts of the two targets
+
+struct LossArgs {
+    const float* logits;  // (B, n, 5)
+    const float* masks;   // (B, n)   instance ids (> 0 = foreground)
+    const float* skel;    // (B, n)   skeleton mask (> 0)
+    const float* baked;   // (B, 3, n)
+    long long n;
+    int Y, Z;
+    float scale[3];
+    float inv_var[3];     // 1 / (-2 (sigma+1e-16)^2)
+};
+
+__device__ inline float embed_prob(const LossArgs& a, int b, long long i, const float* l, float* e_minus_s,
+                                   float* v_out) {
+    const int z = (int)(i % a.Z);
+    const long long t = i / a.Z;
+    const int y = (int)(t % a.Y);
+    const int x = (int)(t / a.Y);
+    const float idx[3] = {(float)x, (float)y, (float)z};
+    float ssum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = tanhf(l[k]);
+        const float e = idx[k] + v * a.scale[k];
+        const float d = e - a.baked[((long long)b * 3 + k) * a.n + i];
+        v_out[k] = v;
+        e_minus_s[k] = d;
+        ssum += (d * d) * a.inv_var[k];
+    }
+    return expf(ssum);
+}
+
+__global__ void __launch_bounds__(256) loss_reduce_kernel(LossArgs a, int nblk, float* __restrict__ partial) {
+    __shared__ float red[4][kLossSums];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    float s[kLossSums];
+#pragma unroll
+    for (int k = 0; k < kLossSums; ++k) s[k] = 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < a.n; i += (long long)nblk * 256) {
+        const float* l = a.logits + ((long long)b * a.n + i) * 5;
+        float d[3], v[3];
+        const float pe = embed_prob(a, b, i, l, d, v);
+        const float ps = sigmoid_(l[3]), pp = sigmoid_(l[4]);
+        const float g = a.masks[(long long)b * a.n + i] > 0.0f ? 1.0f : 0.0f;
+        const float gs = a.skel[(long long)b * a.n + i] > 0.0f ? 1.0f : 0.0f;
+        s[0] += pe * g;
+        s[1] += pe * (1.0f - g);
+        s[2] += (1.0f - pe) * g;
+        s[3] += pp * g;
+        s[4] += pp * (1.0f - g);
+        s[5] += (1.0f - pp) * g;
+        s[6] += ps * gs;
+        s[7] += ps * (1.0f - gs);
+        s[8] += (1.0f - ps) * gs;
+        s[9] += g;
+        s[10] += gs;
+    }
+#pragma unroll
+    for (int k = 0; k < kLossSums; ++k) {
+        float t = s[k];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) t += __shfl_xor(t, m);
+        if ((tid & 63) == 0) red[tid >> 6][k] = t;
+    }
+    __syncthreads();
+    if (tid < kLossSums)
+        partial[((long long)b * nblk + blockIdx.x) * kLossSums + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// params (3, 4): alpha, beta, eps, relative weight per loss (embed, prob, skeleton).
+// losses (4): embed, prob, skeleton, weighted total (means over the batch, loss.py:155).
+// coef (B, 3, 2): d(total)/d(p_i) for a background (g=0) / foreground (g=1) voxel of each loss.
+__global__ void __launch_bounds__(256) loss_finalize_kernel(const float* __restrict__ partial, int B, int nblk,
+                                                            const float* __restrict__ params,
+                                                            float* __restrict__ losses, float* __restrict__ coef) {
+    __shared__ double sums[kLossSums];
+    __shared__ double acc[256];
+    __shared__ double lsum[3];
+    const int tid = threadIdx.x;
+    if (tid < 3) lsum[tid] = 0.0;
+    for (int b = 0; b < B; ++b) {
+        for (int k = 0; k < kLossSums; ++k) {
+            double s = 0.0;
+            for (int j = tid; j < nblk; j += 256) s += (double)partial[((long long)b * nblk + j) * kLossSums + k];
+            acc[tid] = s;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+                for (int j = 0; j < 256; ++j) t += acc[j];
+                sums[k] = t;
+            }
+            __syncthreads();
+        }
+        if (tid < 3) {
+            const double alpha = params[tid * 4], beta = params[tid * 4 + 1], eps = params[tid * 4 + 2];
+            const double wgt = (double)params[tid * 4 + 3] / B;
+            const double fg = sums[tid == 2 ? 10 : 9];
+            double TP = sums[3 * tid], FPs = sums[3 * tid + 1], FNs = sums[3 * tid + 2];
+            double c0 = 0.0, c1 = 0.0, loss;
+            if (fg > 0.0) {
+                const double N = TP + eps;
+                const double D = TP + alpha * (FPs + 1e-10) + beta * FNs + eps;
+                loss = 1.0 - N / D;
+                c0 = wgt * (N * alpha) / (D * D);              // d/dp of a background voxel
+                c1 = -wgt * (D - N * (1.0 - beta)) / (D * D);  // d/dp of a foreground voxel
+            } else {
+                // no instance in the sample: the reference's expanded mask stack is empty, every sum is 0
+                loss = 1.0 - eps / (alpha * 1e-10 + eps);
+            }
+            lsum[tid] += loss;
+            coef[((long long)b * 3 + tid) * 2] = (float)c0;
+            coef[((long long)b * 3 + tid) * 2 + 1] = (float)c1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const double l = lsum[k] / B;
+            losses[k] = (float)l;
+            tot += (double)params[k * 4 + 3] * l;
+        }
+        losses[3] = (float)tot;
+    }
+}
+
+// stand-alone baked_embed_to_prob (lib/embedding_to_prob.py:5-51): planar (B, 3, n) inputs -> (B, n)
+__global__ void __launch_bounds__(256) embed_prob_kernel(const float* __restrict__ emb, const float* __restrict__ baked,
+                                                         float* __restrict__ out, long long n, float iv0, float iv1,
+                                                         float iv2) {
+    const int b = blockIdx.y;
+    const float iv[3] = {iv0, iv1, iv2};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float d = emb[((long long)b * 3 + k) * n + i] - baked[((long long)b * 3 + k) * n + i];
+            s += (d * d) * iv[k];
+        }
+        out[(long long)b * n + i] = expf(s);
+    }
+}
+
+// stand-alone Tversky value (train/loss.py:95-212) of a probability tensor: partial (B, nblk, 4)
+__global__ void __launch_bounds__(256) tversky_reduce_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                             long long n, int nblk, float* __restrict__ partial) {
+    __shared__ float red[4][4];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < n; i += (long long)nblk * 256) {
+        const float p = pred[(long long)b * n + i];
+        const float g = gt[(long long)b * n + i] != 0.0f ? 1.0f : 0.0f;
+        s[0] += p * g;
+        s[1] += p * (1.0f - g);
+        s[2] += (1.0f - p) * g;
+        s[3] += g;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float t = s[k];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) t += __shfl_xor(t, m);
+        if ((tid & 63) == 0) red[tid >> 6][k] = t;
+    }
+    __syncthreads();
+    if (tid < 4) partial[((long long)b * nblk + blockIdx.x) * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+__global__ void __launch_bounds__(256) tversky_finalize_kernel(const float* __restrict__ partial, int B, int nblk,
+                                                               double alpha, double beta, double eps,
+                                                               float* __restrict__ loss) {
+    __shared__ double acc[256];
+    __shared__ double sums[4];
+    const int tid = threadIdx.x;
+    double total = 0.0;
+    for (int b = 0; b < B; ++b) {
+        for (int k = 0; k < 4; ++k) {
+            double s = 0.0;
+            for (int j = tid; j < nblk; j += 256) s += (double)partial[((long long)b * nblk + j) * 4 + k];
+            acc[tid] = s;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+                for (int j = 0; j < 256; ++j) t += acc[j];
+                sums[k] = t;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            if (sums[3] > 0.0)
+                total += 1.0 - (sums[0] + eps) / (sums[0] + alpha * (sums[1] + 1e-10) + beta * sums[2] + eps);
+            else
+                total += 1.0 - eps / (alpha * 1e-10 + eps);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) loss[0] = (float)(total / B);
+}
+
+__global__ void __launch_bounds__(256) loss_bwd_kernel(LossArgs a, const float* __restrict__ coef,
+                                                       float* __restrict__ dlogits) {
+    const int b = blockIdx.y;
+    const float* cf = coef + (long long)b * 6;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+        const float* l = a.logits + ((long long)b * a.n + i) * 5;
+        float* o = dlogits + ((long long)b * a.n + i) * 5;
+        float d[3], v[3];
+        const float pe = embed_prob(a, b, i, l, d, v);
+        const float ps = sigmoid_(l[3]), pp = sigmoid_(l[4]);
+        const int g = a.masks[(long long)b * a.n + i] > 0.0f ? 1 : 0;
+        const int gs = a.skel[(long long)b * a.n + i] > 0.0f ? 1 : 0;
+        const float dpe = cf[0 + g];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)  // d pe/d E_k = pe * 2 (E_k - S_k) * inv_var_k
+            o[k] = dpe * pe * (2.0f * d[k] * a.inv_var[k]) * a.scale[k] * (1.0f - v[k] * v[k]);
+        o[3] = cf[4 + gs] * ps * (1.0f - ps);
+        o[4] = cf[2 + g] * pp * (1.0f - pp);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient: dW[co][ci][tap] = sum_{b,v} dY[b,v][co] * X[b, in(v, tap)][ci]
+// One wave = one 32x32 (cout, cin) tile x one group of taps x one chunk of (b, voxel) pairs,
+// reduced on v_mfma_f32_32x32x2_f32 with K = 2 voxels per instruction.
+// ------------------------------------------------------------------------------------------
+struct WgSrc {
+    const float* data;  // (B, xs, ys, zs, C) activated input
+    int C, up, Xs, Ys, Zs;
+};
+
+struct WgradArgs {
+    WgSrc src[2];
+    int nsrc;
+    const float* dy;  // (B, ox, oy, oz, cout)
+    float* part;      // (nchunk, cout, cin, k3)
+    float* part_bias; // (nchunk, cout)
+    int B, ox, oy, oz, cout, cin, ksize;
+    int nchunk, ncot, ncit, ngroup;
+    long long chunk;  // (b, voxel) pairs per chunk, even
+};
+
+template <int NT>  // taps per wave: 9 (k=3, one dx), 8 (k=2), 1 (k=1)
+__global__ void __launch_bounds__(64) wgrad_kernel(WgradArgs a) {
+    const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
+    int blk = blockIdx.x;
+    const int grp = blk % a.ngroup;
+    blk /= a.ngroup;
+    const int cit = blk % a.ncit;
+    blk /= a.ncit;
+    const int cot = blk % a.ncot;
+    const int chunk = blk / a.ncot;
+    const int k = a.ksize, k3 = k * k * k;
+    const int stride = (k == 3) ? 1 : k, padw = (k == 3) ? 1 : 0;
+
+    // the cin tile lies inside one source (host checks C % 32 == 0 when there are two)
+    int ci0 = 32 * cit, sidx = 0, cbase = 0;
+    if (a.nsrc == 2 && ci0 >= a.src[0].C) {
+        sidx = 1;
+        cbase = a.src[0].C;
+    }
+    const WgSrc S = a.src[sidx];
+    const int ci = ci0 - cbase + col;  // channel inside the source
+    const bool ciok = ci < S.C;
+    const int co = 32 * cot + col;
+    const bool cook = co < a.cout;
+    const int Xf = S.up ? S.Xs * 2 : S.Xs, Yf = S.up ? S.Ys * 2 : S.Ys, Zf = S.up ? S.Zs * 2 : S.Zs;
+    const long long nvox = (long long)a.ox * a.oy * a.oz, total = nvox * a.B;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float bsum = 0.0f;
+
+    const long long p0 = (long long)chunk * a.chunk;
+    long long p1 = p0 + a.chunk;
+    if (p1 > total) p1 = total;
+    for (long long p = p0 + h; p < p1 + h; p += 2) {   // both halves run the same trip count
+        const bool ok = p < p1;
+        const long long pp = ok ? p : p0;
+        const int b = (int)(pp / nvox);
+        const long long v = pp % nvox;
+        const int z = (int)(v % a.oz);
+        const long long t2 = v / a.oz;
+        const int y = (int)(t2 % a.oy), x = (int)(t2 / a.oy);
+        const float av = (ok && cook) ? a.dy[pp * a.cout + co] : 0.0f;
+        bsum += av;
+        const float* sb = S.data + (long long)b * S.Xs * S.Ys * S.Zs * S.C;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int tap = grp * NT + t;
+            const int dx = tap / (k * k), dy = (tap / k) % k, dz = tap % k;
+            int xi = x * stride + dx - padw, yi = y * stride + dy - padw, zi = z * stride + dz - padw;
+            const bool inb = xi >= 0 && xi < Xf && yi >= 0 && yi < Yf && zi >= 0 && zi < Zf;
+            if (S.up) {
+                xi >>= 1;
+                yi >>= 1;
+                zi >>= 1;
+            }
+            float bv = 0.0f;
+            if (ok && inb && ciok) bv = sb[(((long long)xi * S.Ys + yi) * S.Zs + zi) * S.C + ci];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        }
+    }
+    // D[row = cout][col = cin]; this lane holds rows (r&3) + 8*(r>>2) + 4*h of column `col`
+    float* part = a.part + (long long)chunk * a.cout * a.cin * k3;
+    const int cig = ci0 + col;  // channel in the concatenated input
+    if (ciok) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int tap = grp * NT + t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * cot + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < a.cout) part[((long long)row * a.cin + cig) * k3 + tap] = acc[t][r];
+            }
+        }
+    }
+    if (a.part_bias && cit == 0 && grp == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (h == 0 && cook) a.part_bias[(long long)chunk * a.cout + co] = bsum;
+    }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int nchunk, long long n,
+                                                           float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c) s += (double)part[(long long)c * n + i];
+    out[i] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------
+// 2x2x2 sum pooling: backward of the nearest x2 upsampling folded into the decoder convs
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sumpool2_kernel(const float* __restrict__ fine, float* __restrict__ coarse,
+                                                       int B, int cx, int cy, int cz, int C) {
+    const long long n = (long long)B * cx * cy * cz * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int z = (int)(t % cz);
+        t /= cz;
+        const int y = (int)(t % cy);
+        t /= cy;
+        const int x = (int)(t % cx);
+        const int b = (int)(t / cx);
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const long long fi = (((long long)b * 2 * cx + 2 * x + (d >> 2)) * 2 * cy + 2 * y + ((d >> 1) & 1)) * 2 * cz +
+                                 2 * z + (d & 1);
+            s += fine[fi * C + c];
+        }
+        coarse[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// AdamW (torch.optim.AdamW semantics: decoupled decay, bias-corrected moments)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long long n,
+                                                    float lr, float beta1, float beta2, float eps, float wd,
+                                                    float bc1, float bc2_sqrt) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i];
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+int fill_loss_args(LossArgs& a, const float* logits, const float* masks, const float* skel, const float* baked,
+                   int X, int Y, int Z, const float* scale_host, const float* sigma_host) {
+    a.logits = logits;
+    a.masks = masks;
+    a.skel = skel;
+    a.baked = baked;
+    a.n = (long long)X * Y * Z;
+    a.Y = Y;
+    a.Z = Z;
+    for (int k = 0; k < 3; ++k) {
+        a.scale[k] = scale_host[k];
+        const float s = sigma_host[k] + 1e-16f;  // embedding_to_prob.py:38-39, fp32 arithmetic
+        a.inv_var[k] = 1.0f / (s * s * 2.0f * -1.0f);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sk_train_gn_silu(const float* y, const float* affine, float* z, int B, int64_t voxels, int C, void* stream) {
+    SK_CHECK_ARG(y && affine && z && C > 0, "sk_train_gn_silu: bad arguments");
+    long long n = voxels * C;
+    dim3 grid(sk::stream_grid(n, 256, 4), B);
+    gn_silu_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(y, affine, z, C, n);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_train_gn_bwd_num_blocks(int64_t voxels) { return (int)((voxels + kGnbVox - 1) / kGnbVox); }
+
+int sk_train_gn_silu_bwd(const float* dz, const float* y, const float* affine, const float* stats,
+                         const float* gamma, int B, int64_t voxels, int C, int groups, float* dy, float* dgamma,
+                         float* dbeta, float* workspace, void* stream) {
+    SK_CHECK_ARG(dz && y && affine && stats && gamma && dy && dgamma && dbeta && workspace,
+                 "sk_train_gn_silu_bwd: NULL pointer");
+    SK_CHECK_ARG((C == 32 || C == 64 || C == 128) && groups > 0 && groups <= 16 && C % groups == 0,
+                 "sk_train_gn_silu_bwd: C=%d groups=%d unsupported", C, groups);
+    const int nblk = sk_train_gn_bwd_num_blocks(voxels);
+    float* partial = workspace;                              // (B, nblk, C, 2)
+    float* coef = workspace + (long long)B * nblk * C * 2;   // (B, C, 3)
+    gn_bwd_reduce_kernel<<<dim3(nblk, B), 256, 0, (hipStream_t)stream>>>(dz, y, affine, stats, C, groups, voxels, nblk,
+                                                                         partial);
+    SK_CHECK_LAUNCH();
+    gn_bwd_finalize_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(partial, B, nblk, C, groups, (double)voxels, gamma,
+                                                                stats, coef, dgamma, dbeta);
+    SK_CHECK_LAUNCH();
+    long long n = voxels * C;
+    gn_bwd_apply_kernel<<<dim3(sk::stream_grid(n, 256, 4), B), 256, 0, (hipStream_t)stream>>>(dz, y, affine, stats, coef,
+                                                                                               dy, C, groups, n);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int64_t sk_train_gn_bwd_workspace_floats(int B, int64_t voxels, int C) {
+    return (int64_t)B * sk_train_gn_bwd_num_blocks(voxels) * C * 2 + (int64_t)B * C * 3;
+}
+
+int sk_train_loss_num_blocks(int64_t voxels) {
+    int64_t g = (voxels + 256 * 16 - 1) / (256 * 16);
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+int64_t sk_train_loss_workspace_floats(int B, int64_t voxels) {
+    return (int64_t)B * sk_train_loss_num_blocks(voxels) * kLossSums + (int64_t)B * 6;
+}
+
+int sk_train_loss(const float* logits, const float* masks, const float* skeleton_masks, const float* baked, int B,
+                  int X, int Y, int Z, const float* vector_scale_host, const float* sigma_host,
+                  const float* loss_params_host, float* losses, float* dlogits, float* workspace, void* stream) {
+    SK_CHECK_ARG(logits && masks && skeleton_masks && baked && losses && workspace, "sk_train_loss: NULL pointer");
+    SK_CHECK_ARG(vector_scale_host && sigma_host && loss_params_host, "sk_train_loss: NULL host parameter");
+    SK_CHECK_ARG(B >= 1 && X >= 1 && Y >= 1 && Z >= 1, "sk_train_loss: bad extents");
+    LossArgs a{};
+    fill_loss_args(a, logits, masks, skeleton_masks, baked, X, Y, Z, vector_scale_host, sigma_host);
+    const int nblk = sk_train_loss_num_blocks(a.n);
+    float* partial = workspace;
+    float* coef = workspace + (long long)B * nblk * kLossSums;
+    hipStream_t st = (hipStream_t)stream;
+    // the 12 loss parameters travel through a small device buffer at the tail of `losses` (4 + 12 floats)
+    SK_CHECK_HIP(hipMemcpyAsync(losses + 4, loss_params_host, 12 * sizeof(float), hipMemcpyHostToDevice, st));
+    loss_reduce_kernel<<<dim3(nblk, B), 256, 0, st>>>(a, nblk, partial);
+    SK_CHECK_LAUNCH();
+    loss_finalize_kernel<<<1, 256, 0, st>>>(partial, B, nblk, losses + 4, losses, coef);
+    SK_CHECK_LAUNCH();
+    if (dlogits) {
+        loss_bwd_kernel<<<dim3(sk::stream_grid(a.n, 256, 2), B), 256, 0, st>>>(a, coef, dlogits);
+        SK_CHECK_LAUNCH();
+    }
+    return SK_OK;
+}
+
+int sk_baked_embed_to_prob(const float* embedding, const float* baked, float* out, int B, int64_t voxels,
+                           const float* sigma_host, float eps, void* stream) {
+    SK_CHECK_ARG(embedding && baked && out && sigma_host && B >= 1 && voxels >= 1, "sk_baked_embed_to_prob: bad arguments");
+    float iv[3];
+    for (int k = 0; k < 3; ++k) {
+        const float sg = sigma_host[k] + eps;
+        iv[k] = 1.0f / (sg * sg * 2.0f * -1.0f);
+    }
+    embed_prob_kernel<<<dim3(sk::stream_grid(voxels, 256, 2), B), 256, 0, (hipStream_t)stream>>>(embedding, baked, out, voxels,
+                                                                                                  iv[0], iv[1], iv[2]);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_train_tversky(const float* predicted, const float* ground_truth, int B, int64_t voxels, float alpha, float beta,
+                     float eps, float* loss, float* workspace, void* stream) {
+    SK_CHECK_ARG(predicted && ground_truth && loss && workspace && B >= 1 && voxels >= 1, "sk_train_tversky: bad arguments");
+    const int nblk = sk_train_loss_num_blocks(voxels);
+    tversky_reduce_kernel<<<dim3(nblk, B), 256, 0, (hipStream_t)stream>>>(predicted, ground_truth, voxels, nblk, workspace);
+    SK_CHECK_LAUNCH();
+    tversky_finalize_kernel<<<1, 256, 0, (hipStream_t)stream>>>(workspace, B, nblk, alpha, beta, eps, loss);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+static int wgrad_plan(int B, int ox, int oy, int oz, int cout, int cin, int ksize, int* nchunk, long long* chunk,
+                      int* ngroup) {
+    const int ncot = (cout + 31) / 32, ncit = (cin + 31) / 32;
+    *ngroup = ksize == 3 ? 3 : 1;
+    const long long total = (long long)B * ox * oy * oz;
+    long long want = 4096 / ((long long)ncot * ncit * *ngroup);
+    if (want < 1) want = 1;
+    long long c = (total + want - 1) / want;
+    if (c < 512) c = 512;
+    c = (c + 1) & ~1LL;
+    *chunk = c;
+    *nchunk = (int)((total + c - 1) / c);
+    return 0;
+}
+
+int64_t sk_train_conv_wgrad_workspace_floats(int B, int ox, int oy, int oz, int cout, int cin, int ksize) {
+    int nchunk, ngroup;
+    long long chunk;
+    wgrad_plan(B, ox, oy, oz, cout, cin, ksize, &nchunk, &chunk, &ngroup);
+    return (int64_t)nchunk * ((int64_t)cout * cin * ksize * ksize * ksize + cout);
+}
+
+int sk_train_conv_wgrad(const sk_conv_src* srcs, int n_src, const float* dy, int B, int ox, int oy, int oz, int cout,
+                        int ksize, float* dweight, float* dbias, float* workspace, void* stream) {
+    SK_CHECK_ARG(srcs && dy && dweight && workspace, "sk_train_conv_wgrad: NULL pointer");
+    SK_CHECK_ARG(n_src == 1 || n_src == 2, "sk_train_conv_wgrad: n_src must be 1 or 2");
+    SK_CHECK_ARG(ksize == 1 || ksize == 2 || ksize == 3, "sk_train_conv_wgrad: ksize must be 1, 2 or 3");
+    SK_CHECK_ARG(B >= 1 && ox >= 1 && oy >= 1 && oz >= 1 && cout >= 1, "sk_train_conv_wgrad: bad extents");
+    WgradArgs a{};
+    a.nsrc = n_src;
+    for (int i = 0; i < n_src; ++i) {
+        SK_CHECK_ARG(srcs[i].data && srcs[i].c > 0 && srcs[i].affine == nullptr, "sk_train_conv_wgrad: bad source %d", i);
+        SK_CHECK_ARG(n_src == 1 || srcs[i].c % 32 == 0, "sk_train_conv_wgrad: two sources need c %% 32 == 0");
+        int up = srcs[i].upsample ? 1 : 0;
+        SK_CHECK_ARG(!up || (ksize == 3 && ox % 2 == 0 && oy % 2 == 0 && oz % 2 == 0),
+                     "sk_train_conv_wgrad: upsampled source needs ksize 3 and even output extents");
+        a.src[i].data = (const float*)srcs[i].data;
+        a.src[i].C = srcs[i].c;
+        a.src[i].up = up;
+        int s = (ksize == 3) ? 1 : ksize;
+        a.src[i].Xs = up ? ox / 2 : ox * s;
+        a.src[i].Ys = up ? oy / 2 : oy * s;
+        a.src[i].Zs = up ? oz / 2 : oz * s;
+        a.cin += srcs[i].c;
+    }
+    a.dy = dy;
+    a.B = B;
+    a.ox = ox;
+    a.oy = oy;
+    a.oz = oz;
+    a.cout = cout;
+    a.ksize = ksize;
+    a.ncot = (cout + 31) / 32;
+    a.ncit = (a.cin + 31) / 32;
+    wgrad_plan(B, ox, oy, oz, cout, a.cin, ksize, &a.nchunk, &a.chunk, &a.ngroup);
+    const long long nw = (long long)cout * a.cin * ksize * ksize * ksize;
+    a.part = workspace;
+    a.part_bias = dbias ? workspace + (long long)a.nchunk * nw : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((long long)a.nchunk * a.ncot * a.ncit * a.ngroup);
+    if (ksize == 3)
+        wgrad_kernel<9><<<grid, 64, 0, st>>>(a);
+    else if (ksize == 2)
+        wgrad_kernel<8><<<grid, 64, 0, st>>>(a);
+    else
+        wgrad_kernel<1><<<grid, 64, 0, st>>>(a);
+    SK_CHECK_LAUNCH();
+    wgrad_reduce_kernel<<<sk::cdiv(nw, 256), 256, 0, st>>>(a.part, a.nchunk, nw, dweight);
+    SK_CHECK_LAUNCH();
+    if (dbias) {
+        wgrad_reduce_kernel<<<sk::cdiv(cout, 256), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias);
+        SK_CHECK_LAUNCH();
+    }
+    return SK_OK;
+}
+
+int sk_train_sumpool2(const float* fine, float* coarse, int B, int cx, int cy, int cz, int C, void* stream) {
+    SK_CHECK_ARG(fine && coarse && B >= 1 && cx >= 1 && cy >= 1 && cz >= 1 && C >= 1, "sk_train_sumpool2: bad arguments");
+    long long n = (long long)B * cx * cy * cz * C;
+    sumpool2_kernel<<<sk::stream_grid(n, 256, 2), 256, 0, (hipStream_t)stream>>>(fine, coarse, B, cx, cy, cz, C);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_train_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+    SK_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "sk_train_adamw: bad arguments");
+    if (n == 0) return SK_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    adamw_kernel<<<sk::stream_grid(n, 256, 2), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                                                                             beta2, eps, weight_decay, (float)bc1,
+                                                                             (float)sqrt(bc2));
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+}  // extern "C"

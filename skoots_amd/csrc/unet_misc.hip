@@ -195,7 +195,8 @@ __global__ void __launch_bounds__(kFinThreads) gn_finalize_kernel(const float* _
                                                                   int groups, int C, double count,
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float eps,
-                                                                  float* __restrict__ affine) {
+                                                                  float* __restrict__ affine,
+                                                                  float* __restrict__ stats) {
     __shared__ double qv[64];            // per channel quad: (sum, sumsq) interleaved, C/4 <= 32
     __shared__ double accv[kFinThreads];
     const int b = blockIdx.x;
@@ -232,6 +233,10 @@ __global__ void __launch_bounds__(kFinThreads) gn_finalize_kernel(const float* _
         float ga = gamma[tid] * rstd;
         affine[((long long)b * 2) * C + tid] = ga;
         affine[((long long)b * 2 + 1) * C + tid] = beta[tid] - (float)mean * ga;
+        if (stats && tid % gs == 0) {   // (B, groups, 2): mean, rstd -- kept for the backward pass
+            stats[((long long)b * groups + g) * 2] = (float)mean;
+            stats[((long long)b * groups + g) * 2 + 1] = rstd;
+        }
     }
 }
 
@@ -450,17 +455,29 @@ int sk_conv3d_stem_apply(int B, int Xt, int Yt, int Zt, const float* weight, con
     return SK_OK;
 }
 
-int sk_groupnorm_finalize(const float* gn_partial, int B, int nblocks, int groups, int C,
+static int groupnorm_finalize_impl(const float* gn_partial, int B, int nblocks, int groups, int C,
                           int64_t voxels, const float* gamma, const float* beta, float eps,
-                          float* affine, void* stream) {
+                          float* affine, float* stats, void* stream) {
     SK_CHECK_ARG(gn_partial && gamma && beta && affine, "sk_groupnorm_finalize: NULL pointer");
     SK_CHECK_ARG(C % 4 == 0 && C <= 128 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0,
                  "sk_groupnorm_finalize: C=%d groups=%d unsupported", C, groups);
     SK_CHECK_ARG(kFinThreads % (C / 2) == 0, "sk_groupnorm_finalize: C/2 must divide %d", kFinThreads);
     gn_finalize_kernel<<<B, kFinThreads, 0, (hipStream_t)stream>>>(gn_partial, nblocks, groups, C, (double)voxels,
-                                                            gamma, beta, eps, affine);
+                                                            gamma, beta, eps, affine, stats);
     SK_CHECK_LAUNCH();
     return SK_OK;
+}
+
+int sk_groupnorm_finalize(const float* gn_partial, int B, int nblocks, int groups, int C, int64_t voxels,
+                          const float* gamma, const float* beta, float eps, float* affine, void* stream) {
+    return groupnorm_finalize_impl(gn_partial, B, nblocks, groups, C, voxels, gamma, beta, eps, affine, nullptr, stream);
+}
+
+int sk_groupnorm_finalize_stats(const float* gn_partial, int B, int nblocks, int groups, int C, int64_t voxels,
+                                const float* gamma, const float* beta, float eps, float* affine, float* stats,
+                                void* stream) {
+    SK_CHECK_ARG(stats, "sk_groupnorm_finalize_stats: NULL stats");
+    return groupnorm_finalize_impl(gn_partial, B, nblocks, groups, C, voxels, gamma, beta, eps, affine, stats, stream);
 }
 
 int sk_groupnorm_silu(void* x, const float* affine, int B, int64_t voxels, int C, void* stream) {

@@ -1,0 +1,313 @@
+"""One training step of the U-Net on the HIP kernels (BASELINE.json configs[4]).
+
+Reference: the inner step of skoots/train/engine.py:456-499 --
+
+    out = model(images)                                   # (B, 5, X, Y, Z)
+    embedding = vector_to_embedding(vector_scale, out[:, 0:3])
+    emb_prob  = baked_embed_to_prob(embedding, baked, sigma(e))
+    loss = w_e * tversky_e(emb_prob, masks > 0) + w_p * tversky_p(out[:, [-1]], masks > 0)
+         + w_s * tversky_s(out[:, [-2]], skele_masks > 0)
+    loss.backward(); optimizer.step()                     # AdamW, config.py:96-101
+
+Here the same step runs as explicit kernels of libskoots_hip.so (no autograd): the forward
+keeps each block's raw conv output, GroupNorm affine and statistics; the loss and its gradient
+come from one fused kernel pair; the backward walks the recorded layer list in reverse (GN+SiLU
+backward, weight gradient, data gradient); AdamW updates one flat parameter buffer.  All fp32
+(the reference runs bf16 with channels_last_3d, engine.py:68,107-109; fp32 is the higher
+precision).  The network graph is oracle/unet_spec.py's; data loading, augmentation, schedulers
+and logging of the reference's loop are out of scope.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from .. import _ffi
+from ..unet import GN_EPS, GN_GROUPS
+
+
+class _Layer:
+    """Views of one conv (+ GroupNorm) layer's parameters and gradients in the flat buffers."""
+
+    def __init__(self, name: str, ksize: int, norm: bool):
+        self.name, self.ksize, self.norm = name, ksize, norm
+        self.weight = self.bias = self.gamma = self.beta = None
+        self.g_weight = self.g_bias = self.g_gamma = self.g_beta = None
+        self.cin = self.cout = 0
+
+
+class TrainUNet:
+    """The U-Net of oracle/unet_spec.py with fp32 master parameters on the GPU.
+
+    ``forward(images)`` -> logits (B, X, Y, Z, 5) (pre-tanh / pre-sigmoid head outputs) and records
+    what the backward needs; ``backward(dlogits)`` fills ``flat_grad``."""
+
+    def __init__(self, state_dict: Dict[str, Tensor], device="cuda:0",
+                 dims: Sequence[int] = (32, 64, 128, 64, 32), depths: Sequence[int] = (2, 2, 2, 2, 2)):
+        self.device = torch.device(device)
+        self.dims, self.depths = tuple(dims), tuple(depths)
+
+        def stack(name, n):
+            return [_Layer(f"{name}.{i}", 3, True) for i in range(n)]
+
+        self.enc0 = stack("enc0", depths[0])
+        self.down0 = _Layer("down0", 2, True)
+        self.enc1 = stack("enc1", depths[1])
+        self.down1 = _Layer("down1", 2, True)
+        self.mid = stack("mid", depths[2])
+        self.red1 = _Layer("red1", 1, True)
+        self.dec1 = stack("dec1", depths[3])
+        self.red0 = _Layer("red0", 1, True)
+        self.dec0 = stack("dec0", depths[4])
+        self.heads = _Layer("heads", 1, False)
+        self.layers: List[_Layer] = (self.enc0 + [self.down0] + self.enc1 + [self.down1] + self.mid + [self.red1] +
+                                     self.dec1 + [self.red0] + self.dec0 + [self.heads])
+        # flat parameter / gradient buffers, state_dict key order of the module
+        self.param_names: List[str] = []
+        shapes = []
+        for l in self.layers:
+            keys = ([f"{l.name}.conv.weight", f"{l.name}.conv.bias", f"{l.name}.norm.weight", f"{l.name}.norm.bias"]
+                    if l.norm else [f"{l.name}.weight", f"{l.name}.bias"])
+            for k in keys:
+                if k not in state_dict:
+                    raise KeyError(f"state_dict lacks {k}")
+                self.param_names.append(k)
+                shapes.append(tuple(state_dict[k].shape))
+        total = sum(math.prod(s) for s in shapes)
+        self.flat_param = torch.empty(total, dtype=torch.float32, device=self.device)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self._views: Dict[str, Tuple[Tensor, Tensor]] = {}
+        off = 0
+        for k, s in zip(self.param_names, shapes):
+            n = math.prod(s)
+            p = self.flat_param[off:off + n].view(s)
+            p.copy_(state_dict[k].detach().float())
+            self._views[k] = (p, self.flat_grad[off:off + n].view(s))
+            off += n
+        for l in self.layers:
+            if l.norm:
+                (l.weight, l.g_weight), (l.bias, l.g_bias) = self._views[f"{l.name}.conv.weight"], self._views[f"{l.name}.conv.bias"]
+                (l.gamma, l.g_gamma), (l.beta, l.g_beta) = self._views[f"{l.name}.norm.weight"], self._views[f"{l.name}.norm.bias"]
+            else:
+                (l.weight, l.g_weight), (l.bias, l.g_bias) = self._views[f"{l.name}.weight"], self._views[f"{l.name}.bias"]
+            l.cout, l.cin = int(l.weight.shape[0]), int(l.weight.shape[1])
+            if tuple(l.weight.shape[2:]) != (l.ksize,) * 3:
+                raise ValueError(f"{l.name}: weight shape {tuple(l.weight.shape)} does not fit ksize {l.ksize}")
+        self._tape: List[tuple] = []
+        self._ws: Optional[Tensor] = None
+
+    # ------------------------------------------------------------------------------
+    def state_dict(self) -> Dict[str, Tensor]:
+        """Parameters under the module's key names (what a checkpoint's ``model_state_dict`` holds)."""
+        return {k: self._views[k][0].detach().clone() for k in self.param_names}
+
+    def grads(self) -> Dict[str, Tensor]:
+        return {k: self._views[k][1] for k in self.param_names}
+
+    def _workspace(self, floats: int) -> Tensor:
+        if self._ws is None or self._ws.numel() < floats:
+            self._ws = torch.empty(int(floats), dtype=torch.float32, device=self.device)
+        return self._ws
+
+    @staticmethod
+    def _srcs(srcs) -> "C.Array":
+        arr = (_ffi.ConvSrc * len(srcs))()
+        for i, (t, up) in enumerate(srcs):
+            arr[i].data = t.data_ptr()
+            arr[i].affine = None
+            arr[i].c = t.shape[-1]
+            arr[i].upsample = up
+        return arr
+
+    # ------------------------------------------------------------------------------
+    def _block(self, layer: _Layer, srcs: List[Tuple[Tensor, int]], out_shape: Tuple[int, int, int]) -> Tensor:
+        B = srcs[0][0].shape[0]
+        ox, oy, oz = out_shape
+        st = _ffi.stream_ptr(self.device)
+        y = torch.empty((B, ox, oy, oz, layer.cout), dtype=torch.float32, device=self.device)
+        if not layer.norm:
+            _ffi.check(_ffi.lib.sk_conv3d_f32(self._srcs(srcs), len(srcs), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
+                                              _ffi.ptr(y), B, ox, oy, oz, layer.cout, layer.ksize, None, st))
+            self._tape.append((layer, srcs, y, None, None, y))
+            return y
+        nblk = _ffi.lib.sk_conv3d_f32_num_blocks(ox, oy, oz)
+        partial = torch.empty((B, nblk, layer.cout // 4, 2), dtype=torch.float32, device=self.device)
+        _ffi.check(_ffi.lib.sk_conv3d_f32(self._srcs(srcs), len(srcs), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
+                                          _ffi.ptr(y), B, ox, oy, oz, layer.cout, layer.ksize, _ffi.ptr(partial), st))
+        vox = ox * oy * oz
+        affine = torch.empty((B, 2, layer.cout), dtype=torch.float32, device=self.device)
+        stats = torch.empty((B, GN_GROUPS, 2), dtype=torch.float32, device=self.device)
+        _ffi.check(_ffi.lib.sk_groupnorm_finalize_stats(_ffi.ptr(partial), B, nblk, GN_GROUPS, layer.cout, vox,
+                                                        _ffi.ptr(layer.gamma), _ffi.ptr(layer.beta), GN_EPS,
+                                                        _ffi.ptr(affine), _ffi.ptr(stats), st))
+        z = torch.empty_like(y)
+        _ffi.check(_ffi.lib.sk_train_gn_silu(_ffi.ptr(y), _ffi.ptr(affine), _ffi.ptr(z), B, vox, layer.cout, st))
+        self._tape.append((layer, srcs, y, affine, stats, z))
+        return z
+
+    def forward(self, images: Tensor) -> Tensor:
+        """images: (B, 1, X, Y, Z) or (B, X, Y, Z), already normalised (the reference's loader does
+        it); extents multiples of 4.  Returns the head logits (B, X, Y, Z, 5)."""
+        if images.ndim == 5:
+            if images.shape[1] != 1:
+                raise ValueError("images must have one channel")
+            images = images[:, 0]
+        x = images.to(self.device, torch.float32).contiguous().unsqueeze(-1)
+        _ffi.require_gpu(x, "images")
+        _, X, Y, Z, _ = x.shape
+        if X % 4 or Y % 4 or Z % 4:
+            raise ValueError("crop extents must be multiples of 4 (two stride-2 levels)")
+        L0, L1, L2 = (X, Y, Z), (X // 2, Y // 2, Z // 2), (X // 4, Y // 4, Z // 4)
+        self._tape = []
+        self._image = x
+        a = x
+        for l in self.enc0:
+            a = self._block(l, [(a, 0)], L0)
+        s0 = a
+        a = self._block(self.down0, [(s0, 0)], L1)
+        for l in self.enc1:
+            a = self._block(l, [(a, 0)], L1)
+        s1 = a
+        a = self._block(self.down1, [(s1, 0)], L2)
+        for l in self.mid:
+            a = self._block(l, [(a, 0)], L2)
+        r1 = self._block(self.red1, [(a, 0)], L2)
+        for i, l in enumerate(self.dec1):
+            a = self._block(l, [(s1, 0), (r1, 1)] if i == 0 else [(a, 0)], L1)
+        r0 = self._block(self.red0, [(a, 0)], L1)
+        for i, l in enumerate(self.dec0):
+            a = self._block(l, [(s0, 0), (r0, 1)] if i == 0 else [(a, 0)], L0)
+        return self._block(self.heads, [(a, 0)], L0)
+
+    def backward(self, dlogits: Tensor) -> None:
+        """Walk the recorded layers in reverse; gradients of every parameter land in ``flat_grad``."""
+        if not self._tape:
+            raise RuntimeError("backward() needs a preceding forward()")
+        st = _ffi.stream_ptr(self.device)
+        grads: Dict[int, Tensor] = {self._tape[-1][5].data_ptr(): dlogits}
+        for layer, srcs, y, affine, stats, out in reversed(self._tape):
+            dz = grads.pop(out.data_ptr())
+            B, ox, oy, oz, cout = y.shape
+            vox = ox * oy * oz
+            if layer.norm:
+                ws = self._workspace(_ffi.lib.sk_train_gn_bwd_workspace_floats(B, vox, cout))
+                _ffi.check(_ffi.lib.sk_train_gn_silu_bwd(_ffi.ptr(dz), _ffi.ptr(y), _ffi.ptr(affine), _ffi.ptr(stats),
+                                                         _ffi.ptr(layer.gamma), B, vox, cout, GN_GROUPS, _ffi.ptr(dz),
+                                                         _ffi.ptr(layer.g_gamma), _ffi.ptr(layer.g_beta), _ffi.ptr(ws), st))
+            dy = dz
+            ws = self._workspace(_ffi.lib.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, cout, layer.cin, layer.ksize))
+            _ffi.check(_ffi.lib.sk_train_conv_wgrad(self._srcs(srcs), len(srcs), _ffi.ptr(dy), B, ox, oy, oz, cout,
+                                                    layer.ksize, _ffi.ptr(layer.g_weight), _ffi.ptr(layer.g_bias),
+                                                    _ffi.ptr(ws), st))
+            lo = 0
+            for t, up in srcs:
+                c = t.shape[-1]
+                if t.data_ptr() == self._image.data_ptr():
+                    lo += c
+                    continue  # no gradient w.r.t. the input image
+                key = t.data_ptr()
+                if layer.ksize == 2:
+                    have = key in grads
+                    if not have:
+                        grads[key] = torch.empty_like(t)
+                    _ffi.check(_ffi.lib.sk_train_conv_dgrad(_ffi.ptr(dy), _ffi.ptr(layer.weight), _ffi.ptr(grads[key]), B,
+                                                            ox, oy, oz, cout, layer.cin, 0, layer.cin, 2, int(have), st))
+                elif up:
+                    fine = torch.empty((B, ox, oy, oz, c), dtype=torch.float32, device=self.device)
+                    _ffi.check(_ffi.lib.sk_train_conv_dgrad(_ffi.ptr(dy), _ffi.ptr(layer.weight), _ffi.ptr(fine), B, ox, oy,
+                                                            oz, cout, layer.cin, lo, c, layer.ksize, 0, st))
+                    if key in grads:
+                        raise RuntimeError("an upsampled tensor has one consumer in this graph")
+                    grads[key] = torch.empty_like(t)
+                    _ffi.check(_ffi.lib.sk_train_sumpool2(_ffi.ptr(fine), _ffi.ptr(grads[key]), B, ox // 2, oy // 2,
+                                                          oz // 2, c, st))
+                else:
+                    have = key in grads
+                    if not have:
+                        grads[key] = torch.empty_like(t)
+                    _ffi.check(_ffi.lib.sk_train_conv_dgrad(_ffi.ptr(dy), _ffi.ptr(layer.weight), _ffi.ptr(grads[key]), B,
+                                                            ox, oy, oz, cout, layer.cin, lo, c, layer.ksize, int(have), st))
+                lo += c
+        self._tape = []
+
+
+def fused_loss(logits: Tensor, masks: Tensor, skele_masks: Tensor, baked: Tensor, sigma: Sequence[float],
+               vector_scale: Sequence[float] = (60, 60, 12),
+               loss_params=((0.25, 0.75, 1e-8), (0.5, 0.5, 1e-8), (0.5, 1.5, 1e-8)),
+               weights: Sequence[float] = (1.0, 1.0, 1.0), need_grad: bool = True):
+    """The three Tversky terms of the step (engine.py:465-493) and d(total)/d(logits) in two passes over
+    the logits.  logits (B, X, Y, Z, 5) = head outputs before tanh / sigmoid; masks, skele_masks
+    (B, 1, X, Y, Z) (> 0 = foreground); baked (B, 3, X, Y, Z); ``loss_params`` = (alpha, beta, eps) of the
+    embedding, probability and skeleton term.  Returns (losses[4] = embed, prob, skeleton, total; dlogits)."""
+    _ffi.require_gpu(logits, "logits")
+    B, X, Y, Z, five = logits.shape
+    if five != 5 or logits.dtype != torch.float32:
+        raise ValueError("logits must be fp32 (B, X, Y, Z, 5)")
+    n = X * Y * Z
+    dev = logits.device
+    m = masks.reshape(B, n).to(dev, torch.float32).contiguous()
+    sk = skele_masks.reshape(B, n).to(dev, torch.float32).contiguous()
+    bk = baked.reshape(B, 3, n).to(dev, torch.float32).contiguous()
+    params: List[float] = []
+    for (a, b, e), wt in zip(loss_params, weights):
+        params += [float(a), float(b), float(e), float(wt)]
+    losses = torch.empty(16, dtype=torch.float32, device=dev)
+    dl = torch.empty_like(logits) if need_grad else None
+    ws = torch.empty(int(_ffi.lib.sk_train_loss_workspace_floats(B, n)), dtype=torch.float32, device=dev)
+    _ffi.check(_ffi.lib.sk_train_loss(_ffi.ptr(logits), _ffi.ptr(m), _ffi.ptr(sk), _ffi.ptr(bk), B, X, Y, Z,
+                                      _ffi.float_array([float(v) for v in vector_scale]),
+                                      _ffi.float_array([float(s) for s in sigma]), _ffi.float_array(params),
+                                      _ffi.ptr(losses), _ffi.ptr(dl), _ffi.ptr(ws), _ffi.stream_ptr(dev)))
+    return losses[:4], dl
+
+
+class TrainStep:
+    """Optimizer + loss configuration around a :class:`TrainUNet` (engine.py:272-341 of the reference).
+
+    Defaults are the reference's (skoots/config.py:49-64,87,96-101,144): AdamW lr 5e-4, weight decay
+    1e-6, betas (0.9, 0.999), eps 1e-8; Tversky (alpha, beta, eps) = embed (0.25, 0.75, 1e-8), probability
+    (0.5, 0.5, 1e-8), skeleton (0.5, 1.5, 1e-8); relative weights 1; vector scaling (60, 60, 12)."""
+
+    def __init__(self, model: TrainUNet, lr: float = 5e-4, weight_decay: float = 1e-6, betas=(0.9, 0.999),
+                 eps: float = 1e-8, vector_scale=(60, 60, 12),
+                 loss_embed=(0.25, 0.75, 1e-8), loss_prob=(0.5, 0.5, 1e-8), loss_skele=(0.5, 1.5, 1e-8),
+                 weights=(1.0, 1.0, 1.0)):
+        self.model = model
+        self.lr, self.weight_decay, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
+        self.vector_scale = [float(v) for v in vector_scale]
+        self.loss_params = [list(map(float, loss_embed)), list(map(float, loss_prob)), list(map(float, loss_skele))]
+        self.weights = [float(w) for w in weights]
+        self.exp_avg = torch.zeros_like(model.flat_param)
+        self.exp_avg_sq = torch.zeros_like(model.flat_param)
+        self.step_count = 0
+
+    def fused_loss(self, logits: Tensor, masks: Tensor, skele_masks: Tensor, baked: Tensor, sigma: Sequence[float],
+                   weights: Optional[Sequence[float]] = None, need_grad: bool = True):
+        return fused_loss(logits, masks, skele_masks, baked, sigma, self.vector_scale, self.loss_params,
+                          self.weights if weights is None else weights, need_grad)
+
+    def optimizer_step(self) -> None:
+        self.step_count += 1
+        p = self.model.flat_param
+        _ffi.check(_ffi.lib.sk_train_adamw(_ffi.ptr(p), _ffi.ptr(self.model.flat_grad), _ffi.ptr(self.exp_avg),
+                                           _ffi.ptr(self.exp_avg_sq), p.numel(), self.lr, self.betas[0], self.betas[1],
+                                           self.eps, self.weight_decay, self.step_count, _ffi.stream_ptr(p.device)))
+
+    def __call__(self, images: Tensor, masks: Tensor, skele_masks: Tensor, baked: Tensor,
+                 sigma: Sequence[float] = (20.0, 20.0, 20.0), weights: Optional[Sequence[float]] = None) -> Tensor:
+        """One step (engine.py:456-499).  Returns a device tensor (embed, prob, skeleton, total)."""
+        logits = self.model.forward(images)
+        losses, dl = self.fused_loss(logits, masks, skele_masks, baked, sigma, weights)
+        self.model.backward(dl)
+        self.optimizer_step()
+        return losses
+
+
+def train_step(step: TrainStep, images: Tensor, masks: Tensor, skele_masks: Tensor, baked: Tensor,
+               sigma: Sequence[float] = (20.0, 20.0, 20.0)) -> Tensor:
+    """Functional spelling of ``TrainStep.__call__``."""
+    return step(images, masks, skele_masks, baked, sigma)

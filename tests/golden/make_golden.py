@@ -20,6 +20,7 @@ Fixtures are data only (inputs + outputs of reference calls), stored as .npz.
   G5 flood.npz           efficient_flood_fill()                           flood_fill.py:13-261
   G6 postmodel.npz       eval.py:145-284 composed from reference functions on an injected field
   G7 kat.npz             the two __main__ known answers
+  G8 loss.npz            config-5 loss terms and their input gradient (tversky + baked_embed_to_prob)
 """
 import os
 import sys
@@ -315,6 +316,37 @@ def g7():
          cc0=np.array(cc[0]), cc1=np.array(cc[1]))
 
 
+# ----------------------------------------------------------------------------- G8 (config 5: loss)
+def g8():
+    """Training-loss pieces of the config-5 step (train/engine.py:461-496): values and input
+    gradients of the reference's tversky (train/loss.py:95-212) and baked_embed_to_prob
+    (lib/embedding_to_prob.py:5-51) composed exactly as the engine composes them."""
+    from skoots.lib.embedding_to_prob import baked_embed_to_prob
+    from skoots.train.loss import tversky
+    gen = torch.Generator().manual_seed(88)
+    B, X, Y, Z = 2, 12, 10, 8
+    out = torch.rand((B, 5, X, Y, Z), generator=gen)
+    out[:, 0:3] = out[:, 0:3] * 2 - 1
+    out = out.detach().requires_grad_(True)
+    masks = (torch.rand((B, 1, X, Y, Z), generator=gen) > 0.6).float() * torch.randint(1, 5, (B, 1, X, Y, Z), generator=gen)
+    skele = (torch.rand((B, 1, X, Y, Z), generator=gen) > 0.85).float()
+    baked = torch.rand((B, 3, X, Y, Z), generator=gen) * torch.tensor([X, Y, Z]).view(1, 3, 1, 1, 1)
+    scale = torch.tensor((60, 60, 12))
+    sigma = torch.tensor([20.0, 20.0, 20.0])
+    l_embed, l_prob, l_skel = tversky(0.25, 0.75, 1e-8), tversky(0.5, 0.5, 1e-8), tversky(0.5, 1.5, 1e-8)
+    prob, vec, sk = out[:, [-1]], out[:, 0:3], out[:, [-2]]
+    emb = vector_to_embedding(scale, vec)
+    pe = baked_embed_to_prob(emb, baked, sigma)
+    le = l_embed(pe, masks.gt(0).float())
+    lp = l_prob(prob, masks.gt(0).float())
+    ls = l_skel(sk, skele.gt(0).float())
+    loss = 1.0 * le + 1.0 * lp + 1.0 * ls
+    loss.backward()
+    save("loss.npz", out=out.detach().numpy(), masks=masks.numpy(), skele=skele.numpy(), baked=baked.numpy(),
+         scale=scale.numpy(), sigma=sigma.numpy(), embed_prob=pe.detach().numpy(),
+         losses=np.array([le.item(), lp.item(), ls.item(), loss.item()]), grad=out.grad.numpy())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    g1(); g2_g3(); g4(); g5(); g6(); g7()
+    g1(); g2_g3(); g4(); g5(); g6(); g7(); g8()
