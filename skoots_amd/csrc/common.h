@@ -49,4 +49,25 @@ static inline unsigned stream_grid(int64_t n, int block, int per_thread = 1) {
     return (unsigned)g;
 }
 
+#ifdef __HIPCC__
+// Buffer loads: the hardware bounds check returns 0 for an offset past the descriptor's byte count, so a
+// masked lane passes kOob instead of branching around the load (a branch per load lets the compiler chain
+// load -> wait -> use, one memory latency at a time).  The descriptor must be wave-uniform.
+constexpr unsigned kOob = 0xFFFFFFF0u;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    // readfirstlane makes the uniformity provable: otherwise every load becomes a waterfall loop
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* q = (void*)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ inline float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ inline f32x4_t buf_load_f32x4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+#endif
+
 }  // namespace sk

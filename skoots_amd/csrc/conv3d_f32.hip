@@ -133,6 +133,159 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(ConvF32Args a) {
     }
 }
 
+// Same contraction for sources whose channel counts are multiples of 32 (every layer but the stem and
+// the head's data gradient): the weight tile of a (source, 32-channel chunk, dx) stage -- 9 taps x 32 ci
+// x 32 cout -- is staged in LDS for the block's 8 column tiles, and a lane reads its activations as
+// float4 (K is permuted: lane half h owns channels 8j+4h..8j+4h+3 of the chunk).
+constexpr int kWRow = 40;  // LDS row stride (floats): rows 4 apart land on the other 32 banks
+
+__global__ void __launch_bounds__(256) conv_f32_lds_kernel(ConvF32Args a) {
+    __shared__ float wl[9 * 32 * kWRow];
+    __shared__ float red[8 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int nct = (a.cout + 31) / 32;
+    int blk = blockIdx.x;
+    const int ct = blk % nct;
+    blk /= nct;
+    const int nb2 = (a.nblk + 1) / 2;  // blocks of 256 voxels
+    const int b = blk / nb2, vb = blk % nb2;
+    const long long nvox = (long long)a.ox * a.oy * a.oz;
+    const int k = a.ksize, k3 = k * k * k, stride = (k == 3) ? 1 : k, padw = (k == 3) ? 1 : 0;
+    const int ntg = (k == 3) ? 3 : 1, tpg = k3 / ntg;  // tap groups x taps per group (9 | 8 | 1)
+
+    int vx[2], vy[2], vz[2];
+    bool ok[2];
+    long long vidx[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const long long v = ((long long)vb * 8 + 4 * t + w) * 32 + col;
+        ok[t] = v < nvox;
+        vidx[t] = v;
+        const long long vv = ok[t] ? v : 0;
+        vz[t] = (int)(vv % a.oz);
+        const long long q = vv / a.oz;
+        vy[t] = (int)(q % a.oy);
+        vx[t] = (int)(q / a.oy);
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = 32 * ct + 8 * q + 4 * h + j;
+            float bv = (a.bias && c < a.cout) ? a.bias[c] : 0.0f;
+            acc[0][4 * q + j] = bv;
+            acc[1][4 * q + j] = bv;
+        }
+    int cbase = 0;
+    for (int s = 0; s < a.nsrc; ++s) {
+        const SrcF32 S = a.src[s];
+        const long long svox = (long long)S.Xs * S.Ys * S.Zs;
+        // block-uniform descriptor of this batch item's source (host checks < 4 GiB): masked lanes pass an
+        // out-of-range offset and read 0, so no load sits behind a branch
+        const __amdgpu_buffer_rsrc_t rs = sk::make_rsrc(S.data + (long long)b * svox * S.C, (unsigned)(svox * S.C * 4));
+        const int Xf = S.up ? S.Xs * 2 : S.Xs, Yf = S.up ? S.Ys * 2 : S.Ys, Zf = S.up ? S.Zs * 2 : S.Zs;
+        for (int ch = 0; ch < S.C; ch += 32) {
+            for (int tg = 0; tg < ntg; ++tg) {
+                __syncthreads();
+                // stage: wl[tap][ci][co], co contiguous
+                for (int e = tid; e < tpg * 32 * 32; e += 256) {
+                    const int tl = e % tpg, ci = (e / tpg) % 32, co = e / (tpg * 32);
+                    const int tap = tg * tpg + tl;
+                    const int cog = 32 * ct + co;
+                    float val = 0.0f;
+                    if (cog < a.cout) {
+                        const long long wi = a.transposed
+                                                 ? ((long long)(cbase + ch + ci) * a.w_cin_total + a.w_c_lo + cog) * k3 + (k3 - 1 - tap)
+                                                 : ((long long)cog * a.cin + cbase + ch + ci) * k3 + tap;
+                        val = a.w[wi];
+                    }
+                    wl[(tl * 32 + ci) * kWRow + co] = val;
+                }
+                __syncthreads();
+                for (int tl = 0; tl < tpg; ++tl) {
+                    const int tap = tg * tpg + tl;
+                    const int dx = tap / (k * k), dy = (tap / k) % k, dz = tap % k;
+                    const float* wrow = wl + (tl * 32 + 4 * h) * kWRow + col;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        int xi = vx[t] * stride + dx - padw, yi = vy[t] * stride + dy - padw, zi = vz[t] * stride + dz - padw;
+                        const bool inb = ok[t] && xi >= 0 && xi < Xf && yi >= 0 && yi < Yf && zi >= 0 && zi < Zf;
+                        if (S.up) {
+                            xi >>= 1;
+                            yi >>= 1;
+                            zi >>= 1;
+                        }
+                        const unsigned off = inb ? ((unsigned)((xi * S.Ys + yi) * S.Zs + zi) * (unsigned)S.C + (unsigned)(ch + 4 * h)) * 4u
+                                                 : sk::kOob;
+                        f32x4 bq[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bq[j] = sk::buf_load_f32x4(rs, inb ? off + 32u * j : sk::kOob);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 bv = bq[j];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[(8 * j + u) * kWRow], bv[u], acc[t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        cbase += S.C;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float gs[4] = {0, 0, 0, 0}, gq[4] = {0, 0, 0, 0};
+        if (ok[t]) {
+            float* op = a.out + ((long long)b * nvox + vidx[t]) * a.cout;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int c = 32 * ct + 8 * q + 4 * h + j;
+                    if (c < a.cout) {
+                        float r = acc[t][4 * q + j];
+                        if (a.accumulate) r += op[c];
+                        op[c] = r;
+                        gs[q] += r;
+                        gq[q] += r * r;
+                    }
+                }
+        }
+        if (a.partial) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float s = gs[q], ss = gq[q];
+#pragma unroll
+                for (int m = 16; m > 0; m >>= 1) {
+                    s += __shfl_xor(s, m);
+                    ss += __shfl_xor(ss, m);
+                }
+                if (col == 0) {
+                    red[((t * 4 + w) * 8 + 2 * q + h) * 2] = s;
+                    red[((t * 4 + w) * 8 + 2 * q + h) * 2 + 1] = ss;
+                }
+            }
+        }
+    }
+    if (a.partial) {
+        __syncthreads();
+        // two 128-voxel rows per block, the layout sk_conv3d_f32_num_blocks promises
+        if (tid < 32) {
+            const int t = tid >> 4, e = tid & 15;
+            const int row = 2 * vb + t;
+            if (row < a.nblk && 8 * ct * 4 + (e >> 1) * 4 < a.cout) {
+                const float* r0 = red + t * 64;
+                float tsum = r0[e] + r0[16 + e] + r0[32 + e] + r0[48 + e];
+                const int nq = a.cout / 4;
+                a.partial[(((long long)b * a.nblk + row) * nq + 8 * ct) * 2 + e] = tsum;
+            }
+        }
+    }
+}
+
 // Data gradient of a k=2, stride-2 conv: dX[2c + p][ci] = sum_co W[co][ci][p] * dY[c][co].  The
 // weight tap depends on the parity p of the fine voxel, so a wave takes 32 fine voxels of ONE parity
 // class (blockIdx.y): column = coarse voxel, K = the layer's output channels.
@@ -203,6 +356,24 @@ __global__ void __launch_bounds__(256) gn_silu_f32_kernel(float* __restrict__ x,
 
 }  // namespace
 
+// every source a multiple of 32 channels -> LDS-staged kernel, else the plain gather kernel
+static int launch_conv_f32(const ConvF32Args& a, hipStream_t st) {
+    bool lds = true;
+    for (int i = 0; i < a.nsrc; ++i) lds = lds && (a.src[i].C % 32 == 0);
+    for (int i = 0; i < a.nsrc && lds; ++i)
+        SK_CHECK_ARG((long long)a.src[i].Xs * a.src[i].Ys * a.src[i].Zs * a.src[i].C * 4 < (1LL << 32),
+                     "fp32 conv: source %d of one batch item must be < 4 GiB", i);
+    const int nct = (a.cout + 31) / 32;
+    if (lds) {
+        unsigned grid = (unsigned)(((a.nblk + 1) / 2) * a.B * nct);
+        conv_f32_lds_kernel<<<grid, 256, 0, st>>>(a);
+    } else {
+        unsigned grid = (unsigned)(a.nblk * a.B * nct);
+        conv_f32_kernel<<<grid, 256, 0, st>>>(a);
+    }
+    return SK_OK;
+}
+
 extern "C" {
 
 int sk_conv3d_f32_num_blocks(int ox, int oy, int oz) {
@@ -243,8 +414,7 @@ int sk_conv3d_f32(const sk_conv_src* srcs, int n_src, const float* weight, const
     a.cout = cout;
     a.ksize = ksize;
     a.nblk = sk_conv3d_f32_num_blocks(ox, oy, oz);
-    unsigned grid = (unsigned)(a.nblk * B * ((cout + 31) / 32));
-    conv_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    if (int rc = launch_conv_f32(a, (hipStream_t)stream)) return rc;
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
@@ -299,8 +469,7 @@ int sk_train_conv_dgrad(const float* dy, const float* weight, float* dx, int B, 
     a.w_cin_total = cin_total;
     a.w_c_lo = cin_lo;
     a.accumulate = accumulate ? 1 : 0;
-    unsigned grid = (unsigned)(a.nblk * B * ((cin_n + 31) / 32));
-    conv_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    if (int rc = launch_conv_f32(a, (hipStream_t)stream)) return rc;
     SK_CHECK_LAUNCH();
     return SK_OK;
 }

@@ -408,8 +408,8 @@ struct WgradArgs {
     float* part;      // (nchunk, cout, cin, k3)
     float* part_bias; // (nchunk, cout)
     int B, ox, oy, oz, cout, cin, ksize;
-    int nchunk, ncot, ncit, ngroup;
-    long long chunk;  // (b, voxel) pairs per chunk, even
+    int nchunk, nchunk_b, ncot, ncit, ngroup;
+    long long chunk;  // voxels per chunk (even); nchunk = B * nchunk_b
 };
 
 template <int NT>  // taps per wave: 9 (k=3, one dx), 8 (k=2), 1 (k=1)
@@ -421,7 +421,8 @@ __global__ void __launch_bounds__(64) wgrad_kernel(WgradArgs a) {
     const int cit = blk % a.ncit;
     blk /= a.ncit;
     const int cot = blk % a.ncot;
-    const int chunk = blk / a.ncot;
+    const int chunk = blk / a.ncot;          // chunks never straddle a batch item
+    const int b = chunk / a.nchunk_b, cb = chunk % a.nchunk_b;
     const int k = a.ksize, k3 = k * k * k;
     const int stride = (k == 3) ? 1 : k, padw = (k == 3) ? 1 : 0;
 
@@ -437,7 +438,11 @@ __global__ void __launch_bounds__(64) wgrad_kernel(WgradArgs a) {
     const int co = 32 * cot + col;
     const bool cook = co < a.cout;
     const int Xf = S.up ? S.Xs * 2 : S.Xs, Yf = S.up ? S.Ys * 2 : S.Ys, Zf = S.up ? S.Zs * 2 : S.Zs;
-    const long long nvox = (long long)a.ox * a.oy * a.oz, total = nvox * a.B;
+    const long long nvox = (long long)a.ox * a.oy * a.oz;
+    const long long svox = (long long)S.Xs * S.Ys * S.Zs;
+    // wave-uniform descriptors of this batch item's dy and source (host checks both are < 4 GiB)
+    const __amdgpu_buffer_rsrc_t rdy = sk::make_rsrc(a.dy + (long long)b * nvox * a.cout, (unsigned)(nvox * a.cout * 4));
+    const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(S.data + (long long)b * svox * S.C, (unsigned)(svox * S.C * 4));
 
     f32x16 acc[NT];
 #pragma unroll
@@ -446,24 +451,27 @@ __global__ void __launch_bounds__(64) wgrad_kernel(WgradArgs a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     float bsum = 0.0f;
 
-    const long long p0 = (long long)chunk * a.chunk;
-    long long p1 = p0 + a.chunk;
-    if (p1 > total) p1 = total;
-    for (long long p = p0 + h; p < p1 + h; p += 2) {   // both halves run the same trip count
-        const bool ok = p < p1;
-        const long long pp = ok ? p : p0;
-        const int b = (int)(pp / nvox);
-        const long long v = pp % nvox;
-        const int z = (int)(v % a.oz);
-        const long long t2 = v / a.oz;
-        const int y = (int)(t2 % a.oy), x = (int)(t2 / a.oy);
-        const float av = (ok && cook) ? a.dy[pp * a.cout + co] : 0.0f;
-        bsum += av;
-        const float* sb = S.data + (long long)b * S.Xs * S.Ys * S.Zs * S.C;
+    const long long q0 = (long long)cb * a.chunk;
+    long long q1 = q0 + a.chunk;
+    if (q1 > nvox) q1 = nvox;
+    // this lane's K slot walks the voxels q0 + h, q0 + h + 2, ...: decode once, then step
+    long long q = q0 + h;
+    int z = (int)(q % a.oz);
+    long long t2 = q / a.oz;
+    int y = (int)(t2 % a.oy), x = (int)(t2 / a.oy);
+    const long long ntrip = (q1 - q0 + 1) / 2;  // both halves run the same trip count
+
+    // One iteration's operands.  Masked lanes pass an out-of-range offset and get 0 from the buffer bounds
+    // check, so the ten loads issue back to back, and the NEXT iteration's loads are issued before this
+    // iteration's MFMAs.
+    auto fetch = [&](float& av, float (&bv)[NT]) {
+        const bool ok = q < q1;
+        av = sk::buf_load_f32(rdy, (ok && cook) ? (unsigned)(q * a.cout + co) * 4u : sk::kOob);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int tap = grp * NT + t;
-            const int dx = tap / (k * k), dy = (tap / k) % k, dz = tap % k;
+            const int dx = NT == 9 ? grp : (NT == 8 ? (t >> 2) : 0);
+            const int dy = NT == 9 ? t / 3 : (NT == 8 ? ((t >> 1) & 1) : 0);
+            const int dz = NT == 9 ? t % 3 : (NT == 8 ? (t & 1) : 0);
             int xi = x * stride + dx - padw, yi = y * stride + dy - padw, zi = z * stride + dz - padw;
             const bool inb = xi >= 0 && xi < Xf && yi >= 0 && yi < Yf && zi >= 0 && zi < Zf;
             if (S.up) {
@@ -471,10 +479,31 @@ __global__ void __launch_bounds__(64) wgrad_kernel(WgradArgs a) {
                 yi >>= 1;
                 zi >>= 1;
             }
-            float bv = 0.0f;
-            if (ok && inb && ciok) bv = sb[(((long long)xi * S.Ys + yi) * S.Zs + zi) * S.C + ci];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            const unsigned off = ((unsigned)((xi * S.Ys + yi) * S.Zs + zi) * (unsigned)S.C + (unsigned)ci) * 4u;
+            bv[t] = sk::buf_load_f32(rsrc, (ok && inb && ciok) ? off : sk::kOob);
         }
+        q += 2;
+        z += 2;
+        while (z >= a.oz) {
+            z -= a.oz;
+            ++y;
+        }
+        while (y >= a.oy) {
+            y -= a.oy;
+            ++x;
+        }
+    };
+    float av_n, bv_n[NT];
+    fetch(av_n, bv_n);
+    for (long long it = 0; it < ntrip; ++it) {
+        const float av = av_n;
+        float bv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t] = bv_n[t];
+        fetch(av_n, bv_n);  // past the chunk end every lane is masked and the loads return 0
+        bsum += av;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
     }
     // D[row = cout][col = cin]; this lane holds rows (r&3) + 8*(r>>2) + 4*h of column `col`
     float* part = a.part + (long long)chunk * a.cout * a.cin * k3;
@@ -668,25 +697,26 @@ int sk_train_tversky(const float* predicted, const float* ground_truth, int B, i
     return SK_OK;
 }
 
-static int wgrad_plan(int B, int ox, int oy, int oz, int cout, int cin, int ksize, int* nchunk, long long* chunk,
-                      int* ngroup) {
+static int wgrad_plan(int B, int ox, int oy, int oz, int cout, int cin, int ksize, int* nchunk, int* nchunk_b,
+                      long long* chunk, int* ngroup) {
     const int ncot = (cout + 31) / 32, ncit = (cin + 31) / 32;
     *ngroup = ksize == 3 ? 3 : 1;
-    const long long total = (long long)B * ox * oy * oz;
-    long long want = 4096 / ((long long)ncot * ncit * *ngroup);
+    const long long nvox = (long long)ox * oy * oz;
+    long long want = 4096 / ((long long)ncot * ncit * *ngroup * B);  // chunks per batch item: ~4096 waves in all
     if (want < 1) want = 1;
-    long long c = (total + want - 1) / want;
+    long long c = (nvox + want - 1) / want;
     if (c < 512) c = 512;
     c = (c + 1) & ~1LL;
     *chunk = c;
-    *nchunk = (int)((total + c - 1) / c);
+    *nchunk_b = (int)((nvox + c - 1) / c);
+    *nchunk = B * *nchunk_b;
     return 0;
 }
 
 int64_t sk_train_conv_wgrad_workspace_floats(int B, int ox, int oy, int oz, int cout, int cin, int ksize) {
-    int nchunk, ngroup;
+    int nchunk, nchunk_b, ngroup;
     long long chunk;
-    wgrad_plan(B, ox, oy, oz, cout, cin, ksize, &nchunk, &chunk, &ngroup);
+    wgrad_plan(B, ox, oy, oz, cout, cin, ksize, &nchunk, &nchunk_b, &chunk, &ngroup);
     return (int64_t)nchunk * ((int64_t)cout * cin * ksize * ksize * ksize + cout);
 }
 
@@ -722,7 +752,11 @@ int sk_train_conv_wgrad(const sk_conv_src* srcs, int n_src, const float* dy, int
     a.ksize = ksize;
     a.ncot = (cout + 31) / 32;
     a.ncit = (a.cin + 31) / 32;
-    wgrad_plan(B, ox, oy, oz, cout, a.cin, ksize, &a.nchunk, &a.chunk, &a.ngroup);
+    wgrad_plan(B, ox, oy, oz, cout, a.cin, ksize, &a.nchunk, &a.nchunk_b, &a.chunk, &a.ngroup);
+    SK_CHECK_ARG((long long)ox * oy * oz * cout * 4 < (1LL << 32), "sk_train_conv_wgrad: dy of one batch item must be < 4 GiB");
+    for (int i = 0; i < n_src; ++i)
+        SK_CHECK_ARG((long long)a.src[i].Xs * a.src[i].Ys * a.src[i].Zs * a.src[i].C * 4 < (1LL << 32),
+                     "sk_train_conv_wgrad: source %d of one batch item must be < 4 GiB", i);
     const long long nw = (long long)cout * a.cin * ksize * ksize * ksize;
     a.part = workspace;
     a.part_bias = dbias ? workspace + (long long)a.nchunk * nw : nullptr;

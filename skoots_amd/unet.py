@@ -372,10 +372,10 @@ def cfg_to_model(cfg, device="cuda:0", state_dict: Optional[Dict[str, Tensor]] =
     return HipUNet(state_dict, device, dims, depths)
 
 
-def smoke_model(device="cuda:0") -> Optional[HipUNet]:
-    """Deterministic random-init network for __graft_entry__.smoke() (built without the oracle)."""
-    g = torch.Generator().manual_seed(101196)  # train/engine.py:53
-    dims, depths = (32, 64, 128, 64, 32), (2, 2, 2, 2, 2)
+def random_state_dict(dims=(32, 64, 128, 64, 32), depths=(2, 2, 2, 2, 2), seed: int = 101196) -> Dict[str, Tensor]:
+    """Deterministic random-init parameters under the module's key names (seed: train/engine.py:53);
+    what a from-scratch training run starts from and what smoke() / the benches run on."""
+    g = torch.Generator().manual_seed(seed)
     sd: Dict[str, Tensor] = {}
 
     def conv(name, cin, cout, k):
@@ -402,7 +402,13 @@ def smoke_model(device="cuda:0") -> Optional[HipUNet]:
         conv(f"dec0.{i}", d0 + d4 if i == 0 else d4, d4, 3)
     sd["heads.weight"] = (torch.rand((5, d4, 1, 1, 1), generator=g) * 2 - 1) / d4 ** 0.5
     sd["heads.bias"] = (torch.rand(5, generator=g) * 2 - 1) / d4 ** 0.5
-    return HipUNet(sd, device, dims, depths)
+    return sd
+
+
+def smoke_model(device="cuda:0") -> Optional[HipUNet]:
+    """Deterministic random-init network for __graft_entry__.smoke() (built without the oracle)."""
+    dims, depths = (32, 64, 128, 64, 32), (2, 2, 2, 2, 2)
+    return HipUNet(random_state_dict(dims, depths), device, dims, depths)
 
 
 # ----------------------------------------------------------------------------------------
