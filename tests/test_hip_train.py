@@ -266,16 +266,29 @@ def test_train_step_vs_oracle():
     assert max((new[k].cpu() - sd0[k]).abs().max().item() for k in sd0) > 0.5 * lr
 
 
-def test_trained_weights_feed_the_eval_path():
-    """state_dict() of the trainer loads into the inference runner (the checkpoint contract)."""
+def test_trained_weights_feed_the_eval_path(tmp_path):
+    """The trainer's checkpoint (cfg, model_state_dict, optimizer_state_dict) loads with the safe loader and
+    drives the inference runner; the optimizer state restores into a fresh TrainStep."""
     from oracle import unet_spec
-    from skoots_amd.train import TrainUNet
-    from skoots_amd.unet import HipUNet
+    from skoots_amd.train import TrainStep, TrainUNet
+    from skoots_amd.unet import cfg_to_model
     ref = unet_spec.build()
     model = TrainUNet(ref.state_dict(), DEV)
-    net = HipUNet(model.state_dict(), DEV, precision="fp32")
+    step = TrainStep(model)
+    images, masks, skele, baked = _synthetic_batch(1, 16, 12, 8, 7)
+    step(images.to(DEV), masks.to(DEV), skele.to(DEV), baked.to(DEV))
+    path = str(tmp_path / "model.trch")
+    step.save(path)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"cfg", "model_state_dict", "optimizer_state_dict"}
+    assert ck["cfg"]["SKOOTS"]["VECTOR_SCALING"] == [60, 60, 12]
+    net = cfg_to_model(ck["cfg"], DEV, ck["model_state_dict"])
+    net.precision = "fp32"
     img = torch.randn((16, 12, 8), generator=torch.Generator().manual_seed(3)).half().to(DEV)
     out = net.forward_tiles(img, [(0, 0, 0)], (16, 12, 8), 0.0, 1.0)
     logits = model.forward(img.float()[None, None])
     act = torch.cat([torch.tanh(logits[..., 0:3]), torch.sigmoid(logits[..., 3:5])], dim=-1)
     _close(_cf(act), out.float(), 1e-5, "trainer forward vs fp32 eval forward")
+    other = TrainStep(TrainUNet(ck["model_state_dict"], DEV))
+    other.load_optimizer_state(ck["optimizer_state_dict"])
+    assert other.step_count == 1 and torch.equal(other.exp_avg, step.exp_avg) and torch.equal(other.exp_avg_sq, step.exp_avg_sq)

@@ -111,3 +111,35 @@ def test_halo_plan_is_symmetric():
         need = [(wins[r][0], slabs[r][0]), (slabs[r][1], wins[r][1])]
         covered = sum(hi - lo for lo, hi in got)
         assert covered == sum(b - a for a, b in need)
+
+
+def _grad_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from skoots_amd.train import sync_gradients
+        g = torch.arange(10, dtype=torch.float32) * (rank + 1)
+        sync_gradients(g)
+        q.put((rank, g.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_sync_gloo():
+    """Data-parallel training step: the flat gradient buffer is averaged over the ranks."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = (torch.arange(10, dtype=torch.float32) * 1.5).tolist()
+    for _, got in results:
+        assert got == want
