@@ -75,6 +75,17 @@ class UNetSpec(nn.Module):
         self.heads = nn.Conv3d(d4, 5, 1)
 
     def forward(self, x):
+        """Extents that are not multiples of 4 (a volume thinner than the tile) are zero-padded at the
+        high end up to the next multiple of 4 and the output is cropped back; how the reference's own
+        network (bism, absent) treats such crops is not in the tree, so this is the build's definition."""
+        shape = x.shape[2:]
+        pad = [(-s) % 4 for s in shape]
+        if any(pad):
+            x = F.pad(x, (0, pad[2], 0, pad[1], 0, pad[0]))
+            return self._forward(x)[:, :, :shape[0], :shape[1], :shape[2]]
+        return self._forward(x)
+
+    def _forward(self, x):
         for m in self.enc0:
             x = m(x)
         s0 = x
@@ -123,6 +134,11 @@ def forward_fp16_storage(model: "UNetSpec", x):
         b = (m.norm.bias.reshape(1, GN_GROUPS, -1) - mu.float() * gam * rstd).reshape(1, C, 1, 1, 1)
         return _q16(F.silu(a * _q16(y) + b))
 
+    shape = x.shape[2:]
+    pad = [(-s) % 4 for s in shape]
+    if any(pad):
+        x = F.pad(x, (0, pad[2], 0, pad[1], 0, pad[0]))
+        return forward_fp16_storage(model, x)[:, :, :shape[0], :shape[1], :shape[2]]
     t = x
     for i, m in enumerate(model.enc0):
         t = block(m, t, fp32_weights=(i == 0))

@@ -47,7 +47,10 @@ __global__ void __launch_bounds__(256) stem_norm_kernel(StemArgs a) {
     long long t = i / pz;
     int y = (int)(t % py), x = (int)(t / py);
     float v = 0.0f;
-    if (x >= 1 && x <= a.Xt && y >= 1 && y <= a.Yt && z >= 1 && z <= a.Zt) {
+    // voxels of a tile that overhang the volume (a tile padded up to a multiple of 4, see unet.py) are zero
+    // AFTER normalisation, like the conv frame
+    if (x >= 1 && x <= a.Xt && y >= 1 && y <= a.Yt && z >= 1 && z <= a.Zt && a.ox[b] + x - 1 < a.X &&
+        a.oy[b] + y - 1 < a.Y && a.oz[b] + z - 1 < a.Z) {
         float raw = __half2float(a.image[((long long)(a.ox[b] + x - 1) * a.Y + (a.oy[b] + y - 1)) * a.Z +
                                          (a.oz[b] + z - 1)]);
         // eval.py:139  crop.sub(mean).div(std) on an fp16 tensor: each op rounds to fp16
@@ -393,8 +396,9 @@ static int fill_stem_args(StemArgs& a, const void* image, int X, int Y, int Z, c
         a.ox[b] = origins_host[3 * b];
         a.oy[b] = origins_host[3 * b + 1];
         a.oz[b] = origins_host[3 * b + 2];
-        SK_CHECK_ARG(a.ox[b] >= 0 && a.oy[b] >= 0 && a.oz[b] >= 0 && a.ox[b] + Xt <= X &&
-                         a.oy[b] + Yt <= Y && a.oz[b] + Zt <= Z,
+        // a tile may overhang the volume by < 4 voxels per axis (extent padded up to a multiple of 4)
+        SK_CHECK_ARG(a.ox[b] >= 0 && a.oy[b] >= 0 && a.oz[b] >= 0 && a.ox[b] + Xt <= X + 3 &&
+                         a.oy[b] + Yt <= Y + 3 && a.oz[b] + Zt <= Z + 3 && a.ox[b] < X && a.oy[b] < Y && a.oz[b] < Z,
                      "sk_conv3d_stem: tile %d at (%d,%d,%d)+(%d,%d,%d) outside volume (%d,%d,%d)", b,
                      a.ox[b], a.oy[b], a.oz[b], Xt, Yt, Zt, X, Y, Z);
     }

@@ -226,9 +226,17 @@ class HipUNet:
         _ffi.require_gpu(image, "image")
         if image.dtype != torch.float16 or image.ndim != 3:
             raise ValueError("image must be an (X, Y, Z) fp16 tensor")
-        xt, yt, zt = (int(v) for v in tile)
-        if xt % 4 or yt % 4 or zt % 4:
-            raise ValueError(f"tile extents {tuple(tile)} must be multiples of 4 (two stride-2 levels)")
+        ext = tuple(int(v) for v in tile)
+        # The network runs on extents padded up to a multiple of 4 (two stride-2 levels) with zeros in
+        # normalised space -- exactly what oracle/unet_spec.py defines for such a crop -- and the output
+        # is cropped back: a volume thinner than the 300x300x20 tile gives tiles of its own extent
+        # (cropper.py:58-144), which need not be a multiple of 4.
+        xt, yt, zt = ((v + 3) // 4 * 4 for v in ext)
+        if (xt, yt, zt) != ext:
+            if keep_features:
+                raise ValueError("keep_features needs tile extents that are multiples of 4")
+            full = self.forward_tiles(image, origins, (xt, yt, zt), mean, std, out_box=out_box)
+            return full[:, :, :ext[0], :ext[1], :ext[2]]
         if self.precision == "fp32":
             return self._forward_fp32(image, origins, (xt, yt, zt), float(mean), float(std))
         B = len(origins)
@@ -327,8 +335,11 @@ class HipUNet:
     def _forward_fp32(self, image: Tensor, origins, tile, mean: float, std: float) -> Tensor:
         xt, yt, zt = tile
         L0, L1, L2 = tile, (xt // 2, yt // 2, zt // 2), (xt // 4, yt // 4, zt // 4)
-        crops = torch.stack([image[x:x + xt, y:y + yt, z:z + zt] for (x, y, z) in origins])
-        a = crops.sub(mean).div(std).float().unsqueeze(-1).contiguous()  # eval.py:139 (fp16 arithmetic)
+        def crop(x, y, z):  # normalise (eval.py:139, fp16 arithmetic), then zero-pad an overhanging tile
+            c = image[x:x + xt, y:y + yt, z:z + zt].sub(mean).div(std).float()
+            return torch.nn.functional.pad(c, (0, zt - c.shape[2], 0, yt - c.shape[1], 0, xt - c.shape[0]))
+
+        a = torch.stack([crop(x, y, z) for (x, y, z) in origins]).unsqueeze(-1).contiguous()
         for layer in self.enc0:
             a = self._conv_f32(layer, [(a, 0)], L0)
         s0 = a

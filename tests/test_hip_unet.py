@@ -140,7 +140,8 @@ def test_stem_vs_torch(U):
 
 @pytest.mark.parametrize("tile,origins", [((64, 64, 20), [(0, 0, 0)]),
                                            ((32, 48, 20), [(3, 1, 2), (10, 0, 0)]),
-                                           ((128, 128, 20), [(0, 0, 12)])])
+                                           ((128, 128, 20), [(0, 0, 12)]),
+                                           ((30, 45, 18), [(0, 0, 0)])])   # padded up to (32, 48, 20)
 def test_network_vs_oracle(U, tile, origins):
     """Whole U-Net on the GPU against the torch fp32 CPU oracle (oracle/unet_spec.py).
 
@@ -176,7 +177,8 @@ def test_network_vs_oracle(U, tile, origins):
         assert rms(e32) <= 1.25 * rms(emu) + 1e-5
 
 
-@pytest.mark.parametrize("tile,origins", [((64, 64, 20), [(0, 0, 0)]), ((32, 48, 20), [(3, 1, 2), (10, 0, 0)])])
+@pytest.mark.parametrize("tile,origins", [((64, 64, 20), [(0, 0, 0)]), ((32, 48, 20), [(3, 1, 2), (10, 0, 0)]),
+                                           ((30, 45, 18), [(0, 0, 0)]), ((13, 22, 7), [(0, 0, 0)])])
 def test_network_fp32_mode_vs_oracle(U, tile, origins):
     """precision="fp32": the same tiling / normalisation / GroupNorm / heads plumbing on the exact-fp32
     matrix instruction.  Max-abs <= 1e-3 against the fp32 oracle -- the tolerance BASELINE.json's
@@ -200,7 +202,8 @@ def test_network_fp32_mode_vs_oracle(U, tile, origins):
         assert err <= 1e-3
 
 
-def test_end_to_end_with_network_fp32_mode(U):
+@pytest.mark.parametrize("shape", [(140, 132, 34), (190, 186, 18)])  # second: thinner than the tile, no extent % 4 == 0
+def test_end_to_end_with_network_fp32_mode(U, shape):
     """Whole eval path WITH the network (no injected field) in fp32 mode against the CPU oracle on
     the same volume: vectors within 1e-3 wherever both gates agree, and the thresholded skeleton /
     final instance masks differ only where a probability sits within ~1e-5 of the 0.8 threshold."""
@@ -215,13 +218,12 @@ def test_end_to_end_with_network_fp32_mode(U):
         ref.heads.weight[0:3].mul_(0.15)
     hip = U.HipUNet.from_module(ref, DEV, precision="fp32")
     gen = torch.Generator().manual_seed(3)
-    shape = (140, 132, 34)
     vol = torch.randint(0, 256, (1,) + shape, generator=gen).to(torch.float16)
     with torch.no_grad():
         want = O.eval_volume(vol, ref, (60, 60, 12))
     got = E.eval_volume(vol.to(DEV), hip, (60, 60, 12), keep_planar_vectors=True)
     sk_w, sk_g = want["skeleton"][0], got["skeleton"].cpu().numpy()
-    assert sk_w.sum() > 1000
+    assert sk_w.sum() > 1e-3 * sk_w.size
     assert (sk_w != sk_g).mean() < 1e-4
     v_w, v_g = want["vectors"].astype(np.float32), got["state"].vec_planar.cpu().numpy().astype(np.float32)
     both = (np.abs(v_w).sum(0) > 0) == (np.abs(v_g).sum(0) > 0)
