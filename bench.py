@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inject", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="tile batches in flight (HIP streams)")
+    ap.add_argument("--precision", choices=["fp16", "fp32"], default="fp16",
+                    help="fp32: every layer on the exact-fp32 matrix instruction (strict 1e-3 parity mode; not the headline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -177,6 +179,7 @@ def main():
     X, Y, Z = shape
     sv = ShardedVolume(shape, rank, world, dev)
     model = unet.smoke_model(dev)
+    model.precision = args.precision
 
     # ---- synthetic inputs, resident in HBM before the timed region -------------------
     zlo, zhi = sv.window  # local z-window (slab + halo)
@@ -230,7 +233,8 @@ def main():
             "metric": "Mvoxels/s end-to-end (3D U-Net fwd + instance assign)",
             "value": round(voxels / (dt / args.steps) / 1e6, 3), "unit": "Mvoxels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if args.precision == "fp16" else "f32",
             "data": "synthetic",
             "config": {"workload": f"{X}x{Y}x{Z} fp16 volume, 300x300x20 tiles (margin 50,50,5), "
                                    f"U-Net dims [32,64,128,64,32] depths [2,2,2,2,2], N=10 follow, "
@@ -244,6 +248,9 @@ def main():
                          "traffic_unit": "bytes per launch (PMC, profiles/r01_conv_hbm_traffic_pmc.json)",
                          "launches": conv_launches, "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4)},
         }
+        if args.precision != "fp16":  # the MFMA conv profile only instruments the fp16 kernel
+            line["roofline"] = None
+            line["config"]["precision"] = args.precision
         if not args.no_cpu_baseline and world == 1:
             log("timing the CPU restatement (bounded sample)")
             line["cpu_baseline"] = cpu_baseline()
