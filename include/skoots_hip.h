@@ -186,11 +186,12 @@ typedef struct sk_conv_src {
  * materialised).  ksize 2: stride 2, no pad.  ksize 1: pointwise.  weight: packed by
  * sk_conv3d_pack_weight_host; bias (cout) fp32; out (B, ox, oy, oz, cout) fp16 raw.
  * gn_partial: (B, sk_conv3d_num_blocks, cout/4, 2) fp32 per-block (sum, sumsq) of
- * the fp32 accumulators per channel quad, or NULL.  zeros: >= 1 KiB of zero bytes
- * (source of the halo / padding lanes of the LDS-DMA). */
+ * the fp32 accumulators per channel quad, or NULL.  zero_page: 4 KiB; bytes [0, 1024) must
+ * be zero and stay zero (source of the halo / padding lanes of the LDS-DMA), bytes
+ * [2048, 3072) are write-only scratch for the ksize-3 kernel's masked store lanes. */
 int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias,
               void* out, int B, int ox, int oy, int oz, int cout, int ksize,
-              float* gn_partial, const void* zeros, void* stream);
+              float* gn_partial, void* zero_page, void* stream);
 
 /* Rows of gn_partial per batch item that sk_conv3d writes for this output shape. */
 int sk_conv3d_num_blocks(int B, int ox, int oy, int oz, int cout, int ksize);

@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     constexpr int NT = COUT / 32;
     constexpr int P = NT;            // column tiles per wave
     constexpr int R = XS + 2;
+    constexpr bool kLateWait = (NT != 2);  // wait for the next phase's DMA after the epilogue (see there)
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x;
@@ -119,18 +120,26 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     long long out_vox0[P];      // in-plane voxel index of column 0 of tile p (the 32 columns are contiguous)
     long long tile_nvox[P];     // columns with out_vox0 + c < tile_nvox are inside the tile
     bool vvalid[P];
+    bool zlo[P], zhi[P];        // linear mode: this lane's voxel sits on the z = 0 / z = Zt-1 face
     if (a.mode == 0) {
+        // Linear mode: region position q <-> in-plane voxel index v0 - Zt - 1 + q, NO z halo (pitch = Zt), so
+        // the 32 columns of a tile are 32 consecutive positions for every tap: with the 16-byte chunk swizzle
+        // below any 16 consecutive positions cover all 64 banks, i.e. every ds_read_b128 lane group is
+        // conflict-free (a z halo makes q jump by 2 at each row end: SQ_LDS_BANK_CONFLICT was ~50 % of the
+        // LDS cycles).  A dz = -1 / +1 tap on the z = 0 / Zt-1 face would read the neighbouring row's voxel:
+        // those lanes read the plane's zero position instead (one v_cndmask on the address).
         int v0 = patch * kPatch;
-        int y0 = v0 / a.Zt, z0 = v0 - y0 * a.Zt;
-        off = z0;
-        ybase = y0 - 1;
-        zbase = -1;
+        off = v0 - a.Zt - 1;
+        ybase = 0;
+        zbase = 0;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             int v = v0 + 32 * (wm * P + p) + col;
             int vy = v / a.Zt, vz = v - vy * a.Zt;
             vvalid[p] = v < a.Yt * a.Zt;
-            q_row[p] = (vy + 1) * pitch + (vz + 1) - (y0 * pitch + z0);
+            zlo[p] = vz == 0;
+            zhi[p] = vz == a.Zt - 1;
+            q_row[p] = v - off;
             out_vox0[p] = v0 + 32 * (wm * P + p);
             tile_nvox[p] = (long long)a.Yt * a.Zt;
         }
@@ -147,6 +156,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             int yl = vl / a.TZ, zl = vl - yl * a.TZ;
             int vy = y0 + yl, vz = zc0 + zl;
             vvalid[p] = vy < a.Yt && vz < a.Zt;
+            zlo[p] = zhi[p] = false;
             q_row[p] = (yl + 1) * pitch + (zl + 1);
             // a column tile is one 32-voxel z segment of one line (TZ == 32)
             const int ty = y0 + (32 * (wm * P + p)) / a.TZ;
@@ -163,8 +173,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
         int t = w + 4 * k;
         int slot = 64 * t + lane;
         int q = slot >> 2, c = slot & 3;
-        int Pq = q + off;
-        int y = ybase + Pq / pitch, z = zbase + Pq % pitch;
+        int Pq = q + off;        // linear mode: the voxel index itself (may be < 0 above the tile)
+        int y = ybase + (Pq >= 0 ? Pq / pitch : -1), z = zbase + (Pq >= 0 ? Pq % pitch : 0);
         bool ok = (t < ndma) && y >= 0 && y < a.Yt && z >= 0 && z < a.Zt;
         d_vox[k] = ok ? y * a.Zt + z : -1;
         d_up[k] = ok ? (y >> 1) * a.src[1].Zs + (z >> 1) : -1;
@@ -179,7 +189,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
 
     const int xa = xc * a.XC;
     const int xb = min(xa + a.XC, a.Xt);
-    const int plane_bytes = a.nposp * kPosBytes;
+    const int plane_bytes = (a.nposp + 1) * kPosBytes;  // + the zero position (never written by the DMA)
+    const int zero_addr = a.nposp * kPosBytes;
     const bool ring = (a.nchunks == 1);
     const long long out_plane = (long long)a.Yt * a.Zt * COUT * 2;
     char* outb = a.out + (long long)b * a.Xt * out_plane;
@@ -203,6 +214,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     const int nsteps = (xb - xa + XS - 1) / XS;
     const int nphases = nsteps * a.nchunks;
     char* pad = lds + R * plane_bytes + w * kPadBytes;
+    char* trash = const_cast<char*>(a.zeros) + 2048 + lane * 16;  // upper half of the zero page: write-only scratch
     const int rv = lane >> 2, rc = lane & 3;  // epilogue read-back: voxel (0..15), 16-byte chunk
 
     auto issue_dma = [&](int step, int ch) {
@@ -233,6 +245,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     auto wbase = [&](int ch) { return a.wpk + ((long long)ch * (9 * 2 * 3 * NT) + wn) * 1024 + lane * 16; };
 
     half8 a0[3], a1[3];
+    if (tid < R * 4)
+        *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
     issue_dma(0, 0);
 #pragma unroll
     for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(0) + (d * NT) * 1024);
@@ -256,11 +270,14 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             for (int i = 0; i < R; ++i) pslot[i] = (ring ? (step * XS + i) % R : i) * plane_bytes;
 
             auto compute = [&](int dydz, int ks, const half8 (&afr)[3]) {
-                const int tapoff = (dydz / 3 - 1) * pitch + (dydz % 3 - 1);
+                const int dz = dydz % 3 - 1;
+                const int tapoff = (dydz / 3 - 1) * pitch + dz;
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const int q = q_row[p] + tapoff;
-                    const int addr = (q * 4 + ((ks * 2 + h) ^ ((q >> 2) & 3))) * 16;
+                    int addr = (q * 4 + ((ks * 2 + h) ^ ((q >> 2) & 3))) * 16;
+                    if (dz < 0) addr = zlo[p] ? zero_addr : addr;
+                    if (dz > 0) addr = zhi[p] ? zero_addr : addr;
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
                         const half8 bfr = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
@@ -310,10 +327,14 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             issue_dma(nstep, nch);
 #pragma unroll
             for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(nch) + (d * NT) * 1024);
-            // the DMA must have landed before this wave passes the closing barrier; waiting HERE,
-            // before the epilogue issues its stores, keeps those stores out of the wait: they
-            // drain under the next phase's MFMAs (the closing barrier is a bare s_barrier).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // The DMA must have landed before this wave passes the closing barrier.  vmcnt retires in issue
+            // order, so after an epilogue that issues a FIXED number of stores (invalid lanes / planes store to
+            // a scratch line instead of branching) `vmcnt(that number)` means "everything older than the
+            // stores -- the DMA and the weight fragments -- has landed": the DMA latency hides behind the
+            // epilogue's transposes and the stores still drain under the next phase's MFMAs.
+            // Measured per layer (same device, A/B): -4 % time for COUT 32, +4 % for COUT 64 (two column tiles per
+            // wave: a longer epilogue), neutral for COUT 128 -> late wait for NT != 2 only.
+            if (!kLateWait || !step_done || a.ablate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 
         // ---------------- epilogue (overlaps the DMA): raw fp16 store + GroupNorm partials ------
@@ -340,21 +361,33 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                             gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
                         }
                     }
-                    if (x < xb && !(a.ablate & 4)) {
+                    if (!(a.ablate & 4)) {
                         char* op = outb + (long long)x * out_plane + tile_vox0 * (COUT * 2) + wn * 64;
 #pragma unroll
                         for (int hh = 0; hh < 2; ++hh) {
                             const int vv = rv + 16 * hh;
                             const half8 line = *reinterpret_cast<const half8*>(
                                 pad + vv * kPadStride + ((rc ^ ((vv >> 1) & 3)) * 16));
-                            if (tile_vox0 + vv < tile_nvox[p])
+                            const bool sok = x < xb && tile_vox0 + vv < tile_nvox[p];
+                            if constexpr (kLateWait) {
+                                // always issued (the counted wait below relies on it); masked lanes hit the scratch line
+                                char* dst = sok ? op + (long long)vv * (COUT * 2) + rc * 16 : trash;
+                                *reinterpret_cast<half8*>(dst) = line;
+                            } else if (sok) {
                                 *reinterpret_cast<half8*>(op + (long long)vv * (COUT * 2) + rc * 16) = line;
+                            }
                         }
                     }
                 }
             }
         }
-        if (have_next) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (have_next) {
+            if (kLateWait && step_done && !a.ablate) {
+                constexpr int kStores = P * XS * 2;  // global stores the epilogue just issued
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         step = nstep;
         ch = nch;
     }
@@ -383,255 +416,6 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             float t = 0.0f;
 #pragma unroll
             for (int g = 0; g < 4 / NT; ++g) t += red[(g * NT + nt) * 16 + k2];
-            a.partial[((long long)b * nblk + block_in_batch) * (NT * 16) + tid] = t;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// conv3p: producer / consumer variant of the same algorithm (one workgroup per CU).
-//
-// Ablating the kernel above shows its memory phases (LDS-DMA reads, epilogue stores) cost ~30 %
-// because they run back to back with the MFMA phase of the same waves, and vmcnt retires in
-// issue order: any wait for a weight fragment also waits for every older DMA / store of that
-// wave.  Here 8 consumer waves only ever wait for their own weight loads, and 2 producer
-// waves only issue LDS-DMA: while the consumers run phase ph out of one set of LDS planes the
-// producers fill the planes of phase ph+1 (12-slot ring = all 160 KiB of the CU), so a phase
-// costs one s_barrier and the activation traffic overlaps the MFMAs completely.
-//   NT = 1: consumer w -> column tile w&3, output planes 2*(w>>2) + {0,1}
-//   NT = 2: consumer w -> cout tile w&1, column tile w>>1, all 4 output planes
-// ------------------------------------------------------------------------------------------
-constexpr int kPipeSlots = 12;
-constexpr int kPipeConsumers = 8;
-constexpr int kPipeThreads = 640;
-constexpr int kPipeDma = 6;  // DMA wave-instructions per plane per producer wave (nposp <= 192)
-
-template <int COUT>
-__global__ void __launch_bounds__(kPipeThreads) conv3p_kernel(Conv3Args a) {
-    constexpr int NT = COUT / 32;
-    constexpr int XS = 4;
-    constexpr int XW = (NT == 1) ? 2 : 4;   // output planes per consumer wave
-    constexpr int RW = XW + 2;              // input planes a consumer reads
-    constexpr int R = XS + 2;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = w >= kPipeConsumers;
-    const int col = lane & 31, h = lane >> 5;
-    const int wn = (NT == 1) ? 0 : (w & 1);            // cout tile
-    const int ct = (NT == 1) ? (w & 3) : ((w >> 1) & 3);  // column tile
-    const int o0 = (NT == 1) ? 2 * ((w >> 2) & 1) : 0;  // first output plane of this wave
-
-    int blk = blockIdx.x;
-    const int patch = blk % a.npatch;
-    blk /= a.npatch;
-    const int xc = blk % a.nxc;
-    const int b = blk / a.nxc;
-    const int block_in_batch = xc * a.npatch + patch;
-    const int nblk = a.npatch * a.nxc;
-
-    // ---- patch geometry (linear (y,z) ranges only) -----------------------------------------
-    const int pitch = a.pitch;
-    const int v0 = patch * kPatch;
-    const int y0 = v0 / a.Zt, z0 = v0 - y0 * a.Zt;
-    const int off = z0, ybase = y0 - 1, zbase = -1;
-    const int v = v0 + 32 * ct + col;
-    const int vy = v / a.Zt, vz = v - vy * a.Zt;
-    const bool vvalid = v < a.Yt * a.Zt;
-    const int q_row = (vy + 1) * pitch + (vz + 1) - (y0 * pitch + z0);
-    const long long tile_vox0 = v0 + 32 * ct;
-    const long long tile_nvox = (long long)a.Yt * a.Zt;
-
-    const int xa = xc * a.XC;
-    const int xb = min(xa + a.XC, a.Xt);
-    const int plane_bytes = a.nposp * kPosBytes;
-    const bool ring = (a.nchunks == 1);
-    const long long out_plane = (long long)a.Yt * a.Zt * COUT * 2;
-    char* outb = a.out + (long long)b * a.Xt * out_plane;
-    const int nsteps = (xb - xa + XS - 1) / XS;
-    const int nphases = nsteps * a.nchunks;
-    // LDS slot of input plane i of phase (step, ch); ph = step * nchunks + ch
-    auto slot_of = [&](int step, int ph, int i) { return ring ? (step * XS + i) % kPipeSlots : (ph & 1) * R + i; };
-
-    if (producer) {
-        // ================================ producers ============================================
-        const int pw = w - kPipeConsumers;
-        const int ndma = a.nposp / 16;
-        int d_vox[kPipeDma], d_up[kPipeDma], d_cs[kPipeDma];
-#pragma unroll
-        for (int k = 0; k < kPipeDma; ++k) {
-            int t = pw + 2 * k;
-            int slot = 64 * t + lane;
-            int q = slot >> 2, c = slot & 3;
-            int Pq = q + off;
-            int y = ybase + Pq / pitch, z = zbase + Pq % pitch;
-            bool ok = (t < ndma) && y >= 0 && y < a.Yt && z >= 0 && z < a.Zt;
-            d_vox[k] = ok ? y * a.Zt + z : -1;
-            d_up[k] = ok ? (y >> 1) * a.src[1].Zs + (z >> 1) : -1;
-            d_cs[k] = (c ^ ((q >> 2) & 3)) * 16;
-        }
-        auto issue = [&](int ph) {
-            const int step = ph / a.nchunks, ch = ph - step * a.nchunks;
-            const int x0 = xa + step * XS;
-            const int si = ch < a.c0chunks ? 0 : 1;
-            const SrcDev s = a.src[si];
-            const int choff = (ch - (si ? a.c0chunks : 0)) * kChunk * 2;
-            const int first_new = (ring && step > 0) ? 2 : 0;
-            for (int i = (a.ablate & 1) ? R : first_new; i < R; ++i) {
-                const int x = x0 - 1 + i;
-                const bool xok = x >= 0 && x < a.Xt;
-                const char* pbase = s.data + (long long)b * s.batch + (long long)(s.up ? (x >> 1) : x) * s.plane + choff;
-                char* lbase = lds + slot_of(step, ph, i) * plane_bytes;
-#pragma unroll
-                for (int k = 0; k < kPipeDma; ++k) {
-                    const int t = pw + 2 * k;
-                    if (t < ndma) {
-                        const int vox = s.up ? d_up[k] : d_vox[k];
-                        const char* g = (xok && vox >= 0) ? pbase + (long long)vox * (s.C * 2) + d_cs[k]
-                                                          : a.zeros + lane * 16;
-                        dma16(g, lbase + t * 1024);
-                    }
-                }
-            }
-        };
-        issue(0);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        for (int ph = 0; ph < nphases; ++ph) {
-            if (ph + 1 < nphases) issue(ph + 1);
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-    } else {
-        // ================================ consumers ============================================
-        f32x16 acc[XW];
-        float gsum[4], gsq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) gsum[q] = gsq[q] = 0.0f;
-        f32x16 binit;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + 32 * wn + 8 * q + 4 * h);
-            binit[4 * q + 0] = bv[0];
-            binit[4 * q + 1] = bv[1];
-            binit[4 * q + 2] = bv[2];
-            binit[4 * q + 3] = bv[3];
-        }
-        char* pad = lds + kPipeSlots * plane_bytes + w * kPadBytes;
-        const int rv = lane >> 2, rc = lane & 3;
-        auto wbase = [&](int ch) { return a.wpk + ((long long)ch * (9 * 2 * 3 * NT) + wn) * 1024 + lane * 16; };
-        half8 a0[3], a1[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(0) + (d * NT) * 1024);
-        asm volatile("s_barrier" ::: "memory");
-
-        int step = 0, ch = 0;
-        for (int ph = 0; ph < nphases; ++ph) {
-            const int x0 = xa + step * XS;
-            if (ch == 0) {
-#pragma unroll
-                for (int o = 0; o < XW; ++o) acc[o] = binit;
-            }
-            const char* wch = wbase(ch);
-            int pslot[RW];
-#pragma unroll
-            for (int i = 0; i < RW; ++i) pslot[i] = slot_of(step, ph, o0 + i) * plane_bytes;
-            auto compute = [&](int dydz, int ks, const half8 (&afr)[3]) {
-                const int q = q_row + (dydz / 3 - 1) * pitch + (dydz % 3 - 1);
-                const int addr = (q * 4 + ((ks * 2 + h) ^ ((q >> 2) & 3))) * 16;
-#pragma unroll
-                for (int i = 0; i < RW; ++i) {
-                    const half8 bfr = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        const int o = i - d;
-                        if (o >= 0 && o < XW)
-                            acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[d], bfr, acc[o], 0, 0, 0);
-                    }
-                }
-            };
-            const bool step_done = (ch == a.nchunks - 1);
-            int nstep = step, nch = ch + 1;
-            if (step_done) {
-                nstep = step + 1;
-                nch = 0;
-            }
-#pragma unroll 1
-            for (int dydz = 0; dydz < 9; ++dydz) {
-                const char* wrow = wch + (long long)(((a.ablate & 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
-#pragma unroll
-                for (int d = 0; d < 3; ++d)
-                    a1[d] = *reinterpret_cast<const half8*>(wrow + ((3 + d) * NT) * 1024);
-                compute(dydz, 0, a0);
-                // next (dydz, ks=0) fragments; at the last row: the first fragments of the NEXT phase,
-                // requested before the epilogue's stores so that waiting for them never waits for a store
-                const char* nrow = (dydz < 8) ? wrow + (6 * NT) * 1024 : wbase(nch < a.nchunks ? nch : 0);
-#pragma unroll
-                for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(nrow + (d * NT) * 1024);
-                compute(dydz, 1, a1);
-            }
-            if (step_done) {
-#pragma unroll
-                for (int o = 0; o < XW; ++o) {
-                    const int x = x0 + o0 + o;
-                    const bool ok = vvalid && x < xb;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float v0_ = acc[o][4 * q], v1 = acc[o][4 * q + 1], v2 = acc[o][4 * q + 2], v3 = acc[o][4 * q + 3];
-                        half4 hv = {(_Float16)v0_, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-                        *reinterpret_cast<half4*>(pad + col * kPadStride + ((q ^ ((col >> 1) & 3)) * 16) + 8 * h) = hv;
-                        if (ok) {
-                            gsum[q] += (v0_ + v1) + (v2 + v3);
-                            gsq[q] += (v0_ * v0_ + v1 * v1) + (v2 * v2 + v3 * v3);
-                        }
-                    }
-                    if (x < xb && !(a.ablate & 4)) {
-                        char* op = outb + (long long)x * out_plane + tile_vox0 * (COUT * 2) + wn * 64;
-#pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
-                            const int vv = rv + 16 * hh;
-                            const half8 line = *reinterpret_cast<const half8*>(
-                                pad + vv * kPadStride + ((rc ^ ((vv >> 1) & 3)) * 16));
-                            if (tile_vox0 + vv < tile_nvox)
-                                *reinterpret_cast<half8*>(op + (long long)vv * (COUT * 2) + rc * 16) = line;
-                        }
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            step = nstep;
-            ch = nch;
-        }
-
-        // ---- GroupNorm partials of this wave -> LDS (planes are dead now) ----
-        if (a.partial) {
-            float* red = reinterpret_cast<float*>(lds);  // [8 consumer waves][8 quads][2]
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float s = gsum[q], ss = gsq[q];
-#pragma unroll
-                for (int m = 16; m > 0; m >>= 1) {
-                    s += __shfl_xor(s, m);
-                    ss += __shfl_xor(ss, m);
-                }
-                if (col == 0) {
-                    red[(w * 8 + 2 * q + h) * 2 + 0] = s;
-                    red[(w * 8 + 2 * q + h) * 2 + 1] = ss;
-                }
-            }
-        }
-    }
-    if (a.partial) {
-        __syncthreads();
-        const float* red = reinterpret_cast<const float*>(lds);
-        if (tid < NT * 16) {
-            // channel quad Q = 8*nt + k; consumer waves with cout tile nt
-            const int nt = tid / 16, k2 = tid % 16;
-            float t = 0.0f;
-            for (int cw = 0; cw < kPipeConsumers; ++cw) {
-                const int cwn = (NT == 1) ? 0 : (cw & 1);
-                if (cwn == nt) t += red[cw * 16 + k2];
-            }
             a.partial[((long long)b * nblk + block_in_batch) * (NT * 16) + tid] = t;
         }
     }
@@ -783,7 +567,6 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
 struct Plan {
     int mode, TZ, nzc, pitch, nposp, npatch, XC, nxc, xs;
     size_t lds;
-    bool pipe;  // producer/consumer kernel (conv3p) instead of conv3
 };
 
 int conv3_xs(int cout) { return cout == 128 ? 2 : 4; }  // keeps P*XS*16 accumulators <= 128
@@ -794,25 +577,10 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
         p.mode = 0;
         p.TZ = Zt;
         p.nzc = 1;
-        p.pitch = Zt + 2;
+        p.pitch = Zt;  // no z halo: see the kernel's linear-mode comment
         long long nv = (long long)Yt * Zt;
         p.npatch = (int)((nv + kPatch - 1) / kPatch);
-        int worst = 0;
-        for (int pa = 0; pa < p.npatch; ++pa) {
-            long long v0 = (long long)pa * kPatch, v1 = v0 + kPatch - 1;
-            if (v1 >= nv) v1 = nv - 1;
-            long long y0 = v0 / Zt, z0 = v0 % Zt, y1 = v1 / Zt, z1 = v1 % Zt;
-            long long plo = y0 * p.pitch + z0;                       // p(v0) - pitch - 1
-            long long phi = (y1 + 1) * p.pitch + (z1 + 1) + p.pitch + 1;
-            int n = (int)(phi - plo + 1);
-            // the last patch may be ragged: its lanes past nv still index the region
-            long long vl = v0 + kPatch - 1;
-            long long yl = vl / Zt, zl = vl % Zt;
-            long long phl = (yl + 1) * p.pitch + (zl + 1) + p.pitch + 1;
-            n = std::max(n, (int)(phl - plo + 1));
-            worst = std::max(worst, n);
-        }
-        p.nposp = (worst + 15) / 16 * 16;
+        p.nposp = (kPatch + 2 * Zt + 2 + 15) / 16 * 16;  // 128 voxels + one row and one voxel on each side
     } else {
         p.mode = 1;
         p.TZ = 32;
@@ -823,18 +591,9 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
         p.nposp = ((TY + 2) * p.pitch + 15) / 16 * 16;
     }
     if (p.nposp > 64 * kMaxDma) return -1;
-    p.lds = (size_t)(p.xs + 2) * p.nposp * kPosBytes + 4 * kPadBytes;
-    {
-        const char* e = getenv("SK_CONV_PIPE");  // 1 selects the producer/consumer kernel (experimental:
-        const bool want = e && atoi(e) == 1;     // measured 15 % slower than conv3_kernel in round 1)
-        p.pipe = want && p.mode == 0 && p.nposp <= 32 * kPipeDma && (cout == 32 || cout == 64);
-    }
-    if (p.pipe) {
-        p.xs = 4;
-        p.lds = (size_t)kPipeSlots * p.nposp * kPosBytes + kPipeConsumers * kPadBytes;
-    }
-    // x-chunks: enough workgroups to fill the CUs (2 per CU, 1 for the pipelined kernel) several times over
-    int target = p.pipe ? 256 * 6 : 256 * 2 * 6;
+    p.lds = (size_t)(p.xs + 2) * (p.nposp + 1) * kPosBytes + 4 * kPadBytes;
+    // x-chunks: enough workgroups to fill the CUs (2 per CU) several times over
+    int target = 256 * 2 * 6;
     int nxc = (target + p.npatch * B - 1) / (p.npatch * B);
     int max_nxc = (Xt + 2 * p.xs - 1) / (2 * p.xs);  // at least two steps per chunk
     if (nxc > max_nxc) nxc = max_nxc;
@@ -845,16 +604,6 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
     p.XC = XC;
     p.nxc = (Xt + XC - 1) / XC;
     return 0;
-}
-
-template <int COUT>
-int launch_conv3p(const Conv3Args& a, const Plan& p, hipStream_t stream) {
-    auto kern = conv3p_kernel<COUT>;
-    SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-    unsigned grid = (unsigned)(p.npatch * p.nxc * a.B);
-    kern<<<grid, kPipeThreads, p.lds, stream>>>(a);
-    SK_CHECK_LAUNCH();
-    return SK_OK;
 }
 
 template <int COUT, int XS>
@@ -923,7 +672,7 @@ int64_t sk_conv3d_pack_weight_host(const float* w, int cout, int cin, int ksize,
 
 int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,
               int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial,
-              const void* zeros, void* stream_) {
+              void* zeros, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     SK_CHECK_ARG(srcs && weight && bias && out, "sk_conv3d: NULL pointer");
     SK_CHECK_ARG(n_src == 1 || n_src == 2, "sk_conv3d: n_src must be 1 or 2");
@@ -979,7 +728,6 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
             const char* e = getenv("SK_CONV_ABLATE");
             a.ablate = e ? atoi(e) : 0;
         }
-        if (p.pipe) return cout == 32 ? launch_conv3p<32>(a, p, stream) : launch_conv3p<64>(a, p, stream);
         if (cout == 32) return launch_conv3<32, 4>(a, p, stream);
         if (cout == 64) return launch_conv3<64, 4>(a, p, stream);
         return launch_conv3<128, 2>(a, p, stream);
