@@ -83,7 +83,13 @@ __device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
 // P = NT column tiles (32 voxels each) of the 128-voxel patch.  So a wave streams only its
 // own cout tile's weights (weight-fragment reuse = XS*P MFMAs per 1 KiB fragment) and the
 // activation fragment of a column tile is read once per wave that needs it.
-template <int COUT, int XS>
+// RES: rows (dy,dz) of the 9 whose weight fragments stay in registers for the whole workgroup -- only for
+// single-chunk layers (the same 54 fragments every step) of COUT 32, where the kernel leaves ~80 of its 256
+// registers: 3 rows = 18 fragments = 72 VGPRs (246 in all; 4 rows spill), the other 6 rows stream as before.
+// (Keeping chunk 0's rows resident in a two-chunk layer, selected at run time per phase, spills: 1.8x slower;
+// requesting a whole row of streamed fragments two bodies ahead instead of one measured 4 % slower.)
+// Measured A/B on one device: -4..5 % time on enc0.1 / dec0.1.
+template <int COUT, int XS, int RES = 0>
 __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     constexpr int NT = COUT / 32;
     constexpr int P = NT;            // column tiles per wave
@@ -245,11 +251,20 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     auto wbase = [&](int ch) { return a.wpk + ((long long)ch * (9 * 2 * 3 * NT) + wn) * 1024 + lane * 16; };
 
     half8 a0[3], a1[3];
+    half8 wres[RES > 0 ? 2 * RES : 1][3];
+    if constexpr (RES > 0) {
+#pragma unroll
+        for (int r = 0; r < 2 * RES; ++r)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) wres[r][d] = *reinterpret_cast<const half8*>(wbase(0) + ((r * 3 + d) * NT) * 1024);
+    }
     if (tid < R * 4)
         *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
     issue_dma(0, 0);
+    if constexpr (RES == 0) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(0) + (d * NT) * 1024);
+        for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(0) + (d * NT) * 1024);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -299,6 +314,18 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
 #pragma unroll kTapUnroll
             for (int dydz = 0; dydz < 9; ++dydz) {
                 const char* wrow = wch + (long long)(((a.ablate & 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
+                if constexpr (RES > 0) {
+                    if (dydz < RES) {
+                        compute(dydz, 0, wres[2 * dydz]);
+                        if (dydz == RES - 1) {  // first streamed row's ks = 0 fragments, one body ahead
+#pragma unroll
+                            for (int d = 0; d < 3; ++d)
+                                a0[d] = *reinterpret_cast<const half8*>(wrow + ((6 + d) * NT) * 1024);
+                        }
+                        compute(dydz, 1, wres[2 * dydz + 1]);
+                        continue;
+                    }
+                }
                 if (!(a.ablate & 32) || dydz == 0) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
@@ -325,8 +352,10 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
         __syncthreads();  // every wave is done reading the planes about to be overwritten
         if (have_next) {
             issue_dma(nstep, nch);
+            if constexpr (RES == 0) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(nch) + (d * NT) * 1024);
+                for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(nch) + (d * NT) * 1024);
+            }
             // The DMA must have landed before this wave passes the closing barrier.  vmcnt retires in issue
             // order, so after an epilogue that issues a FIXED number of stores (invalid lanes / planes store to
             // a scratch line instead of branching) `vmcnt(that number)` means "everything older than the
@@ -606,9 +635,9 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
     return 0;
 }
 
-template <int COUT, int XS>
+template <int COUT, int XS, int RES = 0>
 int launch_conv3(const Conv3Args& a, const Plan& p, hipStream_t stream) {
-    auto kern = conv3_kernel<COUT, XS>;
+    auto kern = conv3_kernel<COUT, XS, RES>;
     if (p.lds > 48 * 1024)
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)p.lds));
@@ -728,6 +757,7 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
             const char* e = getenv("SK_CONV_ABLATE");
             a.ablate = e ? atoi(e) : 0;
         }
+        if (cout == 32 && a.nchunks == 1 && !a.ablate) return launch_conv3<32, 4, 3>(a, p, stream);
         if (cout == 32) return launch_conv3<32, 4>(a, p, stream);
         if (cout == 64) return launch_conv3<64, 4>(a, p, stream);
         return launch_conv3<128, 2>(a, p, stream);
