@@ -319,6 +319,20 @@ int sk_train_conv_wgrad(const sk_conv_src* srcs, int n_src, const float* dy, int
 int64_t sk_train_conv_wgrad_workspace_floats(int B, int ox, int oy, int oz, int cout, int cin,
                                              int ksize);
 
+/* Mixed-precision pieces (TrainUNet precision="mixed"): fp16 copies feed the fp16 MFMA kernels.
+ * sk_train_absmax_scale: scale (3 floats, device) <- [2^k, 2^-k, scratch] with max|x| * 2^k in [2^12, 2^13).
+ * sk_train_cast_f32_f16: y = fp16(x * scale[0]) (scale NULL: 1).  sk_train_cast_f16_f32: y (+)= float(x) * scale[1].
+ * sk_train_conv_wgrad_f16: sk_train_conv_wgrad with fp16 sources and fp16 dy (scaled by dy_scale[0], or
+ *   unscaled if dy_scale is NULL) on v_mfma_f32_32x32x16_f16; fp32 partial sums, result multiplied by
+ *   dy_scale[1].  Same workspace size as the fp32 entry point. */
+int sk_train_absmax_scale(const float* x, int64_t n, float* scale, void* stream);
+int sk_train_cast_f32_f16(const float* x, void* y, int64_t n, const float* scale, void* stream);
+int sk_train_cast_f16_f32(const void* x, float* y, int64_t n, const float* scale, int accumulate,
+                          void* stream);
+int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, const float* dy_scale,
+                            int B, int ox, int oy, int oz, int cout, int ksize, float* dweight,
+                            float* dbias, float* workspace, void* stream);
+
 /* coarse (B, cx, cy, cz, C) = 2x2x2 block sums of fine (B, 2cx, 2cy, 2cz, C). */
 int sk_train_sumpool2(const float* fine, float* coarse, int B, int cx, int cy, int cz, int C,
                       void* stream);

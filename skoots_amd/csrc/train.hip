@@ -525,13 +525,188 @@ __global__ void __launch_bounds__(64) wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Mixed-precision pieces (TrainUNet precision="mixed"): fp16 copies of the activations and of the
+// (power-of-two scaled) output gradients feed the fast fp16 MFMA kernels; everything else stays fp32.
+// ------------------------------------------------------------------------------------------
+
+// |x| maximum of a tensor as float bits in *out (atomicMax on the bit pattern: valid for non-negative floats)
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+    float m = 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out, __float_as_uint(m));
+}
+
+// scale[0] = 2^k with max*2^k in [2^12, 2^13) (fp16 headroom for the sums the MFMA forms), scale[1] = 2^-k
+__global__ void scale_from_absmax_kernel(const unsigned* __restrict__ mx, float* __restrict__ scale) {
+    const float m = __uint_as_float(mx[0]);
+    int e = 0;
+    if (m > 0.0f && isfinite(m)) {
+        frexpf(m, &e);          // m = f * 2^e, f in [0.5, 1)
+        e = 13 - e;
+    }
+    e = e > 60 ? 60 : (e < -60 ? -60 : e);
+    scale[0] = ldexpf(1.0f, e);
+    scale[1] = ldexpf(1.0f, -e);
+}
+
+__global__ void __launch_bounds__(256) cast_f32_f16_kernel(const float* __restrict__ x, __half* __restrict__ y, long long n,
+                                                           const float* __restrict__ scale) {
+    const float s = scale ? scale[0] : 1.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = __float2half_rn(x[i] * s);
+}
+
+__global__ void __launch_bounds__(256) cast_f16_f32_kernel(const __half* __restrict__ x, float* __restrict__ y, long long n,
+                                                           const float* __restrict__ scale, int accumulate) {
+    const float s = scale ? scale[1] : 1.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = __half2float(x[i]) * s;
+        y[i] = accumulate ? y[i] + v : v;
+    }
+}
+
+// Weight gradient on v_mfma_f32_32x32x16_f16: as wgrad_kernel, with K = 16 voxels per instruction.  A lane's
+// eight K slots are eight consecutive voxels (lane half h: voxels q + 8h .. q + 8h + 7) of one channel, fetched
+// as 16-bit buffer loads (masked lanes read 0 through the bounds check) and packed in registers.
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+
+struct Wg16Src {
+    const __half* data;  // (B, xs, ys, zs, C) activated input, fp16
+    int C, up, Xs, Ys, Zs;
+};
+
+struct Wgrad16Args {
+    Wg16Src src[2];
+    int nsrc;
+    const __half* dy;  // (B, ox, oy, oz, cout) fp16, scaled
+    float* part;
+    float* part_bias;
+    int B, ox, oy, oz, cout, cin, ksize;
+    int nchunk, nchunk_b, ncot, ncit, ngroup;
+    long long chunk;   // voxels per chunk, multiple of 16
+};
+
+__device__ inline _Float16 buf_load_f16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, 0));
+}
+
+template <int NT>
+__global__ void __launch_bounds__(64) wgrad16_kernel(Wgrad16Args a) {
+    const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
+    int blk = blockIdx.x;
+    const int grp = blk % a.ngroup;
+    blk /= a.ngroup;
+    const int cit = blk % a.ncit;
+    blk /= a.ncit;
+    const int cot = blk % a.ncot;
+    const int chunk = blk / a.ncot;
+    const int b = chunk / a.nchunk_b, cb = chunk % a.nchunk_b;
+    const int k = a.ksize, k3 = k * k * k;
+    const int stride = (k == 3) ? 1 : k, padw = (k == 3) ? 1 : 0;
+    int ci0 = 32 * cit, sidx = 0, cbase = 0;
+    if (a.nsrc == 2 && ci0 >= a.src[0].C) {
+        sidx = 1;
+        cbase = a.src[0].C;
+    }
+    const Wg16Src S = a.src[sidx];
+    const int ci = ci0 - cbase + col;
+    const bool ciok = ci < S.C;
+    const int co = 32 * cot + col;
+    const bool cook = co < a.cout;
+    const int Xf = S.up ? S.Xs * 2 : S.Xs, Yf = S.up ? S.Ys * 2 : S.Ys, Zf = S.up ? S.Zs * 2 : S.Zs;
+    const long long nvox = (long long)a.ox * a.oy * a.oz;
+    const long long svox = (long long)S.Xs * S.Ys * S.Zs;
+    const __amdgpu_buffer_rsrc_t rdy = sk::make_rsrc(a.dy + (long long)b * nvox * a.cout, (unsigned)(nvox * a.cout * 2));
+    const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(S.data + (long long)b * svox * S.C, (unsigned)(svox * S.C * 2));
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float bsum = 0.0f;
+
+    const long long q0 = (long long)cb * a.chunk;
+    long long q1 = q0 + a.chunk;
+    if (q1 > nvox) q1 = nvox;
+    const long long ntrip = (q1 - q0 + 15) / 16;
+
+    // operands of the 16 voxels [qb, qb + 16): this lane fetches voxels qb + 8h + j, j = 0..7
+    auto fetch = [&](long long qb, half8_t& av, half8_t (&bv)[NT]) {
+        long long q = qb + 8 * h;
+        int z = (int)(q % a.oz);
+        long long t2 = q / a.oz;
+        int y = (int)(t2 % a.oy), x = (int)(t2 / a.oy);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = q + j < q1;
+            av[j] = buf_load_f16(rdy, (ok && cook) ? (unsigned)((q + j) * a.cout + co) * 2u : sk::kOob);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int dx = NT == 9 ? grp : (NT == 8 ? (t >> 2) : 0);
+                const int dy = NT == 9 ? t / 3 : (NT == 8 ? ((t >> 1) & 1) : 0);
+                const int dz = NT == 9 ? t % 3 : (NT == 8 ? (t & 1) : 0);
+                int xi = x * stride + dx - padw, yi = y * stride + dy - padw, zi = z * stride + dz - padw;
+                const bool inb = xi >= 0 && xi < Xf && yi >= 0 && yi < Yf && zi >= 0 && zi < Zf;
+                if (S.up) {
+                    xi >>= 1;
+                    yi >>= 1;
+                    zi >>= 1;
+                }
+                const unsigned off = ((unsigned)((xi * S.Ys + yi) * S.Zs + zi) * (unsigned)S.C + (unsigned)ci) * 2u;
+                bv[t][j] = buf_load_f16(rsrc, (ok && inb && ciok) ? off : sk::kOob);
+            }
+            if (++z == a.oz) {
+                z = 0;
+                if (++y == a.oy) {
+                    y = 0;
+                    ++x;
+                }
+            }
+        }
+    };
+    half8_t av_n, bv_n[NT];
+    fetch(q0, av_n, bv_n);
+    for (long long it = 0; it < ntrip; ++it) {
+        const half8_t av = av_n;
+        half8_t bv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t] = bv_n[t];
+        fetch(q0 + 16 * (it + 1), av_n, bv_n);  // past the chunk end every lane is masked: zeros
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum += (float)av[j];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv[t], acc[t], 0, 0, 0);
+    }
+    float* part = a.part + (long long)chunk * a.cout * a.cin * k3;
+    const int cig = ci0 + col;
+    if (ciok) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int tap = grp * NT + t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * cot + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < a.cout) part[((long long)row * a.cin + cig) * k3 + tap] = acc[t][r];
+            }
+        }
+    }
+    if (a.part_bias && cit == 0 && grp == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (h == 0 && cook) a.part_bias[(long long)chunk * a.cout + co] = bsum;
+    }
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int nchunk, long long n,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, const float* __restrict__ scale) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     double s = 0.0;
     for (int c = 0; c < nchunk; ++c) s += (double)part[(long long)c * n + i];
-    out[i] = (float)s;
+    out[i] = scale ? (float)(s * (double)scale[1]) : (float)s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -769,12 +944,97 @@ int sk_train_conv_wgrad(const sk_conv_src* srcs, int n_src, const float* dy, int
     else
         wgrad_kernel<1><<<grid, 64, 0, st>>>(a);
     SK_CHECK_LAUNCH();
-    wgrad_reduce_kernel<<<sk::cdiv(nw, 256), 256, 0, st>>>(a.part, a.nchunk, nw, dweight);
+    wgrad_reduce_kernel<<<sk::cdiv(nw, 256), 256, 0, st>>>(a.part, a.nchunk, nw, dweight, nullptr);
     SK_CHECK_LAUNCH();
     if (dbias) {
-        wgrad_reduce_kernel<<<sk::cdiv(cout, 256), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias);
+        wgrad_reduce_kernel<<<sk::cdiv(cout, 256), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, nullptr);
         SK_CHECK_LAUNCH();
     }
+    return SK_OK;
+}
+
+int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, const float* dy_scale, int B, int ox, int oy,
+                            int oz, int cout, int ksize, float* dweight, float* dbias, float* workspace, void* stream) {
+    SK_CHECK_ARG(srcs && dy && dweight && workspace, "sk_train_conv_wgrad_f16: NULL pointer");
+    SK_CHECK_ARG(n_src == 1 || n_src == 2, "sk_train_conv_wgrad_f16: n_src must be 1 or 2");
+    SK_CHECK_ARG(ksize == 1 || ksize == 2 || ksize == 3, "sk_train_conv_wgrad_f16: ksize must be 1, 2 or 3");
+    SK_CHECK_ARG(B >= 1 && ox >= 1 && oy >= 1 && oz >= 1 && cout >= 1, "sk_train_conv_wgrad_f16: bad extents");
+    Wgrad16Args a{};
+    a.nsrc = n_src;
+    for (int i = 0; i < n_src; ++i) {
+        SK_CHECK_ARG(srcs[i].data && srcs[i].c > 0 && srcs[i].affine == nullptr, "sk_train_conv_wgrad_f16: bad source %d", i);
+        SK_CHECK_ARG(n_src == 1 || srcs[i].c % 32 == 0, "sk_train_conv_wgrad_f16: two sources need c %% 32 == 0");
+        int up = srcs[i].upsample ? 1 : 0;
+        SK_CHECK_ARG(!up || (ksize == 3 && ox % 2 == 0 && oy % 2 == 0 && oz % 2 == 0),
+                     "sk_train_conv_wgrad_f16: upsampled source needs ksize 3 and even output extents");
+        a.src[i].data = (const __half*)srcs[i].data;
+        a.src[i].C = srcs[i].c;
+        a.src[i].up = up;
+        int s = (ksize == 3) ? 1 : ksize;
+        a.src[i].Xs = up ? ox / 2 : ox * s;
+        a.src[i].Ys = up ? oy / 2 : oy * s;
+        a.src[i].Zs = up ? oz / 2 : oz * s;
+        a.cin += srcs[i].c;
+        SK_CHECK_ARG((long long)a.src[i].Xs * a.src[i].Ys * a.src[i].Zs * a.src[i].C * 2 < (1LL << 32),
+                     "sk_train_conv_wgrad_f16: source %d of one batch item must be < 4 GiB", i);
+    }
+    SK_CHECK_ARG((long long)ox * oy * oz * cout * 2 < (1LL << 32), "sk_train_conv_wgrad_f16: dy of one batch item must be < 4 GiB");
+    a.dy = (const __half*)dy;
+    a.B = B;
+    a.ox = ox;
+    a.oy = oy;
+    a.oz = oz;
+    a.cout = cout;
+    a.ksize = ksize;
+    a.ncot = (cout + 31) / 32;
+    a.ncit = (a.cin + 31) / 32;
+    wgrad_plan(B, ox, oy, oz, cout, a.cin, ksize, &a.nchunk, &a.nchunk_b, &a.chunk, &a.ngroup);
+    a.chunk = (a.chunk + 15) & ~15LL;  // whole 16-voxel MFMA steps; the chunk count of the plan still covers the volume
+    const long long nw = (long long)cout * a.cin * ksize * ksize * ksize;
+    a.part = workspace;
+    a.part_bias = dbias ? workspace + (long long)a.nchunk * nw : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((long long)a.nchunk * a.ncot * a.ncit * a.ngroup);
+    if (ksize == 3)
+        wgrad16_kernel<9><<<grid, 64, 0, st>>>(a);
+    else if (ksize == 2)
+        wgrad16_kernel<8><<<grid, 64, 0, st>>>(a);
+    else
+        wgrad16_kernel<1><<<grid, 64, 0, st>>>(a);
+    SK_CHECK_LAUNCH();
+    wgrad_reduce_kernel<<<sk::cdiv(nw, 256), 256, 0, st>>>(a.part, a.nchunk, nw, dweight, dy_scale);
+    SK_CHECK_LAUNCH();
+    if (dbias) {
+        wgrad_reduce_kernel<<<sk::cdiv(cout, 256), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, dy_scale);
+        SK_CHECK_LAUNCH();
+    }
+    return SK_OK;
+}
+
+int sk_train_absmax_scale(const float* x, int64_t n, float* scale, void* stream) {
+    SK_CHECK_ARG(x && scale && n >= 1, "sk_train_absmax_scale: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* mx = reinterpret_cast<unsigned*>(scale + 2);  // scale: 3 floats; [2] is the max's bit pattern
+    SK_CHECK_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned), st));
+    absmax_kernel<<<sk::stream_grid(n, 256, 8), 256, 0, st>>>(x, n, mx);
+    SK_CHECK_LAUNCH();
+    scale_from_absmax_kernel<<<1, 1, 0, st>>>(mx, scale);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_train_cast_f32_f16(const float* x, void* y, int64_t n, const float* scale, void* stream) {
+    SK_CHECK_ARG(x && y && n >= 1, "sk_train_cast_f32_f16: bad arguments");
+    cast_f32_f16_kernel<<<sk::stream_grid(n, 256, 4), 256, 0, (hipStream_t)stream>>>(x, (__half*)y, n, scale);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_train_cast_f16_f32(const void* x, float* y, int64_t n, const float* scale, int accumulate, void* stream) {
+    SK_CHECK_ARG(x && y && n >= 1, "sk_train_cast_f16_f32: bad arguments");
+    cast_f16_f32_kernel<<<sk::stream_grid(n, 256, 4), 256, 0, (hipStream_t)stream>>>((const __half*)x, y, n, scale,
+                                                                                     accumulate ? 1 : 0);
+    SK_CHECK_LAUNCH();
     return SK_OK;
 }
 

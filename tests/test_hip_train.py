@@ -201,6 +201,49 @@ def test_conv_backward(ffi, B, osp, srcdef, cout, ksize):
         lo += c
 
 
+@pytest.mark.parametrize("B,osp,srcdef,cout,ksize", BWD_CASES)
+def test_conv_wgrad_f16(ffi, B, osp, srcdef, cout, ksize):
+    """fp16-operand weight gradient (mixed precision): against torch autograd on the SAME fp16-rounded operands
+    (tight: only the summation order differs) with a tiny-magnitude dy that needs the power-of-two scale."""
+    gen = torch.Generator().manual_seed(cout * 3 + ksize + osp[1])
+    srcs_cpu, srcs_dev = [], []
+    for c, up in srcdef:
+        s = 2 if ksize == 2 else 1
+        sp = tuple(v // 2 for v in osp) if up else tuple(v * s for v in osp)
+        t = torch.randn((B, c) + sp, generator=gen).half()
+        srcs_cpu.append((t.float(), up))
+        srcs_dev.append((_cl(t).to(DEV), up))
+    cin = sum(c for c, _ in srcdef)
+    w = torch.zeros((cout, cin, ksize, ksize, ksize), requires_grad=True)
+    bias = torch.zeros(cout, requires_grad=True)
+    x = torch.cat([F.interpolate(t, scale_factor=2, mode="nearest") if up else t for t, up in srcs_cpu], dim=1)
+    y = F.conv3d(x, w, bias, padding=1) if ksize == 3 else F.conv3d(x, w, bias, stride=ksize)
+    dy = torch.randn(y.shape, generator=gen) * 3e-7
+    st = ffi.stream_ptr(torch.device(DEV))
+    dyc = _cl(dy).to(DEV)
+    scale = torch.zeros(3, device=DEV)
+    ffi.check(ffi.lib.sk_train_absmax_scale(ffi.ptr(dyc), dyc.numel(), ffi.ptr(scale), st))
+    sc = scale.cpu()
+    assert 4096 <= dy.abs().max().item() * sc[0].item() < 8192 and abs(sc[0].item() * sc[1].item() - 1) < 1e-6
+    dy16 = torch.empty(dyc.shape, dtype=torch.float16, device=DEV)
+    ffi.check(ffi.lib.sk_train_cast_f32_f16(ffi.ptr(dyc), ffi.ptr(dy16), dyc.numel(), ffi.ptr(scale), st))
+    y.backward(_cf(dy16.cpu().float()) * sc[1])  # the reference sees the same rounded dy
+    arr = (ffi.ConvSrc * len(srcs_dev))()
+    for i, (t, up) in enumerate(srcs_dev):
+        arr[i].data, arr[i].affine, arr[i].c, arr[i].upsample = t.data_ptr(), None, t.shape[-1], up
+    dw, dbias = torch.empty(w.shape, device=DEV), torch.empty(cout, device=DEV)
+    ox, oy, oz = osp
+    ws = torch.empty(int(ffi.lib.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, cout, cin, ksize)), device=DEV)
+    ffi.check(ffi.lib.sk_train_conv_wgrad_f16(arr, len(srcs_dev), ffi.ptr(dy16), ffi.ptr(scale), B, ox, oy, oz, cout, ksize,
+                                              ffi.ptr(dw), ffi.ptr(dbias), ffi.ptr(ws), st))
+    _close(dw, w.grad, 1e-4, "dweight (fp16 operands)")
+    _close(dbias, bias.grad, 1e-4, "dbias (fp16 operands)")
+    # and the round trip of the casts
+    back = torch.zeros(dyc.shape, device=DEV)
+    ffi.check(ffi.lib.sk_train_cast_f16_f32(ffi.ptr(dy16), ffi.ptr(back), dyc.numel(), ffi.ptr(scale), 0, st))
+    _close(back, dyc, 1e-3, "cast round trip")
+
+
 def test_adamw_matches_torch(ffi):
     gen = torch.Generator().manual_seed(5)
     n = 10007
