@@ -324,14 +324,23 @@ int64_t sk_train_conv_wgrad_workspace_floats(int B, int ox, int oy, int oz, int 
  * sk_train_cast_f32_f16: y = fp16(x * scale[0]) (scale NULL: 1).  sk_train_cast_f16_f32: y (+)= float(x) * scale[1].
  * sk_train_conv_wgrad_f16: sk_train_conv_wgrad with fp16 sources and fp16 dy (scaled by dy_scale[0], or
  *   unscaled if dy_scale is NULL) on v_mfma_f32_32x32x16_f16; fp32 partial sums, result multiplied by
- *   dy_scale[1].  Same workspace size as the fp32 entry point. */
+ *   dy_scale[1].  Same workspace size as the fp32 entry point.  zero_page (>= 1 KiB of zeros, or NULL):
+ *   with it and channel counts % 32 == 0 the operands move as whole 64-byte lines (LDS-DMA + ds_read_b64_tr_b16).
+ * sk_train_pack_weight: device-side sk_conv3d_pack_weight_host of the CURRENT fp32 weight (Co, Ci, k, k, k);
+ *   transposed != 0 packs the data-gradient operator of input channels [c_lo, c_lo + c_n) instead
+ *   (rows = those input channels, K = Co, taps flipped).  dst: k^3 * (cin_eff/16) * (cout_eff/32) KiB.
+ * sk_train_gn_silu_mixed: raw fp16 conv output -> y32 (raw), z32 and z16 (GroupNorm affine + SiLU). */
+int sk_train_pack_weight(const float* weight, int Co, int Ci, int ksize, int transposed, int c_lo,
+                         int c_n, void* dst, void* stream);
+int sk_train_gn_silu_mixed(const void* y16, const float* affine, float* y32, float* z32, void* z16,
+                           int B, int64_t voxels, int C, void* stream);
 int sk_train_absmax_scale(const float* x, int64_t n, float* scale, void* stream);
 int sk_train_cast_f32_f16(const float* x, void* y, int64_t n, const float* scale, void* stream);
 int sk_train_cast_f16_f32(const void* x, float* y, int64_t n, const float* scale, int accumulate,
                           void* stream);
 int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, const float* dy_scale,
                             int B, int ox, int oy, int oz, int cout, int ksize, float* dweight,
-                            float* dbias, float* workspace, void* stream);
+                            float* dbias, float* workspace, const void* zero_page, void* stream);
 
 /* coarse (B, cx, cy, cz, C) = 2x2x2 block sums of fine (B, 2cx, 2cy, 2cz, C). */
 int sk_train_sumpool2(const float* fine, float* coarse, int B, int cx, int cy, int cz, int C,

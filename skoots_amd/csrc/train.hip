@@ -700,6 +700,221 @@ __global__ void __launch_bounds__(64) wgrad16_kernel(Wgrad16Args a) {
     }
 }
 
+// The same reduction with whole 16-byte lines: an operand tile of a 16-voxel step is [16 voxels][32 channels]
+// fp16 = 1 KiB = ONE LDS-DMA wave instruction (lane = voxel*4 + 8-channel chunk, channels-last lines as they lie
+// in HBM), and the K-major fragment the MFMA wants (8 voxels of one channel per lane) comes out of LDS with two
+// ds_read_b64_tr_b16 (hardware transpose: per 16-lane group a block of 4 rows x 16 columns, column-major).
+// 10 loads per step instead of 80 16-bit loads; tiles double-buffered, next step's DMA in flight under the MFMAs.
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));  // the builtin's own vector type
+
+__device__ __forceinline__ void dma16_tile(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ half8_t tr_read_frag(const char* tile, int lane) {
+    // lane l: group g = l >> 4 -> channels 16*(g&1) .. +15, voxel half h = g >> 1; lane 4q+p of the group supplies
+    // the address of row (voxel) q, columns 4p .. 4p+3 and receives column (l & 15) of the four rows
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const char* base = tile + (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * p) * 2;
+    // (the _v4i16 form of the builtin miscompiles the element extraction on ROCm 7.2: all four lanes of the result
+    // read element 0; the _v4f16 form is correct)
+    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)base);
+    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + 4 * 64));
+    half8_t r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = (_Float16)lo[j];
+        r[4 + j] = (_Float16)hi[j];
+    }
+    return r;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(64) wgrad16t_kernel(Wgrad16Args a, const char* zero_page) {
+    __shared__ __attribute__((aligned(16))) char tiles[2][(NT + 1) * 1024];
+    const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
+    const int lv = lane >> 2, lc = lane & 3;  // DMA role: voxel of the step, 8-channel chunk
+    int blk = blockIdx.x;
+    const int grp = blk % a.ngroup;
+    blk /= a.ngroup;
+    const int cit = blk % a.ncit;
+    blk /= a.ncit;
+    const int cot = blk % a.ncot;
+    const int chunk = blk / a.ncot;
+    const int b = chunk / a.nchunk_b, cb = chunk % a.nchunk_b;
+    const int k = a.ksize, k3 = k * k * k;
+    const int stride = (k == 3) ? 1 : k, padw = (k == 3) ? 1 : 0;
+    int ci0 = 32 * cit, sidx = 0, cbase = 0;
+    if (a.nsrc == 2 && ci0 >= a.src[0].C) {
+        sidx = 1;
+        cbase = a.src[0].C;
+    }
+    const Wg16Src S = a.src[sidx];
+    const int Xf = S.up ? S.Xs * 2 : S.Xs, Yf = S.up ? S.Ys * 2 : S.Ys, Zf = S.up ? S.Zs * 2 : S.Zs;
+    const long long nvox = (long long)a.ox * a.oy * a.oz;
+    const long long svox = (long long)S.Xs * S.Ys * S.Zs;
+    const char* dyb = reinterpret_cast<const char*>(a.dy + (long long)b * nvox * a.cout) + (32 * cot + 8 * lc) * 2;
+    const char* sb = reinterpret_cast<const char*>(S.data + (long long)b * svox * S.C) + (ci0 - cbase + 8 * lc) * 2;
+    const char* zp = zero_page + lane * 16;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float bsum = 0.0f;
+
+    const long long q0 = (long long)cb * a.chunk;
+    long long q1 = q0 + a.chunk;
+    if (q1 > nvox) q1 = nvox;
+    const int ntrip = q1 > q0 ? (int)((q1 - q0 + 15) / 16) : 0;
+    // this lane's DMA voxel walks q0 + lv, q0 + lv + 16, ...
+    long long q = q0 + lv;
+    int z = (int)(q % a.oz);
+    long long t2 = q / a.oz;
+    int y = (int)(t2 % a.oy), x = (int)(t2 / a.oy);
+
+    auto issue = [&](int buf) {
+        char* tb = tiles[buf];
+        const bool ok = q < q1;
+        dma16_tile(ok ? dyb + q * a.cout * 2 : zp, tb);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int dx = NT == 9 ? grp : (NT == 8 ? (t >> 2) : 0);
+            const int dy = NT == 9 ? t / 3 : (NT == 8 ? ((t >> 1) & 1) : 0);
+            const int dz = NT == 9 ? t % 3 : (NT == 8 ? (t & 1) : 0);
+            int xi = x * stride + dx - padw, yi = y * stride + dy - padw, zi = z * stride + dz - padw;
+            const bool inb = ok && xi >= 0 && xi < Xf && yi >= 0 && yi < Yf && zi >= 0 && zi < Zf;
+            if (S.up) {
+                xi >>= 1;
+                yi >>= 1;
+                zi >>= 1;
+            }
+            dma16_tile(inb ? sb + (long long)((xi * S.Ys + yi) * S.Zs + zi) * S.C * 2 : zp, tb + (t + 1) * 1024);
+        }
+        q += 16;
+        z += 16;
+        while (z >= a.oz) {
+            z -= a.oz;
+            ++y;
+        }
+        while (y >= a.oy) {
+            y -= a.oy;
+            ++x;
+        }
+    };
+    if (ntrip > 0) issue(0);
+    for (int it = 0; it < ntrip; ++it) {
+        const bool more = it + 1 < ntrip;
+        if (more) {
+            issue((it + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT + 1) : "memory");  // this step's tiles have landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const char* tb = tiles[it & 1];
+        const half8_t av = tr_read_frag(tb, lane);
+        half8_t bv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t] = tr_read_frag(tb + (t + 1) * 1024, lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum += (float)av[j];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv[t], acc[t], 0, 0, 0);
+        // the tile buffer is reused by the DMA issued at the top of the next-but-one iteration; every read of it
+        // has completed by then (the MFMAs above consumed them)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    float* part = a.part + (long long)chunk * a.cout * a.cin * k3;
+    const int cig = ci0 + col;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = grp * NT + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * cot + (r & 3) + 8 * (r >> 2) + 4 * h;
+            part[((long long)row * a.cin + cig) * k3 + tap] = acc[t][r];
+        }
+    }
+    if (a.part_bias && cit == 0 && grp == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (h == 0) a.part_bias[(long long)chunk * a.cout + 32 * cot + col] = bsum;
+    }
+}
+
+// Device-side counterpart of sk_conv3d_pack_weight_host (weights change every step in training): fp32
+// torch-layout weight -> fp16 MFMA A fragments.  `transposed`: pack the data-gradient operator instead,
+// W'[co'][ci'][tap] = W[ci'][c_lo + co'][flipped tap]  (co' < eff_cout input channels of the layer, ci' <
+// eff_cin = the layer's output channels).  One thread per fp16 element.
+struct PackArgs {
+    const float* w;  // (Co, Ci, k, k, k)
+    __half* dst;
+    int Co, Ci, ksize, eff_cout, eff_cin, transposed, c_lo;
+    long long n;     // halves to write
+};
+
+__global__ void __launch_bounds__(256) pack_weight_kernel(PackArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+    long long f = i >> 9;  // fragment index
+    const int NT = a.eff_cout / 32, k = a.ksize, k3 = k * k * k;
+    int nt, c0, kx, ky, kz;
+    if (k == 3) {  // [chunk32][dy*3+dz][ks][dx][nt]
+        nt = (int)(f % NT);
+        f /= NT;
+        const int dx = (int)(f % 3);
+        f /= 3;
+        const int ks = (int)(f % 2);
+        f /= 2;
+        const int dydz = (int)(f % 9);
+        const int ch = (int)(f / 9);
+        c0 = ch * 32 + ks * 16;
+        kx = dx;
+        ky = dydz / 3;
+        kz = dydz % 3;
+    } else {       // [tap][ks][nt]
+        nt = (int)(f % NT);
+        f /= NT;
+        const int nks = a.eff_cin / 16;
+        const int ks = (int)(f % nks);
+        const int tap = (int)(f / nks);
+        c0 = ks * 16;
+        kx = tap / (k * k);
+        ky = (tap / k) % k;
+        kz = tap % k;
+    }
+    const int co = 32 * nt + (l & 31), ci = c0 + 8 * (l >> 5) + j;
+    int tap = (kx * k + ky) * k + kz;
+    long long src;
+    if (a.transposed) {
+        tap = k3 - 1 - tap;
+        src = ((long long)ci * a.Ci + a.c_lo + co) * k3 + tap;
+    } else {
+        src = ((long long)co * a.Ci + ci) * k3 + tap;
+    }
+    a.dst[i] = __float2half_rn(a.w[src]);
+}
+
+// GroupNorm affine + SiLU of a RAW fp16 conv output, writing what the mixed-precision step keeps:
+// y32 (raw, for the backward), z32 (activated) and z16 (activated, the next fast conv's source).
+__global__ void __launch_bounds__(256) gn_silu_mixed_kernel(const __half* __restrict__ y16, const float* __restrict__ affine,
+                                                            float* __restrict__ y32, float* __restrict__ z32,
+                                                            __half* __restrict__ z16, int C, long long n_per_batch) {
+    const int b = blockIdx.y;
+    const long long off = (long long)b * n_per_batch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_per_batch; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float yv = __half2float(y16[off + i]);
+        const float u = fmaf(affine[(long long)b * 2 * C + c], yv, affine[(long long)b * 2 * C + C + c]);
+        const float z = u / (1.0f + expf(-u));
+        y32[off + i] = yv;
+        z32[off + i] = z;
+        z16[off + i] = __float2half_rn(z);
+    }
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int nchunk, long long n,
                                                            float* __restrict__ out, const float* __restrict__ scale) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -954,7 +1169,8 @@ int sk_train_conv_wgrad(const sk_conv_src* srcs, int n_src, const float* dy, int
 }
 
 int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, const float* dy_scale, int B, int ox, int oy,
-                            int oz, int cout, int ksize, float* dweight, float* dbias, float* workspace, void* stream) {
+                            int oz, int cout, int ksize, float* dweight, float* dbias, float* workspace,
+                            const void* zero_page, void* stream) {
     SK_CHECK_ARG(srcs && dy && dweight && workspace, "sk_train_conv_wgrad_f16: NULL pointer");
     SK_CHECK_ARG(n_src == 1 || n_src == 2, "sk_train_conv_wgrad_f16: n_src must be 1 or 2");
     SK_CHECK_ARG(ksize == 1 || ksize == 2 || ksize == 3, "sk_train_conv_wgrad_f16: ksize must be 1, 2 or 3");
@@ -995,7 +1211,16 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
     a.part_bias = dbias ? workspace + (long long)a.nchunk * nw : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((long long)a.nchunk * a.ncot * a.ncit * a.ngroup);
-    if (ksize == 3)
+    bool lines = zero_page != nullptr && cout % 32 == 0;  // whole 64-byte channel lines: LDS-DMA + transposed reads
+    for (int i = 0; i < n_src; ++i) lines = lines && srcs[i].c % 32 == 0;
+    if (lines) {
+        if (ksize == 3)
+            wgrad16t_kernel<9><<<grid, 64, 0, st>>>(a, (const char*)zero_page);
+        else if (ksize == 2)
+            wgrad16t_kernel<8><<<grid, 64, 0, st>>>(a, (const char*)zero_page);
+        else
+            wgrad16t_kernel<1><<<grid, 64, 0, st>>>(a, (const char*)zero_page);
+    } else if (ksize == 3)
         wgrad16_kernel<9><<<grid, 64, 0, st>>>(a);
     else if (ksize == 2)
         wgrad16_kernel<8><<<grid, 64, 0, st>>>(a);
@@ -1008,6 +1233,40 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
         wgrad_reduce_kernel<<<sk::cdiv(cout, 256), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, dy_scale);
         SK_CHECK_LAUNCH();
     }
+    return SK_OK;
+}
+
+int sk_train_pack_weight(const float* weight, int Co, int Ci, int ksize, int transposed, int c_lo, int c_n, void* dst,
+                         void* stream) {
+    SK_CHECK_ARG(weight && dst && (ksize == 1 || ksize == 2 || ksize == 3), "sk_train_pack_weight: bad arguments");
+    const int eff_cout = transposed ? c_n : Co, eff_cin = transposed ? Co : Ci;
+    SK_CHECK_ARG(!transposed || (c_lo >= 0 && c_n >= 1 && c_lo + c_n <= Ci), "sk_train_pack_weight: bad channel range");
+    SK_CHECK_ARG(transposed || (c_lo == 0 && c_n == Ci), "sk_train_pack_weight: a channel range needs transposed");
+    SK_CHECK_ARG(eff_cout % 32 == 0 && eff_cin % (ksize == 3 ? 32 : 16) == 0,
+                 "sk_train_pack_weight: unsupported shape cout=%d cin=%d k=%d", eff_cout, eff_cin, ksize);
+    PackArgs a{};
+    a.w = weight;
+    a.dst = (__half*)dst;
+    a.Co = Co;
+    a.Ci = Ci;
+    a.ksize = ksize;
+    a.eff_cout = eff_cout;
+    a.eff_cin = eff_cin;
+    a.transposed = transposed ? 1 : 0;
+    a.c_lo = c_lo;
+    a.n = (long long)ksize * ksize * ksize * (eff_cin / 16) * (eff_cout / 32) * 512;
+    pack_weight_kernel<<<sk::cdiv(a.n, 256), 256, 0, (hipStream_t)stream>>>(a);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_train_gn_silu_mixed(const void* y16, const float* affine, float* y32, float* z32, void* z16, int B, int64_t voxels,
+                           int C, void* stream) {
+    SK_CHECK_ARG(y16 && affine && y32 && z32 && z16 && C > 0, "sk_train_gn_silu_mixed: bad arguments");
+    long long n = voxels * C;
+    gn_silu_mixed_kernel<<<dim3(sk::stream_grid(n, 256, 4), B), 256, 0, (hipStream_t)stream>>>(
+        (const __half*)y16, affine, y32, z32, (__half*)z16, C, n);
+    SK_CHECK_LAUNCH();
     return SK_OK;
 }
 
@@ -1059,3 +1318,4 @@ int sk_train_adamw(float* param, const float* grad, float* exp_avg, float* exp_a
 }
 
 }  // extern "C"
+

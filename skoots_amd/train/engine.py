@@ -47,7 +47,15 @@ class TrainUNet:
     what the backward needs; ``backward(dlogits)`` fills ``flat_grad``."""
 
     def __init__(self, state_dict: Dict[str, Tensor], device="cuda:0",
-                 dims: Sequence[int] = (32, 64, 128, 64, 32), depths: Sequence[int] = (2, 2, 2, 2, 2)):
+                 dims: Sequence[int] = (32, 64, 128, 64, 32), depths: Sequence[int] = (2, 2, 2, 2, 2),
+                 precision: str = "fp32"):
+        """``precision``: "fp32" (every kernel fp32; the parity mode) or "mixed" (fp32 master weights, GroupNorm,
+        loss and optimizer; the convolutions of the forward pass, the data gradients and the weight gradients
+        on the fp16 MFMA kernels with fp32 accumulation, output gradients scaled per tensor by a power of
+        two -- the counterpart of the reference's bf16 step, engine.py:68,107-109)."""
+        if precision not in ("fp32", "mixed"):
+            raise ValueError("precision must be 'fp32' or 'mixed'")
+        self.precision = precision
         self.device = torch.device(device)
         self.dims, self.depths = tuple(dims), tuple(depths)
 
@@ -99,6 +107,9 @@ class TrainUNet:
                 raise ValueError(f"{l.name}: weight shape {tuple(l.weight.shape)} does not fit ksize {l.ksize}")
         self._tape: List[tuple] = []
         self._ws: Optional[Tensor] = None
+        self._half: Dict[int, Tensor] = {}   # data_ptr of an fp32 activation -> its fp16 twin (mixed mode)
+        self._zero_page = torch.zeros(4096, dtype=torch.uint8, device=self.device)
+        self._zero_bias = torch.zeros(128, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------------------
     def state_dict(self) -> Dict[str, Tensor]:
@@ -124,7 +135,68 @@ class TrainUNet:
         return arr
 
     # ------------------------------------------------------------------------------
+    # -- mixed precision helpers ------------------------------------------------------------
+    def _fast(self, layer: _Layer, srcs) -> bool:
+        """The fp16 MFMA kernels take this layer: GroupNorm block, widths 32/64/128, channel counts % 32."""
+        return (self.precision == "mixed" and layer.norm and layer.cout in (32, 64, 128) and
+                all(t.shape[-1] % 32 == 0 for t, _ in srcs))
+
+    def _pack(self, layer: _Layer, transposed: bool = False, c_lo: int = 0, c_n: Optional[int] = None) -> Tensor:
+        c_n = layer.cin if c_n is None else c_n
+        cout_eff, cin_eff = (c_n, layer.cout) if transposed else (layer.cout, layer.cin)
+        buf = torch.empty(layer.ksize ** 3 * (cin_eff // 16) * (cout_eff // 32) * 1024, dtype=torch.uint8, device=self.device)
+        _ffi.check(_ffi.lib.sk_train_pack_weight(_ffi.ptr(layer.weight), layer.cout, layer.cin, layer.ksize, int(transposed),
+                                                 c_lo, c_n, _ffi.ptr(buf), _ffi.stream_ptr(self.device)))
+        return buf
+
+    def _to_half(self, t: Tensor, scale: Optional[Tensor] = None) -> Tensor:
+        h = torch.empty(t.shape, dtype=torch.float16, device=self.device)
+        _ffi.check(_ffi.lib.sk_train_cast_f32_f16(_ffi.ptr(t), _ffi.ptr(h), t.numel(), _ffi.ptr(scale),
+                                                  _ffi.stream_ptr(self.device)))
+        return h
+
+    def _fast_conv(self, srcs16: List[Tuple[Tensor, int]], packed: Tensor, bias: Tensor, out_shape, cout: int, ksize: int,
+                   partial: Optional[Tensor]) -> Tensor:
+        B = srcs16[0][0].shape[0]
+        ox, oy, oz = out_shape
+        y16 = torch.empty((B, ox, oy, oz, cout), dtype=torch.float16, device=self.device)
+        _ffi.check(_ffi.lib.sk_conv3d(self._srcs(srcs16), len(srcs16), _ffi.ptr(packed), _ffi.ptr(bias), _ffi.ptr(y16), B,
+                                      ox, oy, oz, cout, ksize, _ffi.ptr(partial), _ffi.ptr(self._zero_page),
+                                      _ffi.stream_ptr(self.device)))
+        return y16
+
+    def _block_mixed(self, layer: _Layer, srcs: List[Tuple[Tensor, int]], out_shape: Tuple[int, int, int]) -> Tensor:
+        B = srcs[0][0].shape[0]
+        ox, oy, oz = out_shape
+        st = _ffi.stream_ptr(self.device)
+        srcs16 = [(self._half[t.data_ptr()], up) for t, up in srcs]
+        nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, layer.cout, layer.ksize)
+        partial = torch.empty((B, nblk, layer.cout // 4, 2), dtype=torch.float32, device=self.device)
+        y16 = self._fast_conv(srcs16, self._pack(layer), layer.bias, out_shape, layer.cout, layer.ksize, partial)
+        vox = ox * oy * oz
+        affine = torch.empty((B, 2, layer.cout), dtype=torch.float32, device=self.device)
+        stats = torch.empty((B, GN_GROUPS, 2), dtype=torch.float32, device=self.device)
+        _ffi.check(_ffi.lib.sk_groupnorm_finalize_stats(_ffi.ptr(partial), B, nblk, GN_GROUPS, layer.cout, vox,
+                                                        _ffi.ptr(layer.gamma), _ffi.ptr(layer.beta), GN_EPS,
+                                                        _ffi.ptr(affine), _ffi.ptr(stats), st))
+        y = torch.empty((B, ox, oy, oz, layer.cout), dtype=torch.float32, device=self.device)
+        z = torch.empty_like(y)
+        z16 = torch.empty_like(y16)
+        _ffi.check(_ffi.lib.sk_train_gn_silu_mixed(_ffi.ptr(y16), _ffi.ptr(affine), _ffi.ptr(y), _ffi.ptr(z), _ffi.ptr(z16),
+                                                   B, vox, layer.cout, st))
+        self._half[z.data_ptr()] = z16
+        self._tape.append((layer, srcs, y, affine, stats, z))
+        return z
+
     def _block(self, layer: _Layer, srcs: List[Tuple[Tensor, int]], out_shape: Tuple[int, int, int]) -> Tensor:
+        if self._fast(layer, srcs):
+            return self._block_mixed(layer, srcs, out_shape)
+        z = self._block_fp32(layer, srcs, out_shape)
+        if self.precision == "mixed" and layer.norm:
+            self._half[z.data_ptr()] = self._to_half(z)   # the stem's output feeds a fast layer
+        return z
+
+    def _block_fp32(self, layer: _Layer, srcs: List[Tuple[Tensor, int]], out_shape: Tuple[int, int, int]) -> Tensor:
         B = srcs[0][0].shape[0]
         ox, oy, oz = out_shape
         st = _ffi.stream_ptr(self.device)
@@ -163,6 +235,7 @@ class TrainUNet:
             raise ValueError("crop extents must be multiples of 4 (two stride-2 levels)")
         L0, L1, L2 = (X, Y, Z), (X // 2, Y // 2, Z // 2), (X // 4, Y // 4, Z // 4)
         self._tape = []
+        self._half = {}
         self._image = x
         a = x
         for l in self.enc0:
@@ -199,10 +272,21 @@ class TrainUNet:
                                                          _ffi.ptr(layer.gamma), B, vox, cout, GN_GROUPS, _ffi.ptr(dz),
                                                          _ffi.ptr(layer.g_gamma), _ffi.ptr(layer.g_beta), _ffi.ptr(ws), st))
             dy = dz
+            fast = self._fast(layer, srcs)
             ws = self._workspace(_ffi.lib.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, cout, layer.cin, layer.ksize))
-            _ffi.check(_ffi.lib.sk_train_conv_wgrad(self._srcs(srcs), len(srcs), _ffi.ptr(dy), B, ox, oy, oz, cout,
-                                                    layer.ksize, _ffi.ptr(layer.g_weight), _ffi.ptr(layer.g_bias),
-                                                    _ffi.ptr(ws), st))
+            if fast:
+                # fp16 twin of dy, scaled by a power of two so that its maximum sits at 2^12..2^13
+                scale = torch.empty(3, dtype=torch.float32, device=self.device)
+                _ffi.check(_ffi.lib.sk_train_absmax_scale(_ffi.ptr(dy), dy.numel(), _ffi.ptr(scale), st))
+                dy16 = self._to_half(dy, scale)
+                srcs16 = [(self._half[t.data_ptr()], up) for t, up in srcs]
+                _ffi.check(_ffi.lib.sk_train_conv_wgrad_f16(self._srcs(srcs16), len(srcs16), _ffi.ptr(dy16), _ffi.ptr(scale), B,
+                                                            ox, oy, oz, cout, layer.ksize, _ffi.ptr(layer.g_weight),
+                                                            _ffi.ptr(layer.g_bias), _ffi.ptr(ws), _ffi.ptr(self._zero_page), st))
+            else:
+                _ffi.check(_ffi.lib.sk_train_conv_wgrad(self._srcs(srcs), len(srcs), _ffi.ptr(dy), B, ox, oy, oz, cout,
+                                                        layer.ksize, _ffi.ptr(layer.g_weight), _ffi.ptr(layer.g_bias),
+                                                        _ffi.ptr(ws), st))
             lo = 0
             for t, up in srcs:
                 c = t.shape[-1]
@@ -216,6 +300,25 @@ class TrainUNet:
                         grads[key] = torch.empty_like(t)
                     _ffi.check(_ffi.lib.sk_train_conv_dgrad(_ffi.ptr(dy), _ffi.ptr(layer.weight), _ffi.ptr(grads[key]), B,
                                                             ox, oy, oz, cout, layer.cin, 0, layer.cin, 2, int(have), st))
+                elif fast and c in (32, 64, 128):
+                    # data gradient on the fast conv kernel: the layer's weight packed transposed + tap-flipped
+                    dx16 = self._fast_conv([(dy16, 0)], self._pack(layer, True, lo, c), self._zero_bias, (ox, oy, oz), c,
+                                           layer.ksize, None)
+                    if up:
+                        if key in grads:
+                            raise RuntimeError("an upsampled tensor has one consumer in this graph")
+                        fine = torch.empty((B, ox, oy, oz, c), dtype=torch.float32, device=self.device)
+                        _ffi.check(_ffi.lib.sk_train_cast_f16_f32(_ffi.ptr(dx16), _ffi.ptr(fine), fine.numel(), _ffi.ptr(scale),
+                                                                  0, st))
+                        grads[key] = torch.empty_like(t)
+                        _ffi.check(_ffi.lib.sk_train_sumpool2(_ffi.ptr(fine), _ffi.ptr(grads[key]), B, ox // 2, oy // 2,
+                                                              oz // 2, c, st))
+                    else:
+                        have = key in grads
+                        if not have:
+                            grads[key] = torch.empty_like(t)
+                        _ffi.check(_ffi.lib.sk_train_cast_f16_f32(_ffi.ptr(dx16), _ffi.ptr(grads[key]), t.numel(),
+                                                                  _ffi.ptr(scale), int(have), st))
                 elif up:
                     fine = torch.empty((B, ox, oy, oz, c), dtype=torch.float32, device=self.device)
                     _ffi.check(_ffi.lib.sk_train_conv_dgrad(_ffi.ptr(dy), _ffi.ptr(layer.weight), _ffi.ptr(fine), B, ox, oy,
@@ -233,6 +336,7 @@ class TrainUNet:
                                                             ox, oy, oz, cout, layer.cin, lo, c, layer.ksize, int(have), st))
                 lo += c
         self._tape = []
+        self._half = {}
 
 
 def fused_loss(logits: Tensor, masks: Tensor, skele_masks: Tensor, baked: Tensor, sigma: Sequence[float],

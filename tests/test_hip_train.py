@@ -234,10 +234,14 @@ def test_conv_wgrad_f16(ffi, B, osp, srcdef, cout, ksize):
     dw, dbias = torch.empty(w.shape, device=DEV), torch.empty(cout, device=DEV)
     ox, oy, oz = osp
     ws = torch.empty(int(ffi.lib.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, cout, cin, ksize)), device=DEV)
-    ffi.check(ffi.lib.sk_train_conv_wgrad_f16(arr, len(srcs_dev), ffi.ptr(dy16), ffi.ptr(scale), B, ox, oy, oz, cout, ksize,
-                                              ffi.ptr(dw), ffi.ptr(dbias), ffi.ptr(ws), st))
-    _close(dw, w.grad, 1e-4, "dweight (fp16 operands)")
-    _close(dbias, bias.grad, 1e-4, "dbias (fp16 operands)")
+    zero_page = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    for zp in (zero_page, None):  # whole-line kernel (when the channel counts allow it) and the 16-bit-load kernel
+        dw.fill_(7.0)
+        dbias.fill_(7.0)
+        ffi.check(ffi.lib.sk_train_conv_wgrad_f16(arr, len(srcs_dev), ffi.ptr(dy16), ffi.ptr(scale), B, ox, oy, oz, cout,
+                                                  ksize, ffi.ptr(dw), ffi.ptr(dbias), ffi.ptr(ws), ffi.ptr(zp), st))
+        _close(dw, w.grad, 1e-4, "dweight (fp16 operands)")
+        _close(dbias, bias.grad, 1e-4, "dbias (fp16 operands)")
     # and the round trip of the casts
     back = torch.zeros(dyc.shape, device=DEV)
     ffi.check(ffi.lib.sk_train_cast_f16_f32(ffi.ptr(dy16), ffi.ptr(back), dyc.numel(), ffi.ptr(scale), 0, st))
@@ -307,6 +311,34 @@ def test_train_step_vs_oracle():
     assert diff.mean().item() < 0.005 * lr
     # and the parameters did move
     assert max((new[k].cpu() - sd0[k]).abs().max().item() for k in sd0) > 0.5 * lr
+
+
+def test_train_step_mixed_precision_vs_oracle():
+    """precision="mixed": convolutions (forward, data and weight gradients) on the fp16 MFMA kernels, the rest
+    fp32.  Against the fp32 oracle the differences are fp16 operand rounding (the reference itself trains in
+    bf16): losses within 2e-3, every parameter gradient within 3 % of that tensor's max and 1 % in RMS."""
+    from oracle import train_step as O
+    from oracle import unet_spec
+    from skoots_amd.train import TrainStep, TrainUNet
+    ref = unet_spec.build().train()
+    B, X, Y, Z = 2, 16, 12, 8
+    sigma, scale = torch.tensor([20.0, 20.0, 20.0]), torch.tensor((60, 60, 12))
+    model = TrainUNet(ref.state_dict(), DEV, precision="mixed")
+    step = TrainStep(model)
+    opt = O.make_optimizer(ref)
+    images, masks, skele, baked = _synthetic_batch(B, X, Y, Z, 40)
+    want = O.train_step(ref, opt, images, masks, skele, baked, sigma, scale)
+    ref_grads = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    got = step(images.to(DEV), masks.to(DEV), skele.to(DEV), baked.to(DEV), sigma.tolist())
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=2e-3)
+    worst = 0.0
+    for k, g in model.grads().items():
+        r = ref_grads[k].double()
+        e = (g.cpu().double() - r)
+        worst = max(worst, (e.abs().max() / r.abs().max()).item())
+        assert e.abs().max() <= 3e-2 * r.abs().max(), k
+        assert e.pow(2).mean().sqrt() <= 1e-2 * r.abs().max(), k
+    print(f"mixed precision: worst gradient error / max = {worst:.2e}")
 
 
 def test_trained_weights_feed_the_eval_path(tmp_path):
