@@ -332,6 +332,12 @@ int64_t sk_train_conv_wgrad_workspace_floats(int B, int ox, int oy, int oz, int 
  * sk_train_gn_silu_mixed: raw fp16 conv output -> y32 (raw), z32 and z16 (GroupNorm affine + SiLU). */
 int sk_train_pack_weight(const float* weight, int Co, int Ci, int ksize, int transposed, int c_lo,
                          int c_n, void* dst, void* stream);
+/* transposed == 2: transposed WITHOUT the tap flip -- the stride-2 (ksize 2) data gradient in scatter form:
+ * fragment block p (of 8, each (Co/16)*(Ci/32) KiB) is the pointwise operator W_p^T of parity p; run it with
+ * sk_conv3d(ksize 1) into t16[p] (B, cx, cy, cz, Ci) and assemble with sk_train_interleave2:
+ * dx (B, 2cx, 2cy, 2cz, Ci) (+)= t16[parity][coarse voxel] * scale[1]. */
+int sk_train_interleave2(const void* t16, float* dx, int B, int cx, int cy, int cz, int C,
+                         const float* scale, int accumulate, void* stream);
 int sk_train_gn_silu_mixed(const void* y16, const float* affine, float* y32, float* z32, void* z16,
                            int B, int64_t voxels, int C, void* stream);
 int sk_train_absmax_scale(const float* x, int64_t n, float* scale, void* stream);

@@ -525,6 +525,83 @@ __global__ void __launch_bounds__(64) wgrad_kernel(WgradArgs a) {
     }
 }
 
+// Weight gradient of the stem (Cin = 1, k = 3): with one input channel the 27 taps take the place of the input
+// channels -- D[cout][tap] += dY[v][cout] * x[v + tap] -- so ONE MFMA per two voxels covers all taps (the generic
+// kernel would spend 27 MFMAs with 1 of 32 columns in use).  Partial layout as wgrad_kernel: (chunk, cout, 1, 27).
+__global__ void __launch_bounds__(64) wgrad_stem_kernel(WgradArgs a) {
+    const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
+    int blk = blockIdx.x;
+    const int cot = blk % a.ncot;
+    const int chunk = blk / a.ncot;
+    const int b = chunk / a.nchunk_b, cb = chunk % a.nchunk_b;
+    const WgSrc S = a.src[0];
+    const int co = 32 * cot + col;
+    const bool cook = co < a.cout, tapok = col < 27;
+    const int dx = col / 9 - 1, dy = (col / 3) % 3 - 1, dz = col % 3 - 1;  // this lane's tap (B column)
+    const long long nvox = (long long)a.ox * a.oy * a.oz;
+    const __amdgpu_buffer_rsrc_t rdy = sk::make_rsrc(a.dy + (long long)b * nvox * a.cout, (unsigned)(nvox * a.cout * 4));
+    const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(S.data + (long long)b * nvox, (unsigned)(nvox * 4));
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float bsum = 0.0f;
+    const long long q0 = (long long)cb * a.chunk;
+    long long q1 = q0 + a.chunk;
+    if (q1 > nvox) q1 = nvox;
+    long long q = q0 + h;
+    int z = (int)(q % a.oz);
+    long long t2 = q / a.oz;
+    int y = (int)(t2 % a.oy), x = (int)(t2 / a.oy);
+    const long long ntrip = (q1 - q0 + 1) / 2;
+    auto fetch = [&](float& av, float& bv) {
+        const bool ok = q < q1;
+        av = sk::buf_load_f32(rdy, (ok && cook) ? (unsigned)(q * a.cout + co) * 4u : sk::kOob);
+        const int xi = x + dx, yi = y + dy, zi = z + dz;
+        const bool inb = ok && tapok && xi >= 0 && xi < a.ox && yi >= 0 && yi < a.oy && zi >= 0 && zi < a.oz;
+        bv = sk::buf_load_f32(rsrc, inb ? (unsigned)((xi * a.oy + yi) * a.oz + zi) * 4u : sk::kOob);
+        q += 2;
+        z += 2;
+        while (z >= a.oz) {
+            z -= a.oz;
+            ++y;
+        }
+        while (y >= a.oy) {
+            y -= a.oy;
+            ++x;
+        }
+    };
+    float av_n[4], bv_n[4];  // four steps in flight
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fetch(av_n[u], bv_n[u]);
+    for (long long it = 0; it < ntrip; it += 4) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            av[u] = av_n[u];
+            bv[u] = bv_n[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fetch(av_n[u], bv_n[u]);  // past the chunk end: masked, zeros
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bsum += av[u];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+    }
+    float* part = a.part + (long long)chunk * a.cout * 27;
+    if (tapok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * cot + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < a.cout) part[(long long)row * 27 + col] = acc[r];
+        }
+    }
+    if (a.part_bias) {
+        bsum += __shfl_xor(bsum, 32);
+        if (h == 0 && cook) a.part_bias[(long long)chunk * a.cout + co] = bsum;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Mixed-precision pieces (TrainUNet precision="mixed"): fp16 copies of the activations and of the
 // (power-of-two scaled) output gradients feed the fast fp16 MFMA kernels; everything else stays fp32.
@@ -889,12 +966,36 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(PackArgs a) {
     int tap = (kx * k + ky) * k + kz;
     long long src;
     if (a.transposed) {
-        tap = k3 - 1 - tap;
+        if (a.transposed == 1) tap = k3 - 1 - tap;  // 2: transposed without the flip (stride-2 scatter form)
         src = ((long long)ci * a.Ci + a.c_lo + co) * k3 + tap;
     } else {
         src = ((long long)co * a.Ci + ci) * k3 + tap;
     }
     a.dst[i] = __float2half_rn(a.w[src]);
+}
+
+// Data gradient of a k = 2, stride-2 conv from its eight per-parity pointwise products: t16 (8, B, cx, cy, cz, C)
+// holds T_p[c] = W_p^T dY[c]; dX[2c + p] (+)= T_p[c] * scale[1].
+__global__ void __launch_bounds__(256) interleave2_kernel(const __half* __restrict__ t16, float* __restrict__ dx, int B,
+                                                          int cx, int cy, int cz, int C, const float* __restrict__ scale,
+                                                          int accumulate) {
+    const float s = scale ? scale[1] : 1.0f;
+    const long long ncoarse = (long long)B * cx * cy * cz * C;
+    const long long n = ncoarse * 8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int z = (int)(t % (2 * cz));
+        t /= 2 * cz;
+        const int y = (int)(t % (2 * cy));
+        t /= 2 * cy;
+        const int x = (int)(t % (2 * cx));
+        const int b = (int)(t / (2 * cx));
+        const int p = ((x & 1) << 2) | ((y & 1) << 1) | (z & 1);
+        const long long ci = ((((long long)b * cx + (x >> 1)) * cy + (y >> 1)) * cz + (z >> 1)) * C + c;
+        const float v = __half2float(t16[(long long)p * ncoarse + ci]) * s;
+        dx[i] = accumulate ? dx[i] + v : v;
+    }
 }
 
 // GroupNorm affine + SiLU of a RAW fp16 conv output, writing what the mixed-precision step keeps:
@@ -915,13 +1016,21 @@ __global__ void __launch_bounds__(256) gn_silu_mixed_kernel(const __half* __rest
     }
 }
 
+// out[i] = sum over chunks of part[c][i] (fixed order -> deterministic): 64 elements per block, four chunk slices
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int nchunk, long long n,
                                                            float* __restrict__ out, const float* __restrict__ scale) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ double red[256];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
     double s = 0.0;
-    for (int c = 0; c < nchunk; ++c) s += (double)part[(long long)c * n + i];
-    out[i] = scale ? (float)(s * (double)scale[1]) : (float)s;
+    if (i < n)
+        for (int c = sl; c < nchunk; c += 4) s += (double)part[(long long)c * n + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        s = ((red[e] + red[64 + e]) + red[128 + e]) + red[192 + e];
+        out[i] = scale ? (float)(s * (double)scale[1]) : (float)s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1152,17 +1261,19 @@ int sk_train_conv_wgrad(const sk_conv_src* srcs, int n_src, const float* dy, int
     a.part_bias = dbias ? workspace + (long long)a.nchunk * nw : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((long long)a.nchunk * a.ncot * a.ncit * a.ngroup);
-    if (ksize == 3)
+    if (ksize == 3 && n_src == 1 && a.cin == 1 && !a.src[0].up)
+        wgrad_stem_kernel<<<(unsigned)((long long)a.nchunk * a.ncot), 64, 0, st>>>(a);
+    else if (ksize == 3)
         wgrad_kernel<9><<<grid, 64, 0, st>>>(a);
     else if (ksize == 2)
         wgrad_kernel<8><<<grid, 64, 0, st>>>(a);
     else
         wgrad_kernel<1><<<grid, 64, 0, st>>>(a);
     SK_CHECK_LAUNCH();
-    wgrad_reduce_kernel<<<sk::cdiv(nw, 256), 256, 0, st>>>(a.part, a.nchunk, nw, dweight, nullptr);
+    wgrad_reduce_kernel<<<sk::cdiv(nw, 64), 256, 0, st>>>(a.part, a.nchunk, nw, dweight, nullptr);
     SK_CHECK_LAUNCH();
     if (dbias) {
-        wgrad_reduce_kernel<<<sk::cdiv(cout, 256), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, nullptr);
+        wgrad_reduce_kernel<<<sk::cdiv(cout, 64), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, nullptr);
         SK_CHECK_LAUNCH();
     }
     return SK_OK;
@@ -1227,10 +1338,10 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
     else
         wgrad16_kernel<1><<<grid, 64, 0, st>>>(a);
     SK_CHECK_LAUNCH();
-    wgrad_reduce_kernel<<<sk::cdiv(nw, 256), 256, 0, st>>>(a.part, a.nchunk, nw, dweight, dy_scale);
+    wgrad_reduce_kernel<<<sk::cdiv(nw, 64), 256, 0, st>>>(a.part, a.nchunk, nw, dweight, dy_scale);
     SK_CHECK_LAUNCH();
     if (dbias) {
-        wgrad_reduce_kernel<<<sk::cdiv(cout, 256), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, dy_scale);
+        wgrad_reduce_kernel<<<sk::cdiv(cout, 64), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, dy_scale);
         SK_CHECK_LAUNCH();
     }
     return SK_OK;
@@ -1239,6 +1350,7 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
 int sk_train_pack_weight(const float* weight, int Co, int Ci, int ksize, int transposed, int c_lo, int c_n, void* dst,
                          void* stream) {
     SK_CHECK_ARG(weight && dst && (ksize == 1 || ksize == 2 || ksize == 3), "sk_train_pack_weight: bad arguments");
+    SK_CHECK_ARG(transposed >= 0 && transposed <= 2, "sk_train_pack_weight: transposed must be 0, 1 or 2");
     const int eff_cout = transposed ? c_n : Co, eff_cin = transposed ? Co : Ci;
     SK_CHECK_ARG(!transposed || (c_lo >= 0 && c_n >= 1 && c_lo + c_n <= Ci), "sk_train_pack_weight: bad channel range");
     SK_CHECK_ARG(transposed || (c_lo == 0 && c_n == Ci), "sk_train_pack_weight: a channel range needs transposed");
@@ -1252,10 +1364,20 @@ int sk_train_pack_weight(const float* weight, int Co, int Ci, int ksize, int tra
     a.ksize = ksize;
     a.eff_cout = eff_cout;
     a.eff_cin = eff_cin;
-    a.transposed = transposed ? 1 : 0;
+    a.transposed = transposed;
     a.c_lo = c_lo;
     a.n = (long long)ksize * ksize * ksize * (eff_cin / 16) * (eff_cout / 32) * 512;
     pack_weight_kernel<<<sk::cdiv(a.n, 256), 256, 0, (hipStream_t)stream>>>(a);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_train_interleave2(const void* t16, float* dx, int B, int cx, int cy, int cz, int C, const float* scale, int accumulate,
+                         void* stream) {
+    SK_CHECK_ARG(t16 && dx && B >= 1 && cx >= 1 && cy >= 1 && cz >= 1 && C >= 1, "sk_train_interleave2: bad arguments");
+    long long n = (long long)B * cx * cy * cz * C * 8;
+    interleave2_kernel<<<sk::stream_grid(n, 256, 4), 256, 0, (hipStream_t)stream>>>((const __half*)t16, dx, B, cx, cy, cz, C, scale,
+                                                                                    accumulate ? 1 : 0);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }

@@ -141,7 +141,7 @@ class TrainUNet:
         return (self.precision == "mixed" and layer.norm and layer.cout in (32, 64, 128) and
                 all(t.shape[-1] % 32 == 0 for t, _ in srcs))
 
-    def _pack(self, layer: _Layer, transposed: bool = False, c_lo: int = 0, c_n: Optional[int] = None) -> Tensor:
+    def _pack(self, layer: _Layer, transposed: int = 0, c_lo: int = 0, c_n: Optional[int] = None) -> Tensor:
         c_n = layer.cin if c_n is None else c_n
         cout_eff, cin_eff = (c_n, layer.cout) if transposed else (layer.cout, layer.cin)
         buf = torch.empty(layer.ksize ** 3 * (cin_eff // 16) * (cout_eff // 32) * 1024, dtype=torch.uint8, device=self.device)
@@ -294,7 +294,22 @@ class TrainUNet:
                     lo += c
                     continue  # no gradient w.r.t. the input image
                 key = t.data_ptr()
-                if layer.ksize == 2:
+                if layer.ksize == 2 and fast and c in (32, 64, 128):
+                    # stride-2 data gradient: eight pointwise products W_p^T dY on the fast kernel, one per parity of the
+                    # fine voxel, then interleaved into the fine grid
+                    have = key in grads
+                    if not have:
+                        grads[key] = torch.empty_like(t)
+                    packed = self._pack(layer, 2, 0, c)
+                    per = packed.numel() // 8
+                    t16 = torch.empty((8, B, ox, oy, oz, c), dtype=torch.float16, device=self.device)
+                    for par in range(8):
+                        _ffi.check(_ffi.lib.sk_conv3d(self._srcs([(dy16, 0)]), 1, _ffi.ptr(packed[par * per:(par + 1) * per]),
+                                                      _ffi.ptr(self._zero_bias), _ffi.ptr(t16[par]), B, ox, oy, oz, c, 1, None,
+                                                      _ffi.ptr(self._zero_page), st))
+                    _ffi.check(_ffi.lib.sk_train_interleave2(_ffi.ptr(t16), _ffi.ptr(grads[key]), B, ox, oy, oz, c,
+                                                             _ffi.ptr(scale), int(have), st))
+                elif layer.ksize == 2:
                     have = key in grads
                     if not have:
                         grads[key] = torch.empty_like(t)
