@@ -852,15 +852,21 @@ __global__ void __launch_bounds__(64) wgrad16t_kernel(Wgrad16Args a, const char*
     long long t2 = q / a.oz;
     int y = (int)(t2 % a.oy), x = (int)(t2 / a.oy);
 
+    int tdx[NT], tdy[NT], tdz[NT];  // taps of this wave: grp * NT + t
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = grp * NT + t;
+        tdx[t] = tap / (k * k);
+        tdy[t] = (tap / k) % k;
+        tdz[t] = tap % k;
+    }
     auto issue = [&](int buf) {
         char* tb = tiles[buf];
         const bool ok = q < q1;
         dma16_tile(ok ? dyb + q * a.cout * 2 : zp, tb);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int dx = NT == 9 ? grp : (NT == 8 ? (t >> 2) : 0);
-            const int dy = NT == 9 ? t / 3 : (NT == 8 ? ((t >> 1) & 1) : 0);
-            const int dz = NT == 9 ? t % 3 : (NT == 8 ? (t & 1) : 0);
+            const int dx = tdx[t], dy = tdy[t], dz = tdz[t];
             int xi = x * stride + dx - padw, yi = y * stride + dy - padw, zi = z * stride + dz - padw;
             const bool inb = ok && xi >= 0 && xi < Xf && yi >= 0 && yi < Yf && zi >= 0 && zi < Zf;
             if (S.up) {
@@ -1325,8 +1331,18 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
     bool lines = zero_page != nullptr && cout % 32 == 0;  // whole 64-byte channel lines: LDS-DMA + transposed reads
     for (int i = 0; i < n_src; ++i) lines = lines && srcs[i].c % 32 == 0;
     if (lines) {
-        if (ksize == 3)
-            wgrad16t_kernel<9><<<grid, 64, 0, st>>>(a, (const char*)zero_page);
+        if (ksize == 3) {
+            // three taps per wave (nine tap groups): 8 KiB of LDS tiles per wave instead of 20, so ~2.5x the waves
+            // and DMA steps in flight per CU -- the kernel is bound by the latency of its tile loads
+            int tpw = 9;  // 3 measured 1.5 % slower: the kernel is bound by L2 bandwidth (every input line is read once per tap), not by latency
+            if (const char* e = getenv("SK_WGRAD_TPW")) tpw = atoi(e);
+            a.ngroup = 27 / tpw;
+            const unsigned g = (unsigned)((long long)a.nchunk * a.ncot * a.ncit * a.ngroup);
+            if (tpw == 3)
+                wgrad16t_kernel<3><<<g, 64, 0, st>>>(a, (const char*)zero_page);
+            else
+                wgrad16t_kernel<9><<<g, 64, 0, st>>>(a, (const char*)zero_page);
+        }
         else if (ksize == 2)
             wgrad16t_kernel<8><<<grid, 64, 0, st>>>(a, (const char*)zero_page);
         else
