@@ -926,6 +926,148 @@ __global__ void __launch_bounds__(64) wgrad16t_kernel(Wgrad16Args a, const char*
     }
 }
 
+// k = 3 and oz % 16 == 0: a step's 16 voxels lie in one z row, so the three dz taps of a (dx, dy) read the SAME 18
+// input lines shifted by one -- stage that strip once (18 x 64 B) and take the three K-major fragments from it with
+// row-shifted transposed reads.  L2 traffic per step 4.4 KiB instead of 10 (the whole-line kernel is L2-bound:
+// every input line is fetched once per tap).
+__device__ __forceinline__ half8_t tr_read_rows(const char* tile, int lane, int row0, int row1) {
+    // as tr_read_frag with this lane's two source rows given explicitly (rows of its voxels 8h + q and 8h + 4 + q)
+    const int g = lane >> 4, p = lane & 3;
+    const char* base = tile + (16 * (g & 1) + 4 * p) * 2;
+    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + row0 * 64));
+    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + row1 * 64));
+    half8_t r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = (_Float16)lo[j];
+        r[4 + j] = (_Float16)hi[j];
+    }
+    return r;
+}
+
+__global__ void __launch_bounds__(64) wgrad16s_kernel(Wgrad16Args a, const char* zero_page) {
+    constexpr int kStage = 1024 + 3 * 2048;  // dy tile + three strips (each two DMA instructions: 18 of 128 line slots used)
+    __shared__ __attribute__((aligned(16))) char tiles[2][kStage];
+    const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
+    const int lv = lane >> 2, lc = lane & 3;
+    int blk = blockIdx.x;
+    const int grp = blk % 3;  // dx
+    blk /= 3;
+    const int cit = blk % a.ncit;
+    blk /= a.ncit;
+    const int cot = blk % a.ncot;
+    const int chunk = blk / a.ncot;
+    const int b = chunk / a.nchunk_b, cb = chunk % a.nchunk_b;
+    int ci0 = 32 * cit, sidx = 0, cbase = 0;
+    if (a.nsrc == 2 && ci0 >= a.src[0].C) {
+        sidx = 1;
+        cbase = a.src[0].C;
+    }
+    const Wg16Src S = a.src[sidx];
+    const int Xf = S.up ? S.Xs * 2 : S.Xs, Yf = S.up ? S.Ys * 2 : S.Ys;
+    const long long nvox = (long long)a.ox * a.oy * a.oz;
+    const long long svox = (long long)S.Xs * S.Ys * S.Zs;
+    const char* dyb = reinterpret_cast<const char*>(a.dy + (long long)b * nvox * a.cout) + (32 * cot + 8 * lc) * 2;
+    const char* sb = reinterpret_cast<const char*>(S.data + (long long)b * svox * S.C) + (ci0 - cbase + 8 * lc) * 2;
+    const char* zp = zero_page + lane * 16;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float bsum = 0.0f;
+
+    const long long q0 = (long long)cb * a.chunk;   // chunk and nvox are multiples of 16 (oz % 16 == 0)
+    long long q1 = q0 + a.chunk;
+    if (q1 > nvox) q1 = nvox;
+    const int ntrip = q1 > q0 ? (int)((q1 - q0) / 16) : 0;
+    // the step's first voxel (wave-uniform walk): z0 advances by 16 inside the row
+    long long q = q0;
+    int z0 = (int)(q % a.oz);
+    long long t2 = q / a.oz;
+    int y = (int)(t2 % a.oy), x = (int)(t2 / a.oy);
+
+    auto issue = [&](int buf) {
+        char* tb = tiles[buf];
+        dma16_tile(dyb + (q + lv) * a.cout * 2, tb);
+        const int xi = x + grp - 1;
+        const int zs0 = S.up ? ((z0 - 1) >> 1) : (z0 - 1);   // first source line of the strip
+#pragma unroll
+        for (int dyi = 0; dyi < 3; ++dyi) {
+            const int yi = y + dyi - 1;
+            const bool rowok = xi >= 0 && xi < Xf && yi >= 0 && yi < Yf;
+            const int xs = S.up ? xi >> 1 : xi, ys = S.up ? yi >> 1 : yi;
+            const char* rowp = sb + (long long)((xs * S.Ys + ys) * S.Zs) * S.C * 2;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const int r = 16 * part + lv;         // strip row of this lane
+                const int zs = zs0 + r;
+                const bool ok = rowok && r < 18 && zs >= 0 && zs < S.Zs;
+                dma16_tile(ok ? rowp + (long long)zs * S.C * 2 : zp, tb + 1024 + dyi * 2048 + part * 1024);
+            }
+        }
+        q += 16;
+        z0 += 16;
+        if (z0 >= a.oz) {
+            z0 = 0;
+            if (++y == a.oy) {
+                y = 0;
+                ++x;
+            }
+        }
+    };
+    if (ntrip > 0) issue(0);
+    int zc = (int)(q0 % a.oz);  // z0 of the step being consumed
+    for (int it = 0; it < ntrip; ++it) {
+        const bool more = it + 1 < ntrip;
+        if (more) {
+            issue((it + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // 1 + 3 * 2 instructions per stage
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const char* tb = tiles[it & 1];
+        const half8_t av = tr_read_frag(tb, lane);
+        // this lane's voxels of the two reads: v = 8h + q and 8h + 4 + q; strip row of voxel v for tap dz: the source
+        // line of fine z = zc + v + dz - 1, relative to the strip's first line
+        const int qq = (lane & 15) >> 2;
+        const int v0 = 8 * h + qq, v1 = v0 + 4;
+        const int zs0 = S.up ? ((zc - 1) >> 1) : (zc - 1);
+        half8_t bv[9];
+#pragma unroll
+        for (int dyi = 0; dyi < 3; ++dyi)
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                const int f0 = zc + v0 + dz - 1, f1 = zc + v1 + dz - 1;
+                const int r0 = (S.up ? (f0 >> 1) : f0) - zs0, r1 = (S.up ? (f1 >> 1) : f1) - zs0;
+                bv[dyi * 3 + dz] = tr_read_rows(tb + 1024 + dyi * 2048, lane, r0, r1);
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum += (float)av[j];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv[t], acc[t], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        zc += 16;
+        if (zc >= a.oz) zc = 0;
+    }
+    float* part = a.part + (long long)chunk * a.cout * a.cin * 27;
+    const int cig = ci0 + col;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tap = grp * 9 + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * cot + (r & 3) + 8 * (r >> 2) + 4 * h;
+            part[((long long)row * a.cin + cig) * 27 + tap] = acc[t][r];
+        }
+    }
+    if (a.part_bias && cit == 0 && grp == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (h == 0) a.part_bias[(long long)chunk * a.cout + 32 * cot + col] = bsum;
+    }
+}
+
 // Device-side counterpart of sk_conv3d_pack_weight_host (weights change every step in training): fp32
 // torch-layout weight -> fp16 MFMA A fragments.  `transposed`: pack the data-gradient operator instead,
 // W'[co'][ci'][tap] = W[ci'][c_lo + co'][flipped tap]  (co' < eff_cout input channels of the layer, ci' <
@@ -1330,7 +1472,10 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
     const unsigned grid = (unsigned)((long long)a.nchunk * a.ncot * a.ncit * a.ngroup);
     bool lines = zero_page != nullptr && cout % 32 == 0;  // whole 64-byte channel lines: LDS-DMA + transposed reads
     for (int i = 0; i < n_src; ++i) lines = lines && srcs[i].c % 32 == 0;
-    if (lines) {
+    if (lines && ksize == 3 && oz % 16 == 0 && !getenv("SK_WGRAD_NOSTRIP")) {
+        a.ngroup = 3;
+        wgrad16s_kernel<<<(unsigned)((long long)a.nchunk * a.ncot * a.ncit * 3), 64, 0, st>>>(a, (const char*)zero_page);
+    } else if (lines) {
         if (ksize == 3) {
             // three taps per wave (nine tap groups): 8 KiB of LDS tiles per wave instead of 20, so ~2.5x the waves
             // and DMA steps in flight per CU -- the kernel is bound by the latency of its tile loads
