@@ -946,7 +946,9 @@ __device__ __forceinline__ half8_t tr_read_rows(const char* tile, int lane, int 
 }
 
 __global__ void __launch_bounds__(64) wgrad16s_kernel(Wgrad16Args a, const char* zero_page) {
-    constexpr int kStage = 1024 + 3 * 2048;  // dy tile + three strips (each two DMA instructions: 18 of 128 line slots used)
+    // stage = dy tile | three strip mains (rows 0..15) | the three strips' rows 16, 17 in one tile: 5 DMA instructions
+    // per step (the LDS-DMA issue cost, ~100+ cycles per instruction next to MFMAs, is what bounds this kernel)
+    constexpr int kStage = 5 * 1024;
     __shared__ __attribute__((aligned(16))) char tiles[2][kStage];
     const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
     const int lv = lane >> 2, lc = lane & 3;
@@ -993,20 +995,20 @@ __global__ void __launch_bounds__(64) wgrad16s_kernel(Wgrad16Args a, const char*
         dma16_tile(dyb + (q + lv) * a.cout * 2, tb);
         const int xi = x + grp - 1;
         const int zs0 = S.up ? ((z0 - 1) >> 1) : (z0 - 1);   // first source line of the strip
+        const char* tailsrc = zp;   // lane (dyi, row 16 + rr, chunk lc) of the tails tile: lanes 0..23
+        const int tdy = lv >> 1, trr = lv & 1;
 #pragma unroll
         for (int dyi = 0; dyi < 3; ++dyi) {
             const int yi = y + dyi - 1;
             const bool rowok = xi >= 0 && xi < Xf && yi >= 0 && yi < Yf;
             const int xs = S.up ? xi >> 1 : xi, ys = S.up ? yi >> 1 : yi;
             const char* rowp = sb + (long long)((xs * S.Ys + ys) * S.Zs) * S.C * 2;
-#pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                const int r = 16 * part + lv;         // strip row of this lane
-                const int zs = zs0 + r;
-                const bool ok = rowok && r < 18 && zs >= 0 && zs < S.Zs;
-                dma16_tile(ok ? rowp + (long long)zs * S.C * 2 : zp, tb + 1024 + dyi * 2048 + part * 1024);
-            }
+            const int zs = zs0 + lv;
+            dma16_tile((rowok && zs >= 0 && zs < S.Zs) ? rowp + (long long)zs * S.C * 2 : zp, tb + 1024 + dyi * 1024);
+            const int zt = zs0 + 16 + trr;
+            if (tdy == dyi && rowok && zt >= 0 && zt < S.Zs) tailsrc = rowp + (long long)zt * S.C * 2;
         }
+        dma16_tile(tailsrc, tb + 4096);
         q += 16;
         z0 += 16;
         if (z0 >= a.oz) {
@@ -1023,7 +1025,7 @@ __global__ void __launch_bounds__(64) wgrad16s_kernel(Wgrad16Args a, const char*
         const bool more = it + 1 < ntrip;
         if (more) {
             issue((it + 1) & 1);
-            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // 1 + 3 * 2 instructions per stage
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // 5 instructions per stage
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1041,7 +1043,11 @@ __global__ void __launch_bounds__(64) wgrad16s_kernel(Wgrad16Args a, const char*
             for (int dz = 0; dz < 3; ++dz) {
                 const int f0 = zc + v0 + dz - 1, f1 = zc + v1 + dz - 1;
                 const int r0 = (S.up ? (f0 >> 1) : f0) - zs0, r1 = (S.up ? (f1 >> 1) : f1) - zs0;
-                bv[dyi * 3 + dz] = tr_read_rows(tb + 1024 + dyi * 2048, lane, r0, r1);
+                // strip row r lives in the main tile (r < 16) or in the tails tile at row 2 * dyi + r - 16; tr_read_rows
+                // takes rows relative to one base, so express both against the stage base
+                const int a0 = r0 < 16 ? (16 * (1 + dyi) + r0) : (64 + 2 * dyi + r0 - 16);
+                const int a1 = r1 < 16 ? (16 * (1 + dyi) + r1) : (64 + 2 * dyi + r1 - 16);
+                bv[dyi * 3 + dz] = tr_read_rows(tb, lane, a0, a1);
             }
 #pragma unroll
         for (int j = 0; j < 8; ++j) bsum += (float)av[j];
