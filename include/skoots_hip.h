@@ -340,6 +340,16 @@ int sk_train_interleave2(const void* t16, float* dx, int B, int cx, int cy, int 
                          const float* scale, int accumulate, void* stream);
 int sk_train_gn_silu_mixed(const void* y16, const float* affine, float* y32, float* z32, void* z16,
                            int B, int64_t voxels, int C, void* stream);
+/* Lean mixed data flow: sk_train_gn_silu_f16: raw fp16 conv output -> z16 (and z32 if not NULL).
+ * sk_train_gn_silu_bwd_f16: dz (fp32) and the RAW fp16 output -> dy16 = fp16(dy * scale[0]) with scale (3 floats,
+ * device: 2^k, 2^-k, bound) chosen from an upper bound of max|dy| formed in the reduction pass; dgamma, dbeta as
+ * sk_train_gn_silu_bwd.  workspace: sk_train_gn_bwd_f16_workspace_floats(B, voxels, C) floats. */
+int sk_train_gn_silu_f16(const void* y16, const float* affine, void* z16, float* z32, int B,
+                         int64_t voxels, int C, void* stream);
+int sk_train_gn_silu_bwd_f16(const float* dz, const void* y16, const float* affine, const float* stats,
+                             const float* gamma, int B, int64_t voxels, int C, int groups, void* dy16,
+                             float* scale, float* dgamma, float* dbeta, float* workspace, void* stream);
+int64_t sk_train_gn_bwd_f16_workspace_floats(int B, int64_t voxels, int C);
 int sk_train_absmax_scale(const float* x, int64_t n, float* scale, void* stream);
 int sk_train_cast_f32_f16(const float* x, void* y, int64_t n, const float* scale, void* stream);
 int sk_train_cast_f16_f32(const void* x, float* y, int64_t n, const float* scale, int accumulate,

@@ -645,6 +645,173 @@ __global__ void __launch_bounds__(256) cast_f16_f32_kernel(const __half* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Mixed precision, lean data flow: the block keeps only the RAW fp16 conv output y16; GroupNorm + SiLU writes the
+// fp16 activation (plus an fp32 copy only where an fp32 kernel consumes it), and the backward reads y16 and writes
+// the fp16 output gradient directly, scaled by a power of two taken from an upper BOUND of its maximum
+//   |dy| <= |k0| max|du| + |k1| + max|xh| |k2|   per (sample, channel)
+// whose ingredients come out of the reduction pass -- no separate max pass, no fp32 dy, no cast pass.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_silu_f16_kernel(const __half* __restrict__ y16, const float* __restrict__ affine,
+                                                          __half* __restrict__ z16, float* __restrict__ z32, int C,
+                                                          long long n_per_batch) {
+    const int b = blockIdx.y;
+    const long long off = (long long)b * n_per_batch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_per_batch; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float u = fmaf(affine[(long long)b * 2 * C + c], __half2float(y16[off + i]), affine[(long long)b * 2 * C + C + c]);
+        const float z = u / (1.0f + expf(-u));
+        z16[off + i] = __float2half_rn(z);
+        if (z32) z32[off + i] = z;
+    }
+}
+
+__global__ void __launch_bounds__(256) gn_bwd_reduce16_kernel(const float* __restrict__ dz, const __half* __restrict__ y,
+                                                              const float* __restrict__ affine,
+                                                              const float* __restrict__ stats, int C, int groups,
+                                                              long long voxels, int nblk, float* __restrict__ partial) {
+    __shared__ float red[256 * 4];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int c = tid % C, row = tid / C, rows = 256 / C;
+    const int g = c / (C / groups);
+    const float a = affine[(long long)b * 2 * C + c], bb = affine[(long long)b * 2 * C + C + c];
+    const float mean = stats[((long long)b * groups + g) * 2], rstd = stats[((long long)b * groups + g) * 2 + 1];
+    const long long v0 = (long long)blockIdx.x * kGnbVox;
+    long long v1 = v0 + kGnbVox;
+    if (v1 > voxels) v1 = voxels;
+    float s1 = 0.0f, s2 = 0.0f, m1 = 0.0f, m2 = 0.0f;
+    for (long long v = v0 + row; v < v1; v += rows) {
+        const long long i = ((long long)b * voxels + v) * C + c;
+        const float yv = __half2float(y[i]);
+        const float du = dz[i] * silu_grad(fmaf(a, yv, bb));
+        const float xh = (yv - mean) * rstd;
+        s1 += du;
+        s2 += du * xh;
+        m1 = fmaxf(m1, fabsf(du));
+        m2 = fmaxf(m2, fabsf(xh));
+    }
+    red[tid * 4] = s1;
+    red[tid * 4 + 1] = s2;
+    red[tid * 4 + 2] = m1;
+    red[tid * 4 + 3] = m2;
+    __syncthreads();
+    if (tid < C) {
+        for (int r = 1; r < rows; ++r) {
+            s1 += red[(r * C + tid) * 4];
+            s2 += red[(r * C + tid) * 4 + 1];
+            m1 = fmaxf(m1, red[(r * C + tid) * 4 + 2]);
+            m2 = fmaxf(m2, red[(r * C + tid) * 4 + 3]);
+        }
+        float* o = partial + (((long long)b * nblk + blockIdx.x) * C + tid) * 4;
+        o[0] = s1;
+        o[1] = s2;
+        o[2] = m1;
+        o[3] = m2;
+    }
+}
+
+// one block; as gn_bwd_finalize_kernel plus scale (3 floats): [2^k, 2^-k, bound]
+__global__ void __launch_bounds__(1024) gn_bwd_finalize16_kernel(const float* __restrict__ partial, int B, int nblk, int C,
+                                                                 int groups, double voxels, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ stats, float* __restrict__ coef,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 float* __restrict__ scale) {
+    __shared__ double accv[1024];
+    __shared__ double sums[512];  // (C, 4)
+    __shared__ double gm[2 * 16];
+    __shared__ float bound[128];
+    const int tid = threadIdx.x;
+    const int nv = 4 * C;
+    const int val = tid % nv, sl = tid / nv, nsl = 1024 / nv;
+    const bool is_max = (val & 3) >= 2;
+    double dg = 0.0, db = 0.0;
+    float bnd = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        double s = 0.0;
+        const float* base = partial + (long long)b * nblk * nv + val;
+        if (sl < nsl)
+            for (int k = sl; k < nblk; k += nsl) {
+                const double v = (double)base[(long long)k * nv];
+                s = is_max ? (v > s ? v : s) : s + v;
+            }
+        accv[tid] = s;
+        __syncthreads();
+        if (tid < nv) {
+            double t = 0.0;
+            for (int k = 0; k < nsl; ++k) {
+                const double v = accv[k * nv + tid];
+                t = is_max ? (v > t ? v : t) : t + v;
+            }
+            sums[tid] = t;
+        }
+        __syncthreads();
+        const int gs = C / groups;
+        if (tid < groups) {
+            double m1 = 0.0, m2 = 0.0;
+            for (int c = tid * gs; c < (tid + 1) * gs; ++c) {
+                m1 += (double)gamma[c] * sums[4 * c];
+                m2 += (double)gamma[c] * sums[4 * c + 1];
+            }
+            const double n = voxels * gs;
+            gm[2 * tid] = m1 / n;
+            gm[2 * tid + 1] = m2 / n;
+        }
+        __syncthreads();
+        if (tid < C) {
+            const int g = tid / gs;
+            const float rstd = stats[((long long)b * groups + g) * 2 + 1];
+            float* o = coef + ((long long)b * C + tid) * 3;
+            const float k0 = rstd * gamma[tid], k1 = (float)((double)rstd * gm[2 * g]), k2 = (float)((double)rstd * gm[2 * g + 1]);
+            o[0] = k0;
+            o[1] = k1;
+            o[2] = k2;
+            db += sums[4 * tid];
+            dg += sums[4 * tid + 1];
+            bnd = fmaxf(bnd, fabsf(k0) * (float)sums[4 * tid + 2] + fabsf(k1) + (float)sums[4 * tid + 3] * fabsf(k2));
+        }
+        __syncthreads();
+    }
+    if (tid < C) {
+        dgamma[tid] = (float)dg;
+        dbeta[tid] = (float)db;
+        bound[tid] = bnd;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float m = 0.0f;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, bound[c]);
+        int e = 0;
+        if (m > 0.0f && isfinite(m)) {
+            frexpf(m, &e);
+            e = 13 - e;
+        }
+        e = e > 60 ? 60 : (e < -60 ? -60 : e);
+        scale[0] = ldexpf(1.0f, e);
+        scale[1] = ldexpf(1.0f, -e);
+        scale[2] = m;
+    }
+}
+
+__global__ void __launch_bounds__(256) gn_bwd_apply16_kernel(const float* __restrict__ dz, const __half* __restrict__ y,
+                                                             const float* __restrict__ affine,
+                                                             const float* __restrict__ stats, const float* __restrict__ coef,
+                                                             const float* __restrict__ scale, __half* __restrict__ dy16, int C,
+                                                             int groups, long long n_per_batch) {
+    const int b = blockIdx.y;
+    const float sc = scale[0];
+    const long long off = (long long)b * n_per_batch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_per_batch; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int g = c / (C / groups);
+        const float a = affine[(long long)b * 2 * C + c], bb = affine[(long long)b * 2 * C + C + c];
+        const float mean = stats[((long long)b * groups + g) * 2], rstd = stats[((long long)b * groups + g) * 2 + 1];
+        const float* k = coef + ((long long)b * C + c) * 3;
+        const float yv = __half2float(y[off + i]);
+        const float du = dz[off + i] * silu_grad(fmaf(a, yv, bb));
+        dy16[off + i] = __float2half_rn((k[0] * du - k[1] - ((yv - mean) * rstd) * k[2]) * sc);
+    }
+}
+
 // Weight gradient on v_mfma_f32_32x32x16_f16: as wgrad_kernel, with K = 16 voxels per instruction.  A lane's
 // eight K slots are eight consecutive voxels (lane half h: voxels q + 8h .. q + 8h + 7) of one channel, fetched
 // as 16-bit buffer loads (masked lanes read 0 through the bounds check) and packed in registers.
@@ -1545,6 +1712,43 @@ int sk_train_interleave2(const void* t16, float* dx, int B, int cx, int cy, int 
     long long n = (long long)B * cx * cy * cz * C * 8;
     interleave2_kernel<<<sk::stream_grid(n, 256, 4), 256, 0, (hipStream_t)stream>>>((const __half*)t16, dx, B, cx, cy, cz, C, scale,
                                                                                     accumulate ? 1 : 0);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_train_gn_silu_f16(const void* y16, const float* affine, void* z16, float* z32, int B, int64_t voxels, int C,
+                         void* stream) {
+    SK_CHECK_ARG(y16 && affine && z16 && C > 0, "sk_train_gn_silu_f16: bad arguments");
+    long long n = voxels * C;
+    gn_silu_f16_kernel<<<dim3(sk::stream_grid(n, 256, 4), B), 256, 0, (hipStream_t)stream>>>((const __half*)y16, affine,
+                                                                                             (__half*)z16, z32, C, n);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int64_t sk_train_gn_bwd_f16_workspace_floats(int B, int64_t voxels, int C) {
+    return (int64_t)B * sk_train_gn_bwd_num_blocks(voxels) * C * 4 + (int64_t)B * C * 3;
+}
+
+int sk_train_gn_silu_bwd_f16(const float* dz, const void* y16, const float* affine, const float* stats, const float* gamma,
+                             int B, int64_t voxels, int C, int groups, void* dy16, float* scale, float* dgamma, float* dbeta,
+                             float* workspace, void* stream) {
+    SK_CHECK_ARG(dz && y16 && affine && stats && gamma && dy16 && scale && dgamma && dbeta && workspace,
+                 "sk_train_gn_silu_bwd_f16: NULL pointer");
+    SK_CHECK_ARG((C == 32 || C == 64 || C == 128) && groups > 0 && groups <= 16 && C % groups == 0,
+                 "sk_train_gn_silu_bwd_f16: C=%d groups=%d unsupported", C, groups);
+    const int nblk = sk_train_gn_bwd_num_blocks(voxels);
+    float* partial = workspace;                              // (B, nblk, C, 4)
+    float* coef = workspace + (long long)B * nblk * C * 4;   // (B, C, 3)
+    hipStream_t st = (hipStream_t)stream;
+    gn_bwd_reduce16_kernel<<<dim3(nblk, B), 256, 0, st>>>(dz, (const __half*)y16, affine, stats, C, groups, voxels, nblk, partial);
+    SK_CHECK_LAUNCH();
+    gn_bwd_finalize16_kernel<<<1, 1024, 0, st>>>(partial, B, nblk, C, groups, (double)voxels, gamma, stats, coef, dgamma, dbeta,
+                                                 scale);
+    SK_CHECK_LAUNCH();
+    long long n = voxels * C;
+    gn_bwd_apply16_kernel<<<dim3(sk::stream_grid(n, 256, 4), B), 256, 0, st>>>(dz, (const __half*)y16, affine, stats, coef, scale,
+                                                                               (__half*)dy16, C, groups, n);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }

@@ -165,11 +165,18 @@ class TrainUNet:
                                       _ffi.stream_ptr(self.device)))
         return y16
 
-    def _block_mixed(self, layer: _Layer, srcs: List[Tuple[Tensor, int]], out_shape: Tuple[int, int, int]) -> Tensor:
+    def _h(self, t: Tensor) -> Tensor:
+        """fp16 form of an activation: itself, or the registered twin of an fp32 tensor."""
+        return t if t.dtype == torch.float16 else self._half[t.data_ptr()]
+
+    def _block_mixed(self, layer: _Layer, srcs: List[Tuple[Tensor, int]], out_shape: Tuple[int, int, int],
+                     want32: bool = False) -> Tensor:
+        """Fast block: keeps the RAW fp16 conv output for the backward and hands the fp16 activation on (an fp32
+        copy only when ``want32``: the consumer is an fp32 kernel, i.e. the heads)."""
         B = srcs[0][0].shape[0]
         ox, oy, oz = out_shape
         st = _ffi.stream_ptr(self.device)
-        srcs16 = [(self._half[t.data_ptr()], up) for t, up in srcs]
+        srcs16 = [(self._h(t), up) for t, up in srcs]
         nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, layer.cout, layer.ksize)
         partial = torch.empty((B, nblk, layer.cout // 4, 2), dtype=torch.float32, device=self.device)
         y16 = self._fast_conv(srcs16, self._pack(layer), layer.bias, out_shape, layer.cout, layer.ksize, partial)
@@ -179,18 +186,21 @@ class TrainUNet:
         _ffi.check(_ffi.lib.sk_groupnorm_finalize_stats(_ffi.ptr(partial), B, nblk, GN_GROUPS, layer.cout, vox,
                                                         _ffi.ptr(layer.gamma), _ffi.ptr(layer.beta), GN_EPS,
                                                         _ffi.ptr(affine), _ffi.ptr(stats), st))
-        y = torch.empty((B, ox, oy, oz, layer.cout), dtype=torch.float32, device=self.device)
-        z = torch.empty_like(y)
         z16 = torch.empty_like(y16)
-        _ffi.check(_ffi.lib.sk_train_gn_silu_mixed(_ffi.ptr(y16), _ffi.ptr(affine), _ffi.ptr(y), _ffi.ptr(z), _ffi.ptr(z16),
-                                                   B, vox, layer.cout, st))
-        self._half[z.data_ptr()] = z16
-        self._tape.append((layer, srcs, y, affine, stats, z))
-        return z
+        z32 = torch.empty(y16.shape, dtype=torch.float32, device=self.device) if want32 else None
+        _ffi.check(_ffi.lib.sk_train_gn_silu_f16(_ffi.ptr(y16), _ffi.ptr(affine), _ffi.ptr(z16), _ffi.ptr(z32), B, vox,
+                                                 layer.cout, st))
+        out = z16
+        if want32:
+            self._half[z32.data_ptr()] = z16
+            out = z32
+        self._tape.append((layer, srcs, y16, affine, stats, out))
+        return out
 
-    def _block(self, layer: _Layer, srcs: List[Tuple[Tensor, int]], out_shape: Tuple[int, int, int]) -> Tensor:
+    def _block(self, layer: _Layer, srcs: List[Tuple[Tensor, int]], out_shape: Tuple[int, int, int],
+               want32: bool = False) -> Tensor:
         if self._fast(layer, srcs):
-            return self._block_mixed(layer, srcs, out_shape)
+            return self._block_mixed(layer, srcs, out_shape, want32)
         z = self._block_fp32(layer, srcs, out_shape)
         if self.precision == "mixed" and layer.norm:
             self._half[z.data_ptr()] = self._to_half(z)   # the stem's output feeds a fast layer
@@ -253,7 +263,7 @@ class TrainUNet:
             a = self._block(l, [(s1, 0), (r1, 1)] if i == 0 else [(a, 0)], L1)
         r0 = self._block(self.red0, [(a, 0)], L1)
         for i, l in enumerate(self.dec0):
-            a = self._block(l, [(s0, 0), (r0, 1)] if i == 0 else [(a, 0)], L0)
+            a = self._block(l, [(s0, 0), (r0, 1)] if i == 0 else [(a, 0)], L0, want32=(i == len(self.dec0) - 1))
         return self._block(self.heads, [(a, 0)], L0)
 
     def backward(self, dlogits: Tensor) -> None:
@@ -266,24 +276,31 @@ class TrainUNet:
             dz = grads.pop(out.data_ptr())
             B, ox, oy, oz, cout = y.shape
             vox = ox * oy * oz
-            if layer.norm:
-                ws = self._workspace(_ffi.lib.sk_train_gn_bwd_workspace_floats(B, vox, cout))
-                _ffi.check(_ffi.lib.sk_train_gn_silu_bwd(_ffi.ptr(dz), _ffi.ptr(y), _ffi.ptr(affine), _ffi.ptr(stats),
-                                                         _ffi.ptr(layer.gamma), B, vox, cout, GN_GROUPS, _ffi.ptr(dz),
-                                                         _ffi.ptr(layer.g_gamma), _ffi.ptr(layer.g_beta), _ffi.ptr(ws), st))
-            dy = dz
-            fast = self._fast(layer, srcs)
-            ws = self._workspace(_ffi.lib.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, cout, layer.cin, layer.ksize))
+            fast = y.dtype == torch.float16   # recorded by _block_mixed
+            ws = None
             if fast:
-                # fp16 twin of dy, scaled by a power of two so that its maximum sits at 2^12..2^13
+                # GroupNorm + SiLU backward straight to the scaled fp16 output gradient (no fp32 dy, no max / cast passes)
+                ws = self._workspace(max(_ffi.lib.sk_train_gn_bwd_f16_workspace_floats(B, vox, cout),
+                                         _ffi.lib.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, cout, layer.cin, layer.ksize)))
                 scale = torch.empty(3, dtype=torch.float32, device=self.device)
-                _ffi.check(_ffi.lib.sk_train_absmax_scale(_ffi.ptr(dy), dy.numel(), _ffi.ptr(scale), st))
-                dy16 = self._to_half(dy, scale)
-                srcs16 = [(self._half[t.data_ptr()], up) for t, up in srcs]
+                dy16 = torch.empty(y.shape, dtype=torch.float16, device=self.device)
+                _ffi.check(_ffi.lib.sk_train_gn_silu_bwd_f16(_ffi.ptr(dz), _ffi.ptr(y), _ffi.ptr(affine), _ffi.ptr(stats),
+                                                             _ffi.ptr(layer.gamma), B, vox, cout, GN_GROUPS, _ffi.ptr(dy16),
+                                                             _ffi.ptr(scale), _ffi.ptr(layer.g_gamma), _ffi.ptr(layer.g_beta),
+                                                             _ffi.ptr(ws), st))
+                dy = None
+                srcs16 = [(self._h(t), up) for t, up in srcs]
                 _ffi.check(_ffi.lib.sk_train_conv_wgrad_f16(self._srcs(srcs16), len(srcs16), _ffi.ptr(dy16), _ffi.ptr(scale), B,
                                                             ox, oy, oz, cout, layer.ksize, _ffi.ptr(layer.g_weight),
                                                             _ffi.ptr(layer.g_bias), _ffi.ptr(ws), _ffi.ptr(self._zero_page), st))
             else:
+                if layer.norm:
+                    ws = self._workspace(_ffi.lib.sk_train_gn_bwd_workspace_floats(B, vox, cout))
+                    _ffi.check(_ffi.lib.sk_train_gn_silu_bwd(_ffi.ptr(dz), _ffi.ptr(y), _ffi.ptr(affine), _ffi.ptr(stats),
+                                                             _ffi.ptr(layer.gamma), B, vox, cout, GN_GROUPS, _ffi.ptr(dz),
+                                                             _ffi.ptr(layer.g_gamma), _ffi.ptr(layer.g_beta), _ffi.ptr(ws), st))
+                dy = dz
+                ws = self._workspace(_ffi.lib.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, cout, layer.cin, layer.ksize))
                 _ffi.check(_ffi.lib.sk_train_conv_wgrad(self._srcs(srcs), len(srcs), _ffi.ptr(dy), B, ox, oy, oz, cout,
                                                         layer.ksize, _ffi.ptr(layer.g_weight), _ffi.ptr(layer.g_bias),
                                                         _ffi.ptr(ws), st))
@@ -294,12 +311,14 @@ class TrainUNet:
                     lo += c
                     continue  # no gradient w.r.t. the input image
                 key = t.data_ptr()
-                if layer.ksize == 2 and fast and c in (32, 64, 128):
+                if fast and c not in (32, 64, 128):
+                    raise RuntimeError(f"{layer.name}: mixed precision needs source widths of 32, 64 or 128 channels")
+                if layer.ksize == 2 and fast:
                     # stride-2 data gradient: eight pointwise products W_p^T dY on the fast kernel, one per parity of the
                     # fine voxel, then interleaved into the fine grid
                     have = key in grads
                     if not have:
-                        grads[key] = torch.empty_like(t)
+                        grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
                     packed = self._pack(layer, 2, 0, c)
                     per = packed.numel() // 8
                     t16 = torch.empty((8, B, ox, oy, oz, c), dtype=torch.float16, device=self.device)
@@ -312,10 +331,10 @@ class TrainUNet:
                 elif layer.ksize == 2:
                     have = key in grads
                     if not have:
-                        grads[key] = torch.empty_like(t)
+                        grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
                     _ffi.check(_ffi.lib.sk_train_conv_dgrad(_ffi.ptr(dy), _ffi.ptr(layer.weight), _ffi.ptr(grads[key]), B,
                                                             ox, oy, oz, cout, layer.cin, 0, layer.cin, 2, int(have), st))
-                elif fast and c in (32, 64, 128):
+                elif fast:
                     # data gradient on the fast conv kernel: the layer's weight packed transposed + tap-flipped
                     dx16 = self._fast_conv([(dy16, 0)], self._pack(layer, True, lo, c), self._zero_bias, (ox, oy, oz), c,
                                            layer.ksize, None)
@@ -325,13 +344,13 @@ class TrainUNet:
                         fine = torch.empty((B, ox, oy, oz, c), dtype=torch.float32, device=self.device)
                         _ffi.check(_ffi.lib.sk_train_cast_f16_f32(_ffi.ptr(dx16), _ffi.ptr(fine), fine.numel(), _ffi.ptr(scale),
                                                                   0, st))
-                        grads[key] = torch.empty_like(t)
+                        grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
                         _ffi.check(_ffi.lib.sk_train_sumpool2(_ffi.ptr(fine), _ffi.ptr(grads[key]), B, ox // 2, oy // 2,
                                                               oz // 2, c, st))
                     else:
                         have = key in grads
                         if not have:
-                            grads[key] = torch.empty_like(t)
+                            grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
                         _ffi.check(_ffi.lib.sk_train_cast_f16_f32(_ffi.ptr(dx16), _ffi.ptr(grads[key]), t.numel(),
                                                                   _ffi.ptr(scale), int(have), st))
                 elif up:
@@ -340,13 +359,13 @@ class TrainUNet:
                                                             oz, cout, layer.cin, lo, c, layer.ksize, 0, st))
                     if key in grads:
                         raise RuntimeError("an upsampled tensor has one consumer in this graph")
-                    grads[key] = torch.empty_like(t)
+                    grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
                     _ffi.check(_ffi.lib.sk_train_sumpool2(_ffi.ptr(fine), _ffi.ptr(grads[key]), B, ox // 2, oy // 2,
                                                           oz // 2, c, st))
                 else:
                     have = key in grads
                     if not have:
-                        grads[key] = torch.empty_like(t)
+                        grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
                     _ffi.check(_ffi.lib.sk_train_conv_dgrad(_ffi.ptr(dy), _ffi.ptr(layer.weight), _ffi.ptr(grads[key]), B,
                                                             ox, oy, oz, cout, layer.cin, lo, c, layer.ksize, int(have), st))
                 lo += c
