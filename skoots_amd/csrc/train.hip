@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(64) wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * cot + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < a.cout) part[((long long)row * a.cin + cig) * k3 + tap] = acc[t][r];
+                if (row < a.cout) part[((long long)tap * a.cout + row) * a.cin + cig] = acc[t][r];  // tap-major: lanes (cin) contiguous
             }
         }
     }
@@ -934,7 +934,7 @@ __global__ void __launch_bounds__(64) wgrad16_kernel(Wgrad16Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * cot + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < a.cout) part[((long long)row * a.cin + cig) * k3 + tap] = acc[t][r];
+                if (row < a.cout) part[((long long)tap * a.cout + row) * a.cin + cig] = acc[t][r];  // tap-major: lanes (cin) contiguous
             }
         }
     }
@@ -1084,7 +1084,7 @@ __global__ void __launch_bounds__(64) wgrad16t_kernel(Wgrad16Args a, const char*
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * cot + (r & 3) + 8 * (r >> 2) + 4 * h;
-            part[((long long)row * a.cin + cig) * k3 + tap] = acc[t][r];
+            part[((long long)tap * a.cout + row) * a.cin + cig] = acc[t][r];
         }
     }
     if (a.part_bias && cit == 0 && grp == 0) {
@@ -1095,8 +1095,7 @@ __global__ void __launch_bounds__(64) wgrad16t_kernel(Wgrad16Args a, const char*
 
 // k = 3 and oz % 16 == 0: a step's 16 voxels lie in one z row, so the three dz taps of a (dx, dy) read the SAME 18
 // input lines shifted by one -- stage that strip once (18 x 64 B) and take the three K-major fragments from it with
-// row-shifted transposed reads.  L2 traffic per step 4.4 KiB instead of 10 (the whole-line kernel is L2-bound:
-// every input line is fetched once per tap).
+// row-shifted transposed reads.
 __device__ __forceinline__ half8_t tr_read_rows(const char* tile, int lane, int row0, int row1) {
     // as tr_read_frag with this lane's two source rows given explicitly (rows of its voxels 8h + q and 8h + 4 + q)
     const int g = lane >> 4, p = lane & 3;
@@ -1112,11 +1111,13 @@ __device__ __forceinline__ half8_t tr_read_rows(const char* tile, int lane, int 
     return r;
 }
 
-__global__ void __launch_bounds__(64) wgrad16s_kernel(Wgrad16Args a, const char* zero_page) {
-    // stage = dy tile | three strip mains (rows 0..15) | the three strips' rows 16, 17 in one tile: 5 DMA instructions
-    // per step (the LDS-DMA issue cost, ~100+ cycles per instruction next to MFMAs, is what bounds this kernel)
-    constexpr int kStage = 5 * 1024;
-    __shared__ __attribute__((aligned(16))) char tiles[2][kStage];
+// Walking y: a wave takes columns (x, 16-voxel z block) and steps through y.  The three rows y-1, y, y+1 of its
+// input plane x + dx - 1 sit in a four-slot LDS ring, so a step fetches ONE new strip (row y+2, for the next step)
+// and one dy tile: 2.2 KiB per step against 10 for the whole-line kernel above.
+__global__ void __launch_bounds__(64) wgrad16y_kernel(Wgrad16Args a, const char* zero_page, int ncol_chunk) {
+    constexpr int kSlot = 2048;                                   // strip slot: rows 0..15 | rows 16, 17 (own DMA tile)
+    __shared__ __attribute__((aligned(16))) char ring[4 * kSlot];
+    __shared__ __attribute__((aligned(16))) char dyt[2][1024];
     const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
     const int lv = lane >> 2, lc = lane & 3;
     int blk = blockIdx.x;
@@ -1147,82 +1148,63 @@ __global__ void __launch_bounds__(64) wgrad16s_kernel(Wgrad16Args a, const char*
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     float bsum = 0.0f;
 
-    const long long q0 = (long long)cb * a.chunk;   // chunk and nvox are multiples of 16 (oz % 16 == 0)
-    long long q1 = q0 + a.chunk;
-    if (q1 > nvox) q1 = nvox;
-    const int ntrip = q1 > q0 ? (int)((q1 - q0) / 16) : 0;
-    // the step's first voxel (wave-uniform walk): z0 advances by 16 inside the row
-    long long q = q0;
-    int z0 = (int)(q % a.oz);
-    long long t2 = q / a.oz;
-    int y = (int)(t2 % a.oy), x = (int)(t2 / a.oy);
+    const int nzb = a.oz / 16, ncol = a.ox * nzb;
+    const int c0 = cb * ncol_chunk, c1 = min(c0 + ncol_chunk, ncol);
+    const int qq = (lane & 15) >> 2;
+    const int v0 = 8 * h + qq, v1 = v0 + 4;   // this lane's voxels of the two transposed reads
 
-    auto issue = [&](int buf) {
-        char* tb = tiles[buf];
-        dma16_tile(dyb + (q + lv) * a.cout * 2, tb);
+    for (int cidx = c0; cidx < c1; ++cidx) {
+        const int x = cidx / nzb, z0 = (cidx % nzb) * 16;
         const int xi = x + grp - 1;
-        const int zs0 = S.up ? ((z0 - 1) >> 1) : (z0 - 1);   // first source line of the strip
-        const char* tailsrc = zp;   // lane (dyi, row 16 + rr, chunk lc) of the tails tile: lanes 0..23
-        const int tdy = lv >> 1, trr = lv & 1;
-#pragma unroll
-        for (int dyi = 0; dyi < 3; ++dyi) {
-            const int yi = y + dyi - 1;
-            const bool rowok = xi >= 0 && xi < Xf && yi >= 0 && yi < Yf;
-            const int xs = S.up ? xi >> 1 : xi, ys = S.up ? yi >> 1 : yi;
+        const bool xok = xi >= 0 && xi < Xf;
+        const int xs = S.up ? xi >> 1 : xi;
+        const int zs0 = S.up ? ((z0 - 1) >> 1) : (z0 - 1);
+        // strip of fine row yr -> ring slot (yr + 1) & 3: main tile (rows 0..15) + tail tile (rows 16, 17)
+        auto load_row = [&](int yr) {
+            char* slot = ring + ((yr + 1) & 3) * kSlot;
+            const bool rowok = xok && yr >= 0 && yr < Yf;
+            const int ys = S.up ? yr >> 1 : yr;
             const char* rowp = sb + (long long)((xs * S.Ys + ys) * S.Zs) * S.C * 2;
             const int zs = zs0 + lv;
-            dma16_tile((rowok && zs >= 0 && zs < S.Zs) ? rowp + (long long)zs * S.C * 2 : zp, tb + 1024 + dyi * 1024);
-            const int zt = zs0 + 16 + trr;
-            if (tdy == dyi && rowok && zt >= 0 && zt < S.Zs) tailsrc = rowp + (long long)zt * S.C * 2;
-        }
-        dma16_tile(tailsrc, tb + 4096);
-        q += 16;
-        z0 += 16;
-        if (z0 >= a.oz) {
-            z0 = 0;
-            if (++y == a.oy) {
-                y = 0;
-                ++x;
+            dma16_tile((rowok && zs >= 0 && zs < S.Zs) ? rowp + (long long)zs * S.C * 2 : zp, slot);
+            const int zt = zs0 + 16 + lv;
+            dma16_tile((rowok && lv < 2 && zt >= 0 && zt < S.Zs) ? rowp + (long long)zt * S.C * 2 : zp, slot + 1024);
+        };
+        auto load_dy = [&](int yy, int buf) {
+            dma16_tile(dyb + ((long long)(x * a.oy + yy) * a.oz + z0 + lv) * a.cout * 2, dyt[buf]);
+        };
+        // the previous column's fragments were all read before its last MFMAs were issued: the ring can be refilled
+        load_row(-1);
+        load_row(0);
+        load_row(1);
+        load_dy(0, 0);
+        for (int y = 0; y < a.oy; ++y) {
+            const bool more = y + 1 < a.oy;
+            if (more) {
+                load_row(y + 2);           // overwrites the slot of row y - 2: dead since step y - 1
+                load_dy(y + 1, (y + 1) & 1);
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // everything but the three loads just issued
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-        }
-    };
-    if (ntrip > 0) issue(0);
-    int zc = (int)(q0 % a.oz);  // z0 of the step being consumed
-    for (int it = 0; it < ntrip; ++it) {
-        const bool more = it + 1 < ntrip;
-        if (more) {
-            issue((it + 1) & 1);
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // 5 instructions per stage
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        const char* tb = tiles[it & 1];
-        const half8_t av = tr_read_frag(tb, lane);
-        // this lane's voxels of the two reads: v = 8h + q and 8h + 4 + q; strip row of voxel v for tap dz: the source
-        // line of fine z = zc + v + dz - 1, relative to the strip's first line
-        const int qq = (lane & 15) >> 2;
-        const int v0 = 8 * h + qq, v1 = v0 + 4;
-        const int zs0 = S.up ? ((zc - 1) >> 1) : (zc - 1);
-        half8_t bv[9];
+            const half8_t av = tr_read_frag(dyt[y & 1], lane);
+            half8_t bv[9];
 #pragma unroll
-        for (int dyi = 0; dyi < 3; ++dyi)
+            for (int dyi = 0; dyi < 3; ++dyi) {
+                const char* slot = ring + ((y + dyi) & 3) * kSlot;   // row y + dyi - 1
 #pragma unroll
-            for (int dz = 0; dz < 3; ++dz) {
-                const int f0 = zc + v0 + dz - 1, f1 = zc + v1 + dz - 1;
-                const int r0 = (S.up ? (f0 >> 1) : f0) - zs0, r1 = (S.up ? (f1 >> 1) : f1) - zs0;
-                // strip row r lives in the main tile (r < 16) or in the tails tile at row 2 * dyi + r - 16; tr_read_rows
-                // takes rows relative to one base, so express both against the stage base
-                const int a0 = r0 < 16 ? (16 * (1 + dyi) + r0) : (64 + 2 * dyi + r0 - 16);
-                const int a1 = r1 < 16 ? (16 * (1 + dyi) + r1) : (64 + 2 * dyi + r1 - 16);
-                bv[dyi * 3 + dz] = tr_read_rows(tb, lane, a0, a1);
+                for (int dz = 0; dz < 3; ++dz) {
+                    const int f0 = z0 + v0 + dz - 1, f1 = z0 + v1 + dz - 1;
+                    const int r0 = (S.up ? (f0 >> 1) : f0) - zs0, r1 = (S.up ? (f1 >> 1) : f1) - zs0;
+                    bv[dyi * 3 + dz] = tr_read_rows(slot, lane, r0, r1);   // rows 16, 17 are rows 0, 1 of the tail tile
+                }
             }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bsum += (float)av[j];
+            for (int j = 0; j < 8; ++j) bsum += (float)av[j];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv[t], acc[t], 0, 0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        zc += 16;
-        if (zc >= a.oz) zc = 0;
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv[t], acc[t], 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
     }
     float* part = a.part + (long long)chunk * a.cout * a.cin * 27;
     const int cig = ci0 + col;
@@ -1232,7 +1214,7 @@ __global__ void __launch_bounds__(64) wgrad16s_kernel(Wgrad16Args a, const char*
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * cot + (r & 3) + 8 * (r >> 2) + 4 * h;
-            part[((long long)row * a.cin + cig) * 27 + tap] = acc[t][r];
+            part[((long long)tap * a.cout + row) * a.cin + cig] = acc[t][r];
         }
     }
     if (a.part_bias && cit == 0 && grp == 0) {
@@ -1337,9 +1319,12 @@ __global__ void __launch_bounds__(256) gn_silu_mixed_kernel(const __half* __rest
     }
 }
 
-// out[i] = sum over chunks of part[c][i] (fixed order -> deterministic): 64 elements per block, four chunk slices
+// out = sum over chunks of part[c] (fixed order -> deterministic): 64 elements per block, four chunk slices.
+// k3 > 0: the partials are tap-major (tap, cout, cin) -- written with the lanes (cin) contiguous -- and the result
+// goes to the torch layout (cout, cin, k3); k3 == 0: same layout in and out.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int nchunk, long long n,
-                                                           float* __restrict__ out, const float* __restrict__ scale) {
+                                                           float* __restrict__ out, const float* __restrict__ scale, int cout,
+                                                           int cin, int k3) {
     __shared__ double red[256];
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 64 + e;
@@ -1350,7 +1335,14 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     __syncthreads();
     if (sl == 0 && i < n) {
         s = ((red[e] + red[64 + e]) + red[128 + e]) + red[192 + e];
-        out[i] = scale ? (float)(s * (double)scale[1]) : (float)s;
+        long long o = i;
+        if (k3 > 0) {
+            const int ci = (int)(i % cin);
+            const long long t = i / cin;
+            const int row = (int)(t % cout), tap = (int)(t / cout);
+            o = ((long long)row * cin + ci) * k3 + tap;
+        }
+        out[o] = scale ? (float)(s * (double)scale[1]) : (float)s;
     }
 }
 
@@ -1582,7 +1574,8 @@ int sk_train_conv_wgrad(const sk_conv_src* srcs, int n_src, const float* dy, int
     a.part_bias = dbias ? workspace + (long long)a.nchunk * nw : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((long long)a.nchunk * a.ncot * a.ncit * a.ngroup);
-    if (ksize == 3 && n_src == 1 && a.cin == 1 && !a.src[0].up)
+    const bool stem = ksize == 3 && n_src == 1 && a.cin == 1 && !a.src[0].up;
+    if (stem)
         wgrad_stem_kernel<<<(unsigned)((long long)a.nchunk * a.ncot), 64, 0, st>>>(a);
     else if (ksize == 3)
         wgrad_kernel<9><<<grid, 64, 0, st>>>(a);
@@ -1591,10 +1584,10 @@ int sk_train_conv_wgrad(const sk_conv_src* srcs, int n_src, const float* dy, int
     else
         wgrad_kernel<1><<<grid, 64, 0, st>>>(a);
     SK_CHECK_LAUNCH();
-    wgrad_reduce_kernel<<<sk::cdiv(nw, 64), 256, 0, st>>>(a.part, a.nchunk, nw, dweight, nullptr);
+    wgrad_reduce_kernel<<<sk::cdiv(nw, 64), 256, 0, st>>>(a.part, a.nchunk, nw, dweight, nullptr, cout, a.cin, stem ? 0 : ksize * ksize * ksize);
     SK_CHECK_LAUNCH();
     if (dbias) {
-        wgrad_reduce_kernel<<<sk::cdiv(cout, 64), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, nullptr);
+        wgrad_reduce_kernel<<<sk::cdiv(cout, 64), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, nullptr, 0, 0, 0);
         SK_CHECK_LAUNCH();
     }
     return SK_OK;
@@ -1647,7 +1640,9 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
     for (int i = 0; i < n_src; ++i) lines = lines && srcs[i].c % 32 == 0;
     if (lines && ksize == 3 && oz % 16 == 0 && !getenv("SK_WGRAD_NOSTRIP")) {
         a.ngroup = 3;
-        wgrad16s_kernel<<<(unsigned)((long long)a.nchunk * a.ncot * a.ncit * 3), 64, 0, st>>>(a, (const char*)zero_page);
+        const unsigned g3 = (unsigned)((long long)a.nchunk * a.ncot * a.ncit * 3);
+        const int ncol = ox * (oz / 16);
+        wgrad16y_kernel<<<g3, 64, 0, st>>>(a, (const char*)zero_page, (ncol + a.nchunk_b - 1) / a.nchunk_b);
     } else if (lines) {
         if (ksize == 3) {
             // three taps per wave (nine tap groups): 8 KiB of LDS tiles per wave instead of 20, so ~2.5x the waves
@@ -1672,10 +1667,10 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
     else
         wgrad16_kernel<1><<<grid, 64, 0, st>>>(a);
     SK_CHECK_LAUNCH();
-    wgrad_reduce_kernel<<<sk::cdiv(nw, 64), 256, 0, st>>>(a.part, a.nchunk, nw, dweight, dy_scale);
+    wgrad_reduce_kernel<<<sk::cdiv(nw, 64), 256, 0, st>>>(a.part, a.nchunk, nw, dweight, dy_scale, cout, a.cin, ksize * ksize * ksize);
     SK_CHECK_LAUNCH();
     if (dbias) {
-        wgrad_reduce_kernel<<<sk::cdiv(cout, 64), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, dy_scale);
+        wgrad_reduce_kernel<<<sk::cdiv(cout, 64), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, dy_scale, 0, 0, 0);
         SK_CHECK_LAUNCH();
     }
     return SK_OK;
