@@ -621,6 +621,12 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
     }
     if (p.nposp > 64 * kMaxDma) return -1;
     p.lds = (size_t)(p.xs + 2) * (p.nposp + 1) * kPosBytes + 4 * kPadBytes;
+    // Two workgroups per CU need <= 80 KiB each.  The rectangle patches (208 positions a plane) miss that with a
+    // 6-plane ring: run them with XS = 3 (5 planes); measured on the 512x512x128 tile (SK_CONV_RECT_XS4=1 to compare).
+    if (p.xs == 4 && p.lds > 80 * 1024 && !getenv("SK_CONV_RECT_XS4")) {
+        p.xs = 3;
+        p.lds = (size_t)(p.xs + 2) * (p.nposp + 1) * kPosBytes + 4 * kPadBytes;
+    }
     // x-chunks: enough workgroups to fill the CUs (2 per CU) several times over
     int target = 256 * 2 * 6;
     int nxc = (target + p.npatch * B - 1) / (p.npatch * B);
@@ -757,6 +763,7 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
             const char* e = getenv("SK_CONV_ABLATE");
             a.ablate = e ? atoi(e) : 0;
         }
+        if (p.xs == 3) return cout == 32 ? launch_conv3<32, 3>(a, p, stream) : launch_conv3<64, 3>(a, p, stream);
         if (cout == 32 && a.nchunks == 1 && !a.ablate) return launch_conv3<32, 4, 3>(a, p, stream);
         if (cout == 32) return launch_conv3<32, 4>(a, p, stream);
         if (cout == 64) return launch_conv3<64, 4>(a, p, stream);
