@@ -329,7 +329,7 @@ int64_t sk_train_conv_wgrad_workspace_floats(int B, int ox, int oy, int oz, int 
  * sk_train_pack_weight: device-side sk_conv3d_pack_weight_host of the CURRENT fp32 weight (Co, Ci, k, k, k);
  *   transposed != 0 packs the data-gradient operator of input channels [c_lo, c_lo + c_n) instead
  *   (rows = those input channels, K = Co, taps flipped).  dst: k^3 * (cin_eff/16) * (cout_eff/32) KiB.
- * sk_train_gn_silu_mixed: raw fp16 conv output -> y32 (raw), z32 and z16 (GroupNorm affine + SiLU). */
+ */
 int sk_train_pack_weight(const float* weight, int Co, int Ci, int ksize, int transposed, int c_lo,
                          int c_n, void* dst, void* stream);
 /* transposed == 2: transposed WITHOUT the tap flip -- the stride-2 (ksize 2) data gradient in scatter form:
@@ -338,8 +338,6 @@ int sk_train_pack_weight(const float* weight, int Co, int Ci, int ksize, int tra
  * dx (B, 2cx, 2cy, 2cz, Ci) (+)= t16[parity][coarse voxel] * scale[1]. */
 int sk_train_interleave2(const void* t16, float* dx, int B, int cx, int cy, int cz, int C,
                          const float* scale, int accumulate, void* stream);
-int sk_train_gn_silu_mixed(const void* y16, const float* affine, float* y32, float* z32, void* z16,
-                           int B, int64_t voxels, int C, void* stream);
 /* Lean mixed data flow: sk_train_gn_silu_f16: raw fp16 conv output -> z16 (and z32 if not NULL).
  * sk_train_gn_silu_bwd_f16: dz (fp32) and the RAW fp16 output -> dy16 = fp16(dy * scale[0]) with scale (3 floats,
  * device: 2^k, 2^-k, bound) chosen from an upper bound of max|dy| formed in the reduction pass; dgamma, dbeta as

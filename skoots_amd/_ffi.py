@@ -92,7 +92,6 @@ _SIGS = {
     "sk_train_conv_wgrad_workspace_floats": (i64, [i32, i32, i32, i32, i32, i32, i32]),
     "sk_train_pack_weight": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "sk_train_interleave2": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
-    "sk_train_gn_silu_mixed": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, vp]),
     "sk_train_gn_silu_f16": (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
     "sk_train_gn_silu_bwd_f16": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp, vp]),
     "sk_train_gn_bwd_f16_workspace_floats": (i64, [i32, i64, i32]),

@@ -1301,24 +1301,6 @@ __global__ void __launch_bounds__(256) interleave2_kernel(const __half* __restri
     }
 }
 
-// GroupNorm affine + SiLU of a RAW fp16 conv output, writing what the mixed-precision step keeps:
-// y32 (raw, for the backward), z32 (activated) and z16 (activated, the next fast conv's source).
-__global__ void __launch_bounds__(256) gn_silu_mixed_kernel(const __half* __restrict__ y16, const float* __restrict__ affine,
-                                                            float* __restrict__ y32, float* __restrict__ z32,
-                                                            __half* __restrict__ z16, int C, long long n_per_batch) {
-    const int b = blockIdx.y;
-    const long long off = (long long)b * n_per_batch;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_per_batch; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const float yv = __half2float(y16[off + i]);
-        const float u = fmaf(affine[(long long)b * 2 * C + c], yv, affine[(long long)b * 2 * C + C + c]);
-        const float z = u / (1.0f + expf(-u));
-        y32[off + i] = yv;
-        z32[off + i] = z;
-        z16[off + i] = __float2half_rn(z);
-    }
-}
-
 // out = sum over chunks of part[c] (fixed order -> deterministic): 64 elements per block, four chunk slices.
 // k3 > 0: the partials are tap-major (tap, cout, cin) -- written with the lanes (cin) contiguous -- and the result
 // goes to the torch layout (cout, cin, k3); k3 == 0: same layout in and out.
@@ -1744,16 +1726,6 @@ int sk_train_gn_silu_bwd_f16(const float* dz, const void* y16, const float* affi
     long long n = voxels * C;
     gn_bwd_apply16_kernel<<<dim3(sk::stream_grid(n, 256, 4), B), 256, 0, st>>>(dz, (const __half*)y16, affine, stats, coef, scale,
                                                                                (__half*)dy16, C, groups, n);
-    SK_CHECK_LAUNCH();
-    return SK_OK;
-}
-
-int sk_train_gn_silu_mixed(const void* y16, const float* affine, float* y32, float* z32, void* z16, int B, int64_t voxels,
-                           int C, void* stream) {
-    SK_CHECK_ARG(y16 && affine && y32 && z32 && z16 && C > 0, "sk_train_gn_silu_mixed: bad arguments");
-    long long n = voxels * C;
-    gn_silu_mixed_kernel<<<dim3(sk::stream_grid(n, 256, 4), B), 256, 0, (hipStream_t)stream>>>(
-        (const __half*)y16, affine, y32, z32, (__half*)z16, C, n);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
