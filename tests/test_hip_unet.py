@@ -234,3 +234,20 @@ def test_end_to_end_with_network_fp32_mode(U, shape):
         assert np.array_equal(got["instance_mask"].cpu().numpy(), want["instance_mask"])
     else:
         assert (got["instance_mask"].cpu().numpy() != want["instance_mask"]).mean() < 5e-3
+
+
+def test_eval_is_deterministic(U):
+    """Same volume, same weights, two runs of the whole path (fast fp16 network included): bit-identical vectors,
+    skeleton, labels and instance mask -- every reduction in the kernels has a fixed order, the label kernels'
+    atomics are min/first-seen only."""
+    from skoots_amd.lib import eval as E
+    hip = U.smoke_model(DEV)
+    gen = torch.Generator().manual_seed(11)
+    vol = torch.randint(0, 256, (1, 150, 140, 30), generator=gen).to(torch.float16).to(DEV)
+    a = E.eval_volume(vol, hip, (60, 60, 12), keep_planar_vectors=True)
+    b = E.eval_volume(vol, hip, (60, 60, 12), keep_planar_vectors=True)
+    assert torch.equal(a["state"].vec4, b["state"].vec4)
+    assert torch.equal(a["skeleton"], b["skeleton"])
+    assert torch.equal(a["labels"], b["labels"])
+    assert torch.equal(a["instance_mask"], b["instance_mask"])
+    assert a["n_instances"] == b["n_instances"]
