@@ -344,6 +344,24 @@ def test_train_step_mixed_precision_vs_oracle():
     print(f"mixed precision: worst gradient error / max = {worst:.2e}")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "mixed"])
+def test_training_step_is_deterministic(precision):
+    """Two runs of forward + loss + backward from the same state give bit-identical gradients: every reduction is
+    two-stage with a fixed order (no floating-point atomics)."""
+    from skoots_amd.train import TrainStep, TrainUNet
+    from skoots_amd.unet import random_state_dict
+    model = TrainUNet(random_state_dict(), DEV, precision=precision)
+    step = TrainStep(model)
+    images, masks, skele, baked = (t.to(DEV) for t in _synthetic_batch(1, 32, 20, 16, 9))
+    grads = []
+    for _ in range(2):
+        logits = model.forward(images)
+        _, dl = step.fused_loss(logits, masks, skele, baked, [20.0, 20.0, 20.0])
+        model.backward(dl)
+        grads.append(model.flat_grad.clone())
+    assert torch.equal(grads[0], grads[1])
+
+
 def test_trained_weights_feed_the_eval_path(tmp_path):
     """The trainer's checkpoint (cfg, model_state_dict, optimizer_state_dict) loads with the safe loader and
     drives the inference runner; the optimizer state restores into a fresh TrainStep."""
