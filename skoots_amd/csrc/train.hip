@@ -15,6 +15,8 @@
 // is deterministic.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1111,10 +1113,22 @@ __device__ __forceinline__ half8_t tr_read_rows(const char* tile, int lane, int 
     return r;
 }
 
+__device__ __forceinline__ half8_t tr_read_at(const char* p0, const char* p1) {
+    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p0);
+    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p1);
+    half8_t r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = (_Float16)lo[j];
+        r[4 + j] = (_Float16)hi[j];
+    }
+    return r;
+}
+
 // Walking y: a wave takes columns (x, 16-voxel z block) and steps through y.  The three rows y-1, y, y+1 of its
 // input plane x + dx - 1 sit in a four-slot LDS ring, so a step fetches ONE new strip (row y+2, for the next step)
 // and one dy tile: 2.2 KiB per step against 10 for the whole-line kernel above.
-__global__ void __launch_bounds__(64) wgrad16y_kernel(Wgrad16Args a, const char* zero_page, int ncol_chunk) {
+__global__ void __launch_bounds__(64, 2) wgrad16y_kernel(Wgrad16Args a, const char* zero_page, int ncol_chunk) {
     constexpr int kSlot = 2048;                                   // strip slot: rows 0..15 | rows 16, 17 (own DMA tile)
     __shared__ __attribute__((aligned(16))) char ring[4 * kSlot];
     __shared__ __attribute__((aligned(16))) char dyt[2][1024];
@@ -1147,11 +1161,13 @@ __global__ void __launch_bounds__(64) wgrad16y_kernel(Wgrad16Args a, const char*
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     float bsum = 0.0f;
+    const bool want_bias = a.part_bias != nullptr && cit == 0 && grp == 0;
 
     const int nzb = a.oz / 16, ncol = a.ox * nzb;
     const int c0 = cb * ncol_chunk, c1 = min(c0 + ncol_chunk, ncol);
     const int qq = (lane & 15) >> 2;
     const int v0 = 8 * h + qq, v1 = v0 + 4;   // this lane's voxels of the two transposed reads
+    const int lane_off = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;   // its 4 columns of a 64-byte tile row
 
     for (int cidx = c0; cidx < c1; ++cidx) {
         const int x = cidx / nzb, z0 = (cidx % nzb) * 16;
@@ -1159,51 +1175,67 @@ __global__ void __launch_bounds__(64) wgrad16y_kernel(Wgrad16Args a, const char*
         const bool xok = xi >= 0 && xi < Xf;
         const int xs = S.up ? xi >> 1 : xi;
         const int zs0 = S.up ? ((z0 - 1) >> 1) : (z0 - 1);
-        // strip of fine row yr -> ring slot (yr + 1) & 3: main tile (rows 0..15) + tail tile (rows 16, 17)
-        auto load_row = [&](int yr) {
-            char* slot = ring + ((yr + 1) & 3) * kSlot;
-            const bool rowok = xok && yr >= 0 && yr < Yf;
-            const int ys = S.up ? yr >> 1 : yr;
-            const char* rowp = sb + (long long)((xs * S.Ys + ys) * S.Zs) * S.C * 2;
-            const int zs = zs0 + lv;
-            dma16_tile((rowok && zs >= 0 && zs < S.Zs) ? rowp + (long long)zs * S.C * 2 : zp, slot);
-            const int zt = zs0 + 16 + lv;
-            dma16_tile((rowok && lv < 2 && zt >= 0 && zt < S.Zs) ? rowp + (long long)zt * S.C * 2 : zp, slot + 1024);
+        // Column invariants.  Strip of fine row yr -> ring slot (yr + 1) & 3: main tile (rows 0..15) + tail tile (rows
+        // 16, 17).  The y loop is unrolled by four (oy % 4 == 0), which makes every ring slot and dy buffer a
+        // compile-time constant: the 20 transposed reads of a step take immediate offsets from six per-lane bases and
+        // the step's bookkeeping shrinks from ~140 instructions (it, not the MFMAs or the loads, bounded the kernel
+        // at one wave per SIMD) to a few pointer increments.
+        const int zsm = zs0 + lv, zst = zs0 + 16 + lv;
+        const bool mok = xok && zsm >= 0 && zsm < S.Zs, tok = xok && lv < 2 && zst >= 0 && zst < S.Zs;
+        const long long rowstride = (long long)S.Zs * S.C * 2;
+        const char* colm = sb + ((long long)xs * S.Ys * S.Zs + zsm) * S.C * 2;   // + ys * rowstride
+        const char* colt = sb + ((long long)xs * S.Ys * S.Zs + zst) * S.C * 2;
+        const long long dystride = (long long)a.oz * a.cout * 2;
+        const char* dycol = dyb + ((long long)x * a.oy * a.oz + z0 + lv) * a.cout * 2;      // + y * dystride
+        int roff[3][2];   // byte offset inside a slot of this lane's two transposed reads, per dz
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+            const int f0 = z0 + v0 + dz - 1, f1 = z0 + v1 + dz - 1;
+            roff[dz][0] = ((S.up ? (f0 >> 1) : f0) - zs0) * 64 + lane_off;
+            roff[dz][1] = ((S.up ? (f1 >> 1) : f1) - zs0) * 64 + lane_off;
+        }
+        auto load_row = [&](int yr, int slot_idx) {
+            char* slot = ring + slot_idx * kSlot;
+            const bool rowok = yr >= 0 && yr < Yf;
+            const long long ro = (long long)(S.up ? yr >> 1 : yr) * rowstride;
+            dma16_tile((rowok && mok) ? colm + ro : zp, slot);
+            dma16_tile((rowok && tok) ? colt + ro : zp, slot + 1024);
         };
-        auto load_dy = [&](int yy, int buf) {
-            dma16_tile(dyb + ((long long)(x * a.oy + yy) * a.oz + z0 + lv) * a.cout * 2, dyt[buf]);
-        };
-        // the previous column's fragments were all read before its last MFMAs were issued: the ring can be refilled
-        load_row(-1);
-        load_row(0);
-        load_row(1);
-        load_dy(0, 0);
-        for (int y = 0; y < a.oy; ++y) {
-            const bool more = y + 1 < a.oy;
-            if (more) {
-                load_row(y + 2);           // overwrites the slot of row y - 2: dead since step y - 1
-                load_dy(y + 1, (y + 1) & 1);
+        auto step = [&](int y, auto Uc) {
+            constexpr int U = decltype(Uc)::value;   // y & 3
+            if (y + 1 < a.oy) {
+                load_row(y + 2, (U + 3) & 3);        // overwrites the slot of row y - 2: dead since step y - 1
+                dma16_tile(dycol + (long long)(y + 1) * dystride, dyt[(U + 1) & 1]);
                 asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // everything but the three loads just issued
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            const half8_t av = tr_read_frag(dyt[y & 1], lane);
+            const half8_t av = tr_read_frag(dyt[U & 1], lane);
             half8_t bv[9];
 #pragma unroll
             for (int dyi = 0; dyi < 3; ++dyi) {
-                const char* slot = ring + ((y + dyi) & 3) * kSlot;   // row y + dyi - 1
+                const char* slot = ring + ((U + dyi) & 3) * kSlot;   // row y + dyi - 1
 #pragma unroll
-                for (int dz = 0; dz < 3; ++dz) {
-                    const int f0 = z0 + v0 + dz - 1, f1 = z0 + v1 + dz - 1;
-                    const int r0 = (S.up ? (f0 >> 1) : f0) - zs0, r1 = (S.up ? (f1 >> 1) : f1) - zs0;
-                    bv[dyi * 3 + dz] = tr_read_rows(slot, lane, r0, r1);   // rows 16, 17 are rows 0, 1 of the tail tile
-                }
+                for (int dz = 0; dz < 3; ++dz) bv[dyi * 3 + dz] = tr_read_at(slot + roff[dz][0], slot + roff[dz][1]);
             }
+            if (want_bias) {   // wave-uniform: only the (cin tile 0, dx 0) waves sum dy for the bias gradient
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bsum += (float)av[j];
+                for (int j = 0; j < 8; ++j) bsum += (float)av[j];
+            }
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv[t], acc[t], 0, 0, 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        // the previous column's fragments were all read before its last MFMAs were issued: the ring can be refilled
+        load_row(-1, 0);
+        load_row(0, 1);
+        load_row(1, 2);
+        dma16_tile(dycol, dyt[0]);
+        for (int y = 0; y < a.oy; y += 4) {
+            step(y, std::integral_constant<int, 0>{});
+            step(y + 1, std::integral_constant<int, 1>{});
+            step(y + 2, std::integral_constant<int, 2>{});
+            step(y + 3, std::integral_constant<int, 3>{});
         }
     }
     float* part = a.part + (long long)chunk * a.cout * a.cin * 27;
@@ -1620,7 +1652,7 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
     const unsigned grid = (unsigned)((long long)a.nchunk * a.ncot * a.ncit * a.ngroup);
     bool lines = zero_page != nullptr && cout % 32 == 0;  // whole 64-byte channel lines: LDS-DMA + transposed reads
     for (int i = 0; i < n_src; ++i) lines = lines && srcs[i].c % 32 == 0;
-    if (lines && ksize == 3 && oz % 16 == 0 && !getenv("SK_WGRAD_NOSTRIP")) {
+    if (lines && ksize == 3 && oz % 16 == 0 && oy % 4 == 0 && !getenv("SK_WGRAD_NOSTRIP")) {
         a.ngroup = 3;
         const unsigned g3 = (unsigned)((long long)a.nchunk * a.ncot * a.ncit * 3);
         const int ncol = ox * (oz / 16);

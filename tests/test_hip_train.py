@@ -140,9 +140,10 @@ BWD_CASES = [
     (1, (5, 3, 4), [(128, 0)], 64, 1),             # pointwise reducer
     (2, (6, 5, 4), [(32, 0)], 5, 1),               # heads
     (1, (33, 20, 9), [(32, 0)], 32, 3),            # several reduction chunks
-    (2, (5, 6, 16), [(32, 0)], 32, 3),             # z % 16 == 0: the strip-sharing fp16 kernel
-    (1, (4, 6, 32), [(32, 0), (32, 1)], 32, 3),    # ... with an upsampled half
-    (1, (40, 9, 16), [(64, 0)], 64, 3),            # ... several chunks, 2 x 2 tiles
+    (2, (5, 8, 16), [(32, 0)], 32, 3),             # z % 16 == 0, y % 4 == 0: the strip-ring fp16 kernel
+    (1, (4, 12, 32), [(32, 0), (32, 1)], 32, 3),   # ... with an upsampled half
+    (1, (40, 8, 16), [(64, 0)], 64, 3),            # ... several chunks, 2 x 2 tiles
+    (1, (6, 6, 16), [(32, 0)], 32, 3),             # y % 4 != 0: whole-line kernel
 ]
 
 
