@@ -242,7 +242,7 @@ def main():
                        "instances": int(res.get("n_instances", -1)), "blobs_injected": n_blobs,
                        "stage_ms": {k: round(v / (args.steps + args.warmup) * 1e3, 2)
                                     for k, v in sv.timings.items()}},
-            "roofline": {"bound": "mfma", "kernel": "conv3_kernel<COUT,XS> (all 3x3x3 MFMA conv launches)",
+            "roofline": {"bound": "mfma", "kernel": "conv3_m16_kernel / conv3_kernel (all 3x3x3 MFMA conv launches)",
                          "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(achieved / 2500.0, 4), "traffic": conv_hbm_traffic(),
                          "traffic_unit": "bytes per launch (PMC, profiles/r01_conv_hbm_traffic_pmc.json)",

@@ -451,6 +451,401 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// COUT 32 runs on v_mfma_f32_16x16x32_f16 (conv3_m16_kernel): tools/mfma_shape_probe.hip sustains 1.9 PFLOP/s with
+// that shape against 1.65 with 32x32x16 on this part, and the COUT-32 variant has the registers for it (a 32 x 32
+// tile becomes 2 x 2 results of 16 x 16; K = 32 = the whole channel chunk per instruction; the 16-byte chunk
+// swizzle of the staged planes and the fragment packing differ, see below).  A/B on one device: -5 % time on each of
+// the three COUT-32 layers (55 % of the conv time).  With this shape the COUT 64 / 128 variants spill, or lose
+// reuse when XS is cut to fit (+6 % / +15 % time): they stay on conv3_kernel (32x32x16) above.
+//
+// RES: rows (dy,dz) of the 9 whose weight fragments stay in registers for the whole workgroup -- only for
+// single-chunk layers (the same 54 fragments every step) of COUT 32, where the kernel leaves ~80 of its 256
+// registers: 3 rows = 18 fragments = 72 VGPRs (246 in all; 4 rows spill), the other 6 rows stream as before.
+// (Keeping chunk 0's rows resident in a two-chunk layer, selected at run time per phase, spills: 1.8x slower;
+// requesting a whole row of streamed fragments two bodies ahead instead of one measured 4 % slower.)
+// Measured A/B on one device: -4..5 % time on enc0.1 / dec0.1.
+template <int COUT, int XS, int RES = 0>
+__global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
+    constexpr int NT = COUT / 32;
+    constexpr int P = NT;            // column tiles per wave
+    constexpr int R = XS + 2;
+    constexpr bool kLateWait = (NT != 2);  // wait for the next phase's DMA after the epilogue (see there)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w % NT;           // cout tile of this wave
+    const int wm = w / NT;           // voxel group of this wave
+    // v_mfma_f32_16x16x32_f16 operand roles: c16 = row of A (cout) / column of B (voxel), g = 8-wide K group;
+    // a 32 x 32 (cout, voxel) tile is 2 x 2 of its 16 x 16 results: i = cout half, j = voxel half.
+    const int c16 = lane & 15, g = lane >> 4;
+
+    // Workgroups are dealt round-robin over the 8 XCDs (private L2 each).  Neighbouring patches
+    // share their y/z halo and consecutive x-chunks share two planes: give each XCD a contiguous
+    // run of the (batch, x-chunk, patch) order so those re-reads hit its own L2 (bijective remap).
+    int blk = blockIdx.x;
+    if (!(a.ablate & 16)) {
+        const int nwg = gridDim.x, xcd = blk & 7, qn = nwg >> 3, rn = nwg & 7;
+        blk = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blk >> 3);
+    }
+    const int patch = blk % a.npatch;
+    blk /= a.npatch;
+    const int xc = blk % a.nxc;
+    const int b = blk / a.nxc;
+    const int block_in_batch = xc * a.npatch + patch;
+    const int nblk = a.npatch * a.nxc;
+
+    // ---- patch geometry ------------------------------------------------------------
+    const int pitch = a.pitch;
+    int off, ybase, zbase;      // region position q -> (y, z): Pq = q + off; y = ybase + Pq/pitch; z = zbase + Pq%pitch
+    int q_row[P];               // region position of this lane's voxel c16 of column tile p (voxel 16 + c16: + 16)
+    int out_vox0[P];            // in-plane voxel index of column 0 of tile p (the 32 columns are contiguous)
+    int tile_nvox[P];           // columns with out_vox0 + c < tile_nvox are inside the tile
+    // per-lane flags of voxel (p, j), bit 2p + j: on the z = 0 face (linear mode) | << 8: on the z = Zt-1 face | << 16:
+    // inside the tile.  One VGPR instead of 3 x 2P lane masks (the COUT 128 variant spilled on those).
+    unsigned vflags = 0;
+    auto zlo = [&](int p, int j) { return (vflags >> (2 * p + j)) & 1u; };
+    auto zhi = [&](int p, int j) { return (vflags >> (8 + 2 * p + j)) & 1u; };
+    auto vvalid = [&](int p, int j) { return (vflags >> (16 + 2 * p + j)) & 1u; };
+    if (a.mode == 0) {
+        // Linear mode: region position q <-> in-plane voxel index v0 - Zt - 1 + q, NO z halo (pitch = Zt), so
+        // the 32 columns of a tile are 32 consecutive positions for every tap: with the 16-byte chunk swizzle
+        // below any 16 consecutive positions cover all 64 banks, i.e. every ds_read_b128 lane group is
+        // conflict-free (a z halo makes q jump by 2 at each row end: SQ_LDS_BANK_CONFLICT was ~50 % of the
+        // LDS cycles).  A dz = -1 / +1 tap on the z = 0 / Zt-1 face would read the neighbouring row's voxel:
+        // those lanes read the plane's zero position instead (one v_cndmask on the address).
+        int v0 = patch * kPatch;
+        off = v0 - a.Zt - 1;
+        ybase = 0;
+        zbase = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int v = v0 + 32 * (wm * P + p) + 16 * j + c16;
+                int vy = v / a.Zt, vz = v - vy * a.Zt;
+                vflags |= (unsigned)(v < a.Yt * a.Zt) << (16 + 2 * p + j);
+                vflags |= (unsigned)(vz == 0) << (2 * p + j);
+                vflags |= (unsigned)(vz == a.Zt - 1) << (8 + 2 * p + j);
+                if (j == 0) q_row[p] = v - off;
+            }
+            out_vox0[p] = v0 + 32 * (wm * P + p);
+            tile_nvox[p] = a.Yt * a.Zt;
+        }
+    } else {
+        const int TY = kPatch / a.TZ;
+        int yg = patch / a.nzc, zc = patch - yg * a.nzc;
+        int y0 = yg * TY, zc0 = zc * a.TZ;
+        off = 0;
+        ybase = y0 - 1;
+        zbase = zc0 - 1;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int vl = 32 * (wm * P + p) + 16 * j + c16;
+                int yl = vl / a.TZ, zl = vl - yl * a.TZ;
+                int vy = y0 + yl, vz = zc0 + zl;
+                vflags |= (unsigned)(vy < a.Yt && vz < a.Zt) << (16 + 2 * p + j);
+                if (j == 0) q_row[p] = (yl + 1) * pitch + (zl + 1);
+            }
+            // a column tile is one 32-voxel z segment of one line (TZ == 32)
+            const int ty = y0 + (32 * (wm * P + p)) / a.TZ;
+            out_vox0[p] = ty * a.Zt + zc0;
+            tile_nvox[p] = ty < a.Yt ? ty * a.Zt + a.Zt : 0;
+        }
+    }
+
+    // ---- DMA bookkeeping: this lane's slots of a plane --------------------------------
+    const int ndma = a.nposp / 16;  // wave-instructions per plane
+    int d_vox[kMaxDma], d_up[kMaxDma], d_cs[kMaxDma];
+#pragma unroll
+    for (int k = 0; k < kMaxDma; ++k) {
+        int t = w + 4 * k;
+        int slot = 64 * t + lane;
+        int q = slot >> 2, c = slot & 3;
+        int Pq = q + off;        // linear mode: the voxel index itself (may be < 0 above the tile)
+        int y = ybase + (Pq >= 0 ? Pq / pitch : -1), z = zbase + (Pq >= 0 ? Pq % pitch : 0);
+        bool ok = (t < ndma) && y >= 0 && y < a.Yt && z >= 0 && z < a.Zt;
+        d_vox[k] = ok ? y * a.Zt + z : -1;
+        d_up[k] = ok ? (y >> 1) * a.src[1].Zs + (z >> 1) : -1;
+        // source 16-byte chunk (swizzle on the SOURCE side): slot s of position q holds chunk s ^ 2*((q>>2)&1), which
+        // makes every ds_read_b128 lane group of the B reads (16 positions x the wave's 4 K groups) conflict-free
+        // for any alignment of the 16 consecutive positions (searched exhaustively)
+        d_cs[k] = (c ^ (((q >> 2) & 1) << 1)) * 16;
+    }
+
+    // ---- accumulators + GroupNorm partials ----------------------------------------------
+    f32x4 acc[P][XS][2][2];   // [i = cout half][j = voxel half]; element r: cout 32 wn + 16 i + 4 g + r, voxel 16 j + c16
+    float gsum[2], gsq[2];    // channel quad 4 i + g of the wave's cout tile
+#pragma unroll
+    for (int q = 0; q < 2; ++q) gsum[q] = gsq[q] = 0.0f;
+
+    const int xa = xc * a.XC;
+    const int xb = min(xa + a.XC, a.Xt);
+    const int plane_bytes = (a.nposp + 1) * kPosBytes;  // + the zero position (never written by the DMA)
+    const int zero_addr = a.nposp * kPosBytes;
+    const bool ring = (a.nchunks == 1);
+    const long long out_plane = (long long)a.Yt * a.Zt * COUT * 2;
+    char* outb = a.out + (long long)b * a.Xt * out_plane;
+
+    // bias is the initial accumulator: cout = 32 wn + 16 i + 4 g + r (re-read per step: 8 registers less in the loop)
+    const float* biasp = a.bias + 32 * wn + 4 * g;
+
+    // ---- phase sequence ---------------------------------------------------------------------
+    // A phase = (step, chunk): 27 taps of one 32-channel chunk for the XS output planes of a step.
+    // After a phase's MFMAs: barrier (LDS planes free) -> LDS-DMA of the NEXT phase's planes ->
+    // wait for it -> if the step is complete, its epilogue (transpose + stores + GroupNorm
+    // partials) -> bare s_barrier.  The epilogue's global stores are never waited for.
+    const int nsteps = (xb - xa + XS - 1) / XS;
+    const int nphases = nsteps * a.nchunks;
+    char* pad = lds + R * plane_bytes + w * kPadBytes;
+    char* trash = const_cast<char*>(a.zeros) + 2048 + lane * 16;  // upper half of the zero page: write-only scratch
+    const int rv = lane >> 2, rc = lane & 3;  // epilogue read-back: voxel (0..15), 16-byte chunk
+
+    auto issue_dma = [&](int step, int ch) {
+        const int x0 = xa + step * XS;
+        const int si = ch < a.c0chunks ? 0 : 1;
+        const SrcDev s = a.src[si];
+        const int choff = (ch - (si ? a.c0chunks : 0)) * kChunk * 2;  // byte offset of the chunk
+        const int first_new = (ring && step > 0) ? 2 : 0;  // planes 0,1 survive in the ring
+        for (int i = (a.ablate & 1) ? R : first_new; i < R; ++i) {
+            const int x = x0 - 1 + i;
+            const int slotp = ring ? (step * XS + i) % R : i;
+            const bool xok = x >= 0 && x < a.Xt;
+            const char* pbase = s.data + (long long)b * s.batch + (long long)(s.up ? (x >> 1) : x) * s.plane + choff;
+            char* lbase = lds + slotp * plane_bytes;
+#pragma unroll
+            for (int k = 0; k < kMaxDma; ++k) {
+                const int t = w + 4 * k;
+                if (t < ndma) {
+                    const int vox = s.up ? d_up[k] : d_vox[k];
+                    const char* g = (xok && vox >= 0) ? pbase + (long long)vox * (s.C * 2) + d_cs[k]
+                                                      : a.zeros + lane * 16;
+                    dma16(g, lbase + t * 1024);
+                }
+            }
+        }
+    };
+    // weight fragment index: (((ch*9 + dydz)*2 + ks)*3 + d)*NT + nt
+    auto wbase = [&](int ch) { return a.wpk + ((long long)ch * (9 * 2 * 3 * NT) + wn) * 1024 + lane * 16; };
+
+    half8 a0[3], a1[3];
+    half8 wres[RES > 0 ? 2 * RES : 1][3];
+    if constexpr (RES > 0) {
+#pragma unroll
+        for (int r = 0; r < 2 * RES; ++r)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) wres[r][d] = *reinterpret_cast<const half8*>(wbase(0) + ((r * 3 + d) * NT) * 1024);
+    }
+    if (tid < R * 4)
+        *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
+    issue_dma(0, 0);
+    if constexpr (RES == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(0) + (d * NT) * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int step = 0, ch = 0;
+    for (int ph = 0; ph < nphases; ++ph) {
+        const int x0 = xa + step * XS;
+        if (ch == 0) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int o = 0; o < XS; ++o)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[p][o][i][0] = acc[p][o][i][1] = *reinterpret_cast<const f32x4*>(biasp + 16 * i);
+        }
+        // ---------------- MFMA over the 27 taps of this chunk ---------------------------
+        {
+            const char* wch = wbase(ch);
+            int pslot[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) pslot[i] = (ring ? (step * XS + i) % R : i) * plane_bytes;
+
+            // one (dy,dz) row for cout half `ks` (= i): K = the chunk's 32 channels in ONE instruction
+            auto compute = [&](int dydz, int ks, const half8 (&afr)[3]) {
+                const int dz = dydz % 3 - 1;
+                const int tapoff = (dydz / 3 - 1) * pitch + dz;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    // the second voxel half sits 16 positions on: same swizzle term ((q + 16) >> 2 has the parity of
+                    // q >> 2), so its address is this one + 1 KiB
+                    const int q = q_row[p] + tapoff;
+                    const int base = (q * 4 + (g ^ (((q >> 2) & 1) << 1))) * 16;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        int addr = base + 1024 * j;
+                        if (dz < 0) addr = zlo(p, j) ? zero_addr : addr;
+                        if (dz > 0) addr = zhi(p, j) ? zero_addr : addr;
+#pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            const half8 bfr = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) {
+                                const int o = i - d;  // x_in = x_out + (d - 1)
+                                if (o >= 0 && o < XS)
+                                    acc[p][o][ks][j] =
+                                        __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[d], bfr, acc[p][o][ks][j], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            };
+            // hipcc schedules the ds_read / MFMA interleave of a (dydz, ks) body itself (pinning
+            // it with sched_barrier measured 8 % slower); the weight fragments of the next body
+            // are requested one body ahead.
+            // Fully unrolling the 9 tap rows lets hipcc hoist the next row's loads: +1.5 % for
+            // COUT 32 / 64, -8 % for COUT 128 (code size), measured A/B on one device.
+            constexpr int kTapUnroll = (NT <= 1) ? 9 : 1;
+#pragma unroll kTapUnroll
+            for (int dydz = 0; dydz < 9; ++dydz) {
+                const char* wrow = wch + (long long)(((a.ablate & 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
+                if constexpr (RES > 0) {
+                    if (dydz < RES) {
+                        compute(dydz, 0, wres[2 * dydz]);
+                        if (dydz == RES - 1) {  // first streamed row's ks = 0 fragments, one body ahead
+#pragma unroll
+                            for (int d = 0; d < 3; ++d)
+                                a0[d] = *reinterpret_cast<const half8*>(wrow + ((6 + d) * NT) * 1024);
+                        }
+                        compute(dydz, 1, wres[2 * dydz + 1]);
+                        continue;
+                    }
+                }
+                if (!(a.ablate & 32) || dydz == 0) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                        a1[d] = *reinterpret_cast<const half8*>(wrow + ((3 + d) * NT) * 1024);
+                }
+                compute(dydz, 0, a0);
+                if (dydz < 8 && !(a.ablate & 32)) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                        a0[d] = *reinterpret_cast<const half8*>(wrow + ((6 + d) * NT) * 1024);
+                }
+                compute(dydz, 1, a1);
+            }
+        }
+
+        // ---------------- hand the LDS planes to the next phase ---------------------------
+        const bool step_done = (ch == a.nchunks - 1);
+        int nstep = step, nch = ch + 1;
+        if (step_done) {
+            nstep = step + 1;
+            nch = 0;
+        }
+        const bool have_next = ph + 1 < nphases;
+        __syncthreads();  // every wave is done reading the planes about to be overwritten
+        if (have_next) {
+            issue_dma(nstep, nch);
+            if constexpr (RES == 0) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(nch) + (d * NT) * 1024);
+            }
+            // The DMA must have landed before this wave passes the closing barrier.  vmcnt retires in issue
+            // order, so after an epilogue that issues a FIXED number of stores (invalid lanes / planes store to
+            // a scratch line instead of branching) `vmcnt(that number)` means "everything older than the
+            // stores -- the DMA and the weight fragments -- has landed": the DMA latency hides behind the
+            // epilogue's transposes and the stores still drain under the next phase's MFMAs.
+            // Measured per layer (same device, A/B): -4 % time for COUT 32, +4 % for COUT 64 (two column tiles per
+            // wave: a longer epilogue), neutral for COUT 128 -> late wait for NT != 2 only.
+            if (!kLateWait || !step_done || a.ablate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+
+        // ---------------- epilogue (overlaps the DMA): raw fp16 store + GroupNorm partials ------
+        // The accumulator tile is [cout rows in registers][voxel columns on lanes]; the output
+        // is channels-last.  Each wave transposes its 32x32 tile through a private 2 KiB LDS
+        // pad (16-B chunks XOR-swizzled) so that every lane stores 16 contiguous bytes and one
+        // store instruction writes 1 KiB of whole 64-B voxel lines (4 lanes per line).
+        if (step_done) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int tile_vox0 = out_vox0[p];  // in-plane index of the tile's first voxel
+#pragma unroll
+                for (int o = 0; o < XS; ++o) {
+                    const int x = x0 + o;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const f32x4 r = acc[p][o][i][j];
+                            half4 hv = {(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
+                            // voxel 16 j + c16, channels 16 i + 4 g .. +3 of the tile: 16-byte chunk 2 i + (g >> 1), half g & 1
+                            const int vx = 16 * j + c16;
+                            *reinterpret_cast<half4*>(pad + vx * kPadStride + (((2 * i + (g >> 1)) ^ ((vx >> 1) & 3)) * 16) +
+                                                      8 * (g & 1)) = hv;
+                            if (vvalid(p, j) && x < xb) {
+                                gsum[i] += (r[0] + r[1]) + (r[2] + r[3]);
+                                gsq[i] += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+                            }
+                        }
+                    if (!(a.ablate & 4)) {
+                        char* op = outb + (long long)x * out_plane + (long long)tile_vox0 * (COUT * 2) + wn * 64;
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const int vv = rv + 16 * hh;
+                            const half8 line = *reinterpret_cast<const half8*>(
+                                pad + vv * kPadStride + ((rc ^ ((vv >> 1) & 3)) * 16));
+                            const bool sok = x < xb && tile_vox0 + vv < tile_nvox[p];
+                            if constexpr (kLateWait) {
+                                // always issued (the counted wait below relies on it); masked lanes hit the scratch line
+                                char* dst = sok ? op + (long long)vv * (COUT * 2) + rc * 16 : trash;
+                                *reinterpret_cast<half8*>(dst) = line;
+                            } else if (sok) {
+                                *reinterpret_cast<half8*>(op + (long long)vv * (COUT * 2) + rc * 16) = line;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (have_next) {
+            if (kLateWait && step_done && !a.ablate) {
+                constexpr int kStores = P * XS * 2;  // global stores the epilogue just issued
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        step = nstep;
+        ch = nch;
+    }
+
+    // ---- block-level reduction of the GroupNorm partials ------------------------------------
+    if (a.partial) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds);  // [4 waves][8 quads of the wave's cout tile][2]
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float s = gsum[i], ss = gsq[i];
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) {   // the 16 lanes that share g
+                s += __shfl_xor(s, m);
+                ss += __shfl_xor(ss, m);
+            }
+            if (c16 == 0) {
+                red[(w * 8 + 4 * i + g) * 2 + 0] = s;
+                red[(w * 8 + 4 * i + g) * 2 + 1] = ss;
+            }
+        }
+        __syncthreads();
+        if (tid < NT * 16) {
+            // channel quad Q = cout/4 = 8*nt + k ; waves with wn == nt: w = wm*NT + nt
+            const int nt = tid / 16, k2 = tid % 16;
+            float t = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 4 / NT; ++g) t += red[(g * NT + nt) * 16 + k2];
+            a.partial[((long long)b * nblk + block_in_batch) * (NT * 16) + tid] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Gather GEMM for the layers with no spatial reuse of activations: 2x2x2 stride-2
 // down-sampling convs (8 taps, each input voxel feeds one output voxel) and 1x1x1
 // channel reducers.  B fragments come straight from global memory (16 B per lane),
@@ -641,6 +1036,18 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
     return 0;
 }
 
+template <int XS, int RES = 0>
+int launch_conv3_m16(const Conv3Args& a, const Plan& p, hipStream_t stream) {
+    auto kern = conv3_m16_kernel<32, XS, RES>;
+    if (p.lds > 48 * 1024)
+        SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)p.lds));
+    unsigned grid = (unsigned)(p.npatch * p.nxc * a.B);
+    kern<<<grid, 256, p.lds, stream>>>(a);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
 template <int COUT, int XS, int RES = 0>
 int launch_conv3(const Conv3Args& a, const Plan& p, hipStream_t stream) {
     auto kern = conv3_kernel<COUT, XS, RES>;
@@ -669,9 +1076,9 @@ int sk_conv3d_num_blocks(int B, int ox, int oy, int oz, int cout, int ksize) {
 }
 
 int64_t sk_conv3d_pack_weight_host(const float* w, int cout, int cin, int ksize, void* dst) {
-    // torch layout (cout, cin, kx, ky, kz) fp32 -> A fragments of v_mfma_f32_32x32x16_f16:
-    // fragment (1 KiB) = 64 lanes x 8 halves, lane l holds W[cout = 32nt + (l&31)][cin = c0 + 8(l>>5) + j]
-    // ksize 3: order [chunk32][dy*3+dz][ks(2)][dx][nt];  ksize 1/2: order [tap][ks(cin/16)][nt]
+    // torch layout (cout, cin, kx, ky, kz) fp32 -> MFMA A fragments (1 KiB = 64 lanes x 8 halves).
+    // ksize 1/2 (v_mfma_f32_32x32x16_f16): lane l holds W[cout = 32nt + (l&31)][cin = c0 + 8(l>>5) + j],
+    // order [tap][ks(cin/16)][nt]; ksize 3: see emit16 below
     if (!(ksize == 1 || ksize == 2 || ksize == 3) || cout % 32 || cin % (ksize == 3 ? 32 : 16)) {
         sk::set_error("sk_conv3d_pack_weight_host: unsupported shape cout=%d cin=%d k=%d", cout, cin, ksize);
         return SK_ERR_ARG;
@@ -690,7 +1097,20 @@ int64_t sk_conv3d_pack_weight_host(const float* w, int cout, int cin, int ksize,
                 out[f * 512 + l * 8 + j] = __float2half(W(32 * nt + (l & 31), c0 + 8 * (l >> 5) + j, kx, ky, kz));
         ++f;
     };
-    if (ksize == 3) {
+    // ksize 3 with cout 32 runs on v_mfma_f32_16x16x32_f16: fragment = [16 cout][32 channels of the chunk], lane l
+    // holds W[cout = 16i + (l&15)][cin = 32ch + 8(l>>4) + j]; order [chunk32][dy*3+dz][i(2)][dx]
+    auto emit16 = [&](int nt, int i, int c0, int kx, int ky, int kz) {
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j)
+                out[f * 512 + l * 8 + j] = __float2half(W(32 * nt + 16 * i + (l & 15), c0 + 8 * (l >> 4) + j, kx, ky, kz));
+        ++f;
+    };
+    if (ksize == 3 && cout == 32) {   // the COUT-32 conv kernel is the 16x16x32 one
+        for (int ch = 0; ch < cin / 32; ++ch)
+            for (int dydz = 0; dydz < 9; ++dydz)
+                for (int i = 0; i < 2; ++i)
+                    for (int dx = 0; dx < 3; ++dx) emit16(0, i, ch * 32, dx, dydz / 3, dydz % 3);
+    } else if (ksize == 3) {          // 32x32x16: order [chunk32][dy*3+dz][ks(2)][dx][nt]
         for (int ch = 0; ch < cin / 32; ++ch)
             for (int dydz = 0; dydz < 9; ++dydz)
                 for (int ks = 0; ks < 2; ++ks)
@@ -763,10 +1183,12 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
             const char* e = getenv("SK_CONV_ABLATE");
             a.ablate = e ? atoi(e) : 0;
         }
-        if (p.xs == 3) return cout == 32 ? launch_conv3<32, 3>(a, p, stream) : launch_conv3<64, 3>(a, p, stream);
-        if (cout == 32 && a.nchunks == 1 && !a.ablate) return launch_conv3<32, 4, 3>(a, p, stream);
-        if (cout == 32) return launch_conv3<32, 4>(a, p, stream);
-        if (cout == 64) return launch_conv3<64, 4>(a, p, stream);
+        if (cout == 32) {   // 16x16x32 kernel
+            if (p.xs == 3) return launch_conv3_m16<3>(a, p, stream);
+            if (a.nchunks == 1 && !a.ablate) return launch_conv3_m16<4, 2>(a, p, stream);
+            return launch_conv3_m16<4>(a, p, stream);
+        }
+        if (cout == 64) return p.xs == 3 ? launch_conv3<64, 3>(a, p, stream) : launch_conv3<64, 4>(a, p, stream);
         return launch_conv3<128, 2>(a, p, stream);
     }
     SK_CHECK_ARG(ksize == 1 || ksize == 2, "sk_conv3d: ksize must be 1, 2 or 3");

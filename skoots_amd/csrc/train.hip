@@ -1273,7 +1273,22 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(PackArgs a) {
     long long f = i >> 9;  // fragment index
     const int NT = a.eff_cout / 32, k = a.ksize, k3 = k * k * k;
     int nt, c0, kx, ky, kz;
-    if (k == 3) {  // [chunk32][dy*3+dz][ks][dx][nt]
+    int co, ci;
+    if (k == 3 && a.eff_cout == 32) {  // 16x16x32 fragments (the COUT-32 conv kernel): [chunk32][dy*3+dz][i(2)][dx],
+        nt = 0;                        // lane: cout 16i + (l&15), cin 32ch + 8(l>>4) + j
+        const int dx = (int)(f % 3);
+        f /= 3;
+        const int ih = (int)(f % 2);
+        f /= 2;
+        const int dydz = (int)(f % 9);
+        const int ch = (int)(f / 9);
+        c0 = ch * 32;
+        kx = dx;
+        ky = dydz / 3;
+        kz = dydz % 3;
+        co = 16 * ih + (l & 15);
+        ci = c0 + 8 * (l >> 4) + j;
+    } else if (k == 3) {               // 32x32x16 fragments: [chunk32][dy*3+dz][ks][dx][nt]
         nt = (int)(f % NT);
         f /= NT;
         const int dx = (int)(f % 3);
@@ -1286,6 +1301,8 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(PackArgs a) {
         kx = dx;
         ky = dydz / 3;
         kz = dydz % 3;
+        co = 32 * nt + (l & 31);
+        ci = c0 + 8 * (l >> 5) + j;
     } else {       // [tap][ks][nt]
         nt = (int)(f % NT);
         f /= NT;
@@ -1296,8 +1313,9 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(PackArgs a) {
         kx = tap / (k * k);
         ky = (tap / k) % k;
         kz = tap % k;
+        co = 32 * nt + (l & 31);
+        ci = c0 + 8 * (l >> 5) + j;
     }
-    const int co = 32 * nt + (l & 31), ci = c0 + 8 * (l >> 5) + j;
     int tap = (kx * k + ky) * k + kz;
     long long src;
     if (a.transposed) {
