@@ -132,7 +132,7 @@ def conv_hbm_traffic():
         return None
     tot, n = 0.0, 0
     for k in prof["kernels"]:
-        if "conv3_kernel" in k["kernel"]:
+        if "conv3_kernel" in k["kernel"] or "conv3_m16_kernel" in k["kernel"]:
             tot += (k["fetch_MB_per_launch_x2_gfx950_correction"] + k["write_MB_per_launch"]) * k["launches"]
             n += k["launches"]
     return round(tot / n * 1024 * 1024) if n else None
