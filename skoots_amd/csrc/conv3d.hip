@@ -456,7 +456,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
 // tile becomes 2 x 2 results of 16 x 16; K = 32 = the whole channel chunk per instruction; the 16-byte chunk
 // swizzle of the staged planes and the fragment packing differ, see below).  A/B on one device: -5 % time on each of
 // the three COUT-32 layers (55 % of the conv time).  With this shape the COUT 64 / 128 variants spill, or lose
-// reuse when XS is cut to fit (+6 % / +15 % time): they stay on conv3_kernel (32x32x16) above.
+// reuse when XS is cut to fit (COUT 64: +22 % with a 76-byte spill at XS 4, +6 % at XS 3; COUT 128: +15 %): they stay
+// on conv3_kernel (32x32x16) above.
 //
 // RES: rows (dy,dz) of the 9 whose weight fragments stay in registers for the whole workgroup -- only for
 // single-chunk layers (the same 54 fragments every step) of COUT 32, where the kernel leaves ~80 of its 256
@@ -559,7 +560,12 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
 
     // ---- DMA bookkeeping: this lane's slots of a plane --------------------------------
     const int ndma = a.nposp / 16;  // wave-instructions per plane
-    int d_vox[kMaxDma], d_up[kMaxDma], d_cs[kMaxDma];
+    int d_vox[kMaxDma], d_up[kMaxDma];
+    // source 16-byte chunk (swizzle on the SOURCE side): slot s of position q holds chunk s ^ 2*((q>>2)&1), which makes
+    // every ds_read_b128 lane group of the B reads (16 positions x the wave's 4 K groups) conflict-free for any
+    // alignment of the 16 consecutive positions (searched exhaustively).  q >> 2 = 4 t + (lane >> 4): the same for
+    // every DMA instruction t of this lane.
+    const int d_cs = ((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 16;
 #pragma unroll
     for (int k = 0; k < kMaxDma; ++k) {
         int t = w + 4 * k;
@@ -570,10 +576,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
         bool ok = (t < ndma) && y >= 0 && y < a.Yt && z >= 0 && z < a.Zt;
         d_vox[k] = ok ? y * a.Zt + z : -1;
         d_up[k] = ok ? (y >> 1) * a.src[1].Zs + (z >> 1) : -1;
-        // source 16-byte chunk (swizzle on the SOURCE side): slot s of position q holds chunk s ^ 2*((q>>2)&1), which
-        // makes every ds_read_b128 lane group of the B reads (16 positions x the wave's 4 K groups) conflict-free
-        // for any alignment of the 16 consecutive positions (searched exhaustively)
-        d_cs[k] = (c ^ (((q >> 2) & 1) << 1)) * 16;
+        (void)c;
     }
 
     // ---- accumulators + GroupNorm partials ----------------------------------------------
@@ -621,7 +624,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                 const int t = w + 4 * k;
                 if (t < ndma) {
                     const int vox = s.up ? d_up[k] : d_vox[k];
-                    const char* g = (xok && vox >= 0) ? pbase + (long long)vox * (s.C * 2) + d_cs[k]
+                    const char* g = (xok && vox >= 0) ? pbase + (long long)vox * (s.C * 2) + d_cs
                                                       : a.zeros + lane * 16;
                     dma16(g, lbase + t * 1024);
                 }
@@ -1109,7 +1112,8 @@ int64_t sk_conv3d_pack_weight_host(const float* w, int cout, int cin, int ksize,
         for (int ch = 0; ch < cin / 32; ++ch)
             for (int dydz = 0; dydz < 9; ++dydz)
                 for (int i = 0; i < 2; ++i)
-                    for (int dx = 0; dx < 3; ++dx) emit16(0, i, ch * 32, dx, dydz / 3, dydz % 3);
+                    for (int dx = 0; dx < 3; ++dx)
+                        for (int nt = 0; nt < NT; ++nt) emit16(nt, i, ch * 32, dx, dydz / 3, dydz % 3);
     } else if (ksize == 3) {          // 32x32x16: order [chunk32][dy*3+dz][ks(2)][dx][nt]
         for (int ch = 0; ch < cin / 32; ++ch)
             for (int dydz = 0; dydz < 9; ++dydz)
