@@ -9,9 +9,10 @@
 //   * activations are channels-last fp16 (B, X, Y, Z, C), already normalised +
 //     activated by the fused GroupNorm+SiLU pass; weights are pre-packed on the host
 //     in MFMA A-fragment order (sk_conv3d_pack_weight_host);
-//   * D[cout][voxel] += W[cout][cin,tap] * act[cin,tap][voxel] with
-//     v_mfma_f32_32x32x16_f16: rows = 32 output channels, columns = 32 voxels of a
-//     (y,z) patch, K = 16 input channels of one tap;
+//   * D[cout][voxel] += W[cout][cin,tap] * act[cin,tap][voxel]: rows = 32 output
+//     channels, columns = 32 voxels of a (y,z) patch; conv3_kernel (COUT 64, 128) on
+//     v_mfma_f32_32x32x16_f16 (K = 16 input channels of one tap), conv3_m16_kernel (COUT 32) on
+//     v_mfma_f32_16x16x32_f16 (K = the tap's whole 32-channel chunk, 2 x 2 results per tile);
 //   * a workgroup (4 waves, one 32-voxel column set each) owns a 128-voxel (y,z)
 //     patch and MARCHES along x, XS output planes per step.  The input planes of a
 //     step (XS+2, with y/z halo) sit in an LDS ring filled by LDS-DMA
@@ -24,7 +25,8 @@
 //     16-lane groups of ds_read_b128 hit 16 distinct bank slots;
 //   * input channels are consumed in chunks of 32 (the channel concat of skip +
 //     upsampled tensors is two chunks from two sources, never materialised);
-//   * the epilogue adds the bias, stores fp16 raw outputs (8 B per lane) and
+//   * the epilogue adds the bias, stores fp16 raw outputs (transposed through a per-wave LDS
+//     pad into whole 64-byte voxel lines, 16 B per lane) and
 //     accumulates per-channel-quad (sum, sumsq) of the fp32 accumulators for the
 //     GroupNorm that follows; per-block partials are reduced in a fixed order by
 //     sk_groupnorm_finalize (deterministic, no float atomics).
