@@ -366,6 +366,19 @@ int sk_train_adamw(float* param, const float* grad, float* exp_avg, float* exp_a
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * Training-target baking (skoots/lib/skeleton.py:448-528 with its Triton kernel :51-251, and
+ * average_baked_skeletons :18-48).  masks (X, Y, Z) int32 instance ids; the skeletons as a CSR table: ids (K,
+ * ascending), offsets (K+1), points (offsets[K], 3) fp32 voxel coordinates.  baked (3, X, Y, Z) fp32 = the
+ * nearest point of the voxel's own skeleton under anisotropy_host (3) (first minimal point on ties, exact
+ * distances), 0 for background / unknown ids; distance (X, Y, Z) fp32 or NULL.
+ * sk_average_baked_skeletons: out[c, v] = sum of the zero-padded 3x3x3 neighbourhood / number of entries > 0. */
+int sk_bake_skeleton(const int32_t* masks, const int32_t* ids, const int32_t* offsets,
+                     const float* points, int K, int X, int Y, int Z, const float* anisotropy_host,
+                     float* baked, float* distance, void* stream);
+int sk_average_baked_skeletons(const float* baked, float* out, int C, int X, int Y, int Z,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

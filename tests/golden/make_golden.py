@@ -21,6 +21,7 @@ Fixtures are data only (inputs + outputs of reference calls), stored as .npz.
   G6 postmodel.npz       eval.py:145-284 composed from reference functions on an injected field
   G7 kat.npz             the two __main__ known answers
   G8 loss.npz            config-5 loss terms and their input gradient (tversky + baked_embed_to_prob)
+  G9 bake.npz            bake_skeleton (CPU path) + average_baked_skeletons              skeleton.py:18-48,370-528
 """
 import os
 import sys
@@ -347,6 +348,34 @@ def g8():
          losses=np.array([le.item(), lp.item(), ls.item(), loss.item()]), grad=out.grad.numpy())
 
 
+# ----------------------------------------------------------------------------- G9 (next row N3: target baking)
+def g9():
+    """Training-target baking: the reference's CPU path of bake_skeleton (lib/skeleton.py:370-445,
+    448-528) and average_baked_skeletons (lib/skeleton.py:18-48) on a small instance mask."""
+    from skoots.lib.skeleton import average_baked_skeletons, bake_skeleton
+    gen = torch.Generator().manual_seed(99)
+    X, Y, Z = 26, 22, 12
+    masks = torch.zeros((X, Y, Z), dtype=torch.int64)
+    masks[2:12, 3:14, 1:9] = 1
+    masks[13:24, 2:11, 2:11] = 4
+    masks[14:25, 12:21, 0:6] = 7
+    masks[3:6, 16:20, 9:12] = 9          # instance with a single skeleton point
+    skeletons = {}
+    for i in (1, 4, 7, 9):
+        nz = masks.eq(i).nonzero()
+        k = 1 if i == 9 else 6
+        pick = torch.randperm(nz.shape[0], generator=gen)[:k]
+        skeletons[i] = nz[pick].float()
+    anis = (1.0, 1.0, 3.0)
+    raw = bake_skeleton(masks.clone(), skeletons, anis, average=False, device="cpu")
+    avg = bake_skeleton(masks.clone(), skeletons, anis, average=True, device="cpu")
+    ids = np.array(sorted(skeletons), dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum([skeletons[int(i)].shape[0] for i in ids])]).astype(np.int32)
+    pts = np.concatenate([skeletons[int(i)].numpy() for i in ids]).astype(np.float32)
+    save("bake.npz", masks=masks.numpy().astype(np.int32), ids=ids, offsets=offs, points=pts,
+         anisotropy=np.array(anis, dtype=np.float32), baked=raw.numpy(), baked_avg=avg.numpy())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    g1(); g2_g3(); g4(); g5(); g6(); g7(); g8()
+    g1(); g2_g3(); g4(); g5(); g6(); g7(); g8(); g9()
