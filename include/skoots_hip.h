@@ -379,6 +379,16 @@ int sk_bake_skeleton(const int32_t* masks, const int32_t* ids, const int32_t* of
 int sk_average_baked_skeletons(const float* baked, float* out, int C, int X, int Y, int Z,
                                void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * Validation metrics (skoots/validate/lib.py:190-229 mask_iou): iou (N, M) fp32 of the N
+ * ground-truth and M predicted instances, intersection / union of voxel counts, 0 for pairs that do not touch.
+ * gt, pred (n) int32; lut_gt (max_gt + 1) / lut_pred (max_pred + 1) int32 map an id to its 1-based row / column
+ * (0 = ignore: background or unlisted).  workspace: sk_mask_iou_workspace_bytes(N, M). */
+size_t sk_mask_iou_workspace_bytes(int N, int M);
+int sk_mask_iou(const int32_t* gt, const int32_t* pred, int64_t n, const int32_t* lut_gt, int max_gt, int N,
+                const int32_t* lut_pred, int max_pred, int M, float* iou, void* workspace,
+                size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

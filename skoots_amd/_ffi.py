@@ -102,6 +102,8 @@ _SIGS = {
     "sk_train_sumpool2": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "sk_bake_skeleton": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, fp, vp, vp, vp]),
     "sk_average_baked_skeletons": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "sk_mask_iou_workspace_bytes": (sz, [i32, i32]),
+    "sk_mask_iou": (i32, [vp, vp, i64, vp, i32, i32, vp, i32, i32, vp, vp, sz, vp]),
     "sk_train_adamw": (i32, [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]),
 }
 

@@ -22,6 +22,7 @@ Fixtures are data only (inputs + outputs of reference calls), stored as .npz.
   G7 kat.npz             the two __main__ known answers
   G8 loss.npz            config-5 loss terms and their input gradient (tversky + baked_embed_to_prob)
   G9 bake.npz            bake_skeleton (CPU path) + average_baked_skeletons              skeleton.py:18-48,370-528
+  G10 validate.npz       mask_iou / accuracies_from_iou / f1_score / get_segmentation_errors   validate/lib.py:170-438
 """
 import os
 import sys
@@ -376,6 +377,38 @@ def g9():
          anisotropy=np.array(anis, dtype=np.float32), baked=raw.numpy(), baked_avg=avg.numpy())
 
 
+# ----------------------------------------------------------------------------- G10 (next row N4: validation metrics)
+def g10():
+    """Instance-level validation metrics: mask_iou, accuracies_from_iou, f1_score and
+    get_segmentation_errors of skoots/validate/lib.py:170-232,358-438 on two small label volumes."""
+    if "skimage.io" not in sys.modules:
+        sys.modules["skimage.io"] = types.ModuleType("skimage.io")
+    from skoots.validate.lib import accuracies_from_iou, f1_score, get_segmentation_errors, mask_iou
+    gen = torch.Generator().manual_seed(123)
+    X, Y, Z = 30, 28, 10
+    gt = torch.zeros((1, X, Y, Z), dtype=torch.int32)
+    pred = torch.zeros((1, X, Y, Z), dtype=torch.int32)
+    gt[0, 2:10, 2:12, 1:8] = 3
+    gt[0, 12:22, 3:12, 0:9] = 5
+    gt[0, 3:14, 15:26, 2:9] = 8
+    gt[0, 18:28, 16:27, 1:6] = 11          # missed by the prediction
+    pred[0, 3:11, 2:12, 1:8] = 2           # good match of 3
+    pred[0, 12:17, 3:12, 0:9] = 4          # gt 5 split in two
+    pred[0, 17:22, 3:12, 0:9] = 6
+    pred[0, 3:14, 15:26, 2:5] = 9          # partial match of 8
+    pred[0, 24:29, 1:6, 6:10] = 12         # false positive
+    pred[0, 2:6, 13:17, 0:3] = 13          # straddles gt 8 and background
+    noise = torch.rand((1, X, Y, Z), generator=gen) > 0.97
+    pred[noise] = 0
+    iou = mask_iou(gt, pred)
+    acc = {str(t): accuracies_from_iou(iou, t) for t in (0.1, 0.5, 0.75)}
+    over, under = get_segmentation_errors(gt, pred)
+    tp, fp, fn = acc["0.5"]
+    save("validate.npz", gt=gt.numpy(), pred=pred.numpy(), iou=iou.numpy(),
+         acc=np.array([acc[k] for k in ("0.1", "0.5", "0.75")], dtype=np.float64),
+         f1=np.array([f1_score(tp, fp, fn)]), seg_errors=np.array([over, under]))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    g1(); g2_g3(); g4(); g5(); g6(); g7(); g8(); g9()
+    g1(); g2_g3(); g4(); g5(); g6(); g7(); g8(); g9(); g10()
