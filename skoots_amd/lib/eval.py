@@ -256,7 +256,8 @@ def eval(image_path: str, checkpoint_path: str, used_cached_data: bool = False) 
     """Evaluates SKOOTS on an arbitrary image (drop-in for ``skoots.lib.eval.eval``).
 
     Writes next to the image, with the reference's names: ``<base>_skoots_skeleton`` (1,X,Y,Z) u1
-    and ``<base>_skoots_vectors`` (3,X,Y,Z) f2 (``.npy``: zarr is not in this image),
+    and ``<base>_skoots_vectors`` (3,X,Y,Z) f2 as ``.zarr`` directory stores (zarr v2 layout, uncompressed,
+    written by ``zarr_store``: the zarr package itself is not in this image),
     ``<base>_skoots_benchmark.txt`` and ``<base>_instance_mask.tif`` (Z,X,Y), and prints DONE.
 
     ``checkpoint_path``: ``torch.save``d dict with ``cfg`` (dict/attribute config holding
@@ -289,15 +290,16 @@ def eval(image_path: str, checkpoint_path: str, used_cached_data: bool = False) 
 
     logging.info("Constructing SKOOTS model")
     model = unet.cfg_to_model(cfg, device, checkpoint["model_state_dict"])
-    skel_path, vec_path = base + "_skoots_skeleton.npy", base + "_skoots_vectors.npy"
+    from . import zarr_store
+    skel_path, vec_path = base + "_skoots_skeleton.zarr", base + "_skoots_vectors.zarr"  # eval.py:102-103
 
     benchmark_start = time.time()
     dev_img = img16.to(device)
     if used_cached_data and os.path.exists(skel_path) and os.path.exists(vec_path):  # eval.py:105 (os.exists bug fixed)
         from ..parallel import ShardedVolume  # noqa: F401
         state = VolumeState((x, y, z), device)
-        state.skeleton.copy_(torch.from_numpy(np.load(skel_path)[0]).to(device))
-        vp = torch.from_numpy(np.load(vec_path)).to(device)
+        state.skeleton.copy_(torch.from_numpy(zarr_store.load(skel_path)[0]).to(device))
+        vp = torch.from_numpy(zarr_store.load(vec_path)).to(device)
         _ffi.check(_ffi.lib.sk_vec_interleave(_ffi.ptr(vp), _ffi.ptr(state.vec4), x * y * z,
                                               _ffi.stream_ptr(device)))
         state.label()
@@ -311,8 +313,8 @@ def eval(image_path: str, checkpoint_path: str, used_cached_data: bool = False) 
     torch.cuda.synchronize(device)
     dt = time.time() - benchmark_start
 
-    np.save(skel_path, skeleton.cpu().numpy()[np.newaxis])
-    np.save(vec_path, vectors.cpu().numpy())
+    zarr_store.save(skel_path, skeleton.cpu().numpy()[np.newaxis])
+    zarr_store.save(vec_path, vectors.cpu().numpy())
     logging.info("writing benchmark information")
     with open(base + "_skoots_benchmark.txt", "w") as f:  # eval.py:286-295
         f.write("SKOOTS Segmentation Benchmark:\n")

@@ -31,8 +31,9 @@ def test_eval_writes_reference_outputs(tmp_path):
 
     sk_eval(ipath, cpath)
     base = str(tmp_path / "vol")
-    skel = np.load(base + "_skoots_skeleton.npy")
-    vec = np.load(base + "_skoots_vectors.npy")
+    from skoots_amd.lib import zarr_store
+    skel = zarr_store.load(base + "_skoots_skeleton.zarr")
+    vec = zarr_store.load(base + "_skoots_vectors.zarr")
     assert skel.shape == (1, X, Y, Z) and skel.dtype == np.uint8
     assert vec.shape == (3, X, Y, Z) and vec.dtype == np.float16
     assert "Time:" in open(base + "_skoots_benchmark.txt").read()
