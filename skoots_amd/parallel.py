@@ -5,9 +5,10 @@ rehearsals in tests/).
 The reference is single device (skoots/lib/eval.py:57).  The path shards naturally:
 
   stage 1  tiles are independent.  Rank r owns the planes [z_lo, z_hi) of the volume; every
-           tile of the global 300x300x20 grid (unchanged) runs on exactly one rank, the owner
-           of the first plane it writes last; the few planes a slab-straddling tile writes
-           for the next rank are sent point to point (input halo comes with the image).
+           tile of the global 300x300x20 grid (unchanged) runs on exactly one rank: the tiles,
+           z-major, are cut into equal runs, so a z position that straddles two slabs is split
+           in (x, y) between them; what a rank's tiles write into a neighbour's slab is sent
+           point to point, packed (input halo comes with the image).
   stage 2  each rank labels its slab; the label planes either side of every slab
            boundary are exchanged, the (few) seam equivalences are all-gathered and
            every rank applies the same union to its slab.  The slabs are then
@@ -48,41 +49,57 @@ def window_of(slab: Tuple[int, int], Z: int, world: int, halo: int = HALO) -> Tu
     return (max(0, slab[0] - halo), min(Z, slab[1] + halo))
 
 
-def tiles_for_slab(shape: Sequence[int], tile: Sequence[int], overlap: Sequence[int],
-                   slab: Tuple[int, int]) -> Tuple[List[Tuple[int, int, int]], List[int]]:
-    """Distinct tile origins (reference order) this rank evaluates, plus the effective tile size
-    (cropper.py:97-144 grid, eval.py:160-176 scatter).  Every tile runs on exactly ONE rank: the
-    owner of the first plane the tile writes last.  The (<= 9) planes such a tile writes beyond
-    the slab are handed to the next rank by :func:`exchange_straddle`."""
+def _owned_range(own: np.ndarray, origin: int) -> Tuple[int, int]:
+    idx = np.nonzero(own == origin)[0]
+    return (int(idx[0]), int(idx[-1]) + 1) if idx.size else (0, 0)
+
+
+def tile_plan(shape: Sequence[int], tile: Sequence[int], overlap: Sequence[int], world: int,
+              halo: int = HALO) -> Tuple[List[List[Tuple[int, int, int]]], List[int]]:
+    """Which rank evaluates which tile of the reference's global grid (cropper.py:97-144), plus the
+    effective tile size.  Every distinct tile runs on exactly ONE rank.  With one rank: all of them in
+    the reference's order.  Otherwise the tiles, sorted z-major, are cut into ``world`` equal contiguous
+    runs -- a z position of the grid that straddles two slabs is split between the two ranks in (x, y),
+    so every rank evaluates T/world tiles (+-1) whatever Z/world is (whole z positions per rank would
+    leave 7 : 6 imbalances at 2048x2048x512 on 8 ranks).  What a rank's tiles write into another
+    rank's slab travels point to point afterwards (:func:`exchange_blocks`).  Raises ``ValueError`` if a
+    run does not fit the rank's window (slab +- halo): slabs too thin for the halo."""
     eff = list(tile)
     origins = cropper.distinct_origins(shape, eff, overlap)
-    own_z = cropper.owner_table(shape[2], eff[2], overlap[2])
-    first_plane = {}
-    for z, oz in enumerate(own_z):
-        if oz >= 0 and int(oz) not in first_plane:
-            first_plane[int(oz)] = z
-    mine = {oz for oz, z in first_plane.items() if slab[0] <= z < slab[1]}
-    return [o for o in origins if o[2] in mine], eff
+    if world == 1:
+        return [origins], eff
+    slabs = slab_bounds(shape[2], world)
+    windows = [window_of(s, shape[2], world, halo) for s in slabs]
+    order = sorted(origins, key=lambda o: (o[2], o[0], o[1]))
+    T = len(order)
+    plan = [order[T * r // world:T * (r + 1) // world] for r in range(world)]
+    for r, (p_, w) in enumerate(zip(plan, windows)):
+        for o in p_:
+            if not (w[0] <= o[2] and o[2] + eff[2] <= w[1]):
+                raise ValueError(f"tile at z={o[2]} does not fit rank {r}'s window {w} (slab +- {halo} planes): "
+                                 f"slabs of {shape[2]}/{world} planes are too thin for this halo")
+    return plan, eff
 
 
-def straddle_extent(shape: Sequence[int], tile: Sequence[int], overlap: Sequence[int],
-                    slabs: List[Tuple[int, int]]) -> List[int]:
-    """e[r]: number of planes [slab_r.hi, slab_r.hi + e[r]) that rank r's tiles write for rank r+1."""
-    eff = list(tile)
-    cropper.clamp_crop_(eff, shape)
-    own_z = cropper.owner_table(shape[2], eff[2], overlap[2])
-    first_plane = {}
-    for z, oz in enumerate(own_z):
-        if oz >= 0 and int(oz) not in first_plane:
-            first_plane[int(oz)] = z
+def block_plan(shape: Sequence[int], eff: Sequence[int], overlap: Sequence[int],
+               plan: List[List[Tuple[int, int, int]]]) -> List[Tuple[int, int, Tuple[int, ...]]]:
+    """(src, dst, (x0, x1, y0, y1, z0, z1)) for every box of voxels that a tile evaluated on rank
+    ``src`` writes (as their last writer, eval.py:160-176) into the slab of another rank ``dst``;
+    global coordinates, deterministic order (the same list on every rank)."""
+    world = len(plan)
+    slabs = slab_bounds(shape[2], world)
+    own = [cropper.owner_table(dm, c, o) for dm, c, o in zip(shape, eff, overlap)]
+    rng = [{int(o): _owned_range(t, int(o)) for o in np.unique(t) if o >= 0} for t in own]
     out = []
-    for (lo, hi) in slabs:
-        e = 0
-        for oz, z0 in first_plane.items():
-            if lo <= z0 < hi:
-                last = int(np.nonzero(own_z == oz)[0][-1])
-                e = max(e, last + 1 - hi)
-        out.append(max(e, 0))
+    for src, tiles in enumerate(plan):
+        for (ox, oy, oz) in tiles:
+            (x0, x1), (y0, y1), (z0, z1) = rng[0].get(ox, (0, 0)), rng[1].get(oy, (0, 0)), rng[2].get(oz, (0, 0))
+            if x0 >= x1 or y0 >= y1:
+                continue
+            for dst, (lo, hi) in enumerate(slabs):
+                a, b = max(z0, lo), min(z1, hi)
+                if dst != src and a < b:
+                    out.append((src, dst, (x0, x1, y0, y1, a, b)))
     return out
 
 
@@ -162,24 +179,37 @@ def exchange_halo(arr: Tensor, slabs, windows, rank: int, comm: Comm) -> None:
         arr[:, :, lo - w0:hi - w0] = t
 
 
-def exchange_straddle(arrays: Sequence[Tensor], extents: List[int], slabs, windows, rank: int, comm: "Comm") -> None:
-    """Planes a rank's last tile wrote beyond its slab go to the next rank (which did not evaluate
-    that tile).  ``arrays``: window-shaped (X, Y, Zl, ...) tensors, updated in place."""
-    world = len(slabs)
+def exchange_blocks(arrays: Sequence[Tensor], blocks, windows, rank: int, comm: "Comm") -> None:
+    """Deliver what this rank's tiles wrote into other ranks' slabs (:func:`block_plan`) and take in
+    what theirs wrote into this one.  ``arrays``: window-shaped (X, Y, Zl, ...) tensors, updated in
+    place; one packed message per (array, peer)."""
     w0 = windows[rank][0]
-    sends, like, dst = [], [], []
+
+    def view(arr, box):
+        x0, x1, y0, y1, z0, z1 = box
+        return arr[x0:x1, y0:y1, z0 - w0:z1 - w0]
+
+    out_by, in_by = {}, {}
+    for src, dst, box in blocks:
+        if src == rank:
+            out_by.setdefault(dst, []).append(box)
+        elif dst == rank:
+            in_by.setdefault(src, []).append(box)
+    sends, like, dst_views = [], [], []
     for arr in arrays:
-        if rank + 1 < world and extents[rank] > 0:
-            hi = slabs[rank][1]
-            sends.append((rank + 1, arr[:, :, hi - w0:hi + extents[rank] - w0]))
-        if rank > 0 and extents[rank - 1] > 0:
-            lo = slabs[rank][0]
-            view = arr[:, :, lo - w0:lo + extents[rank - 1] - w0]
-            like.append((rank - 1, torch.empty(tuple(view.shape), dtype=arr.dtype, device=arr.device)))
-            dst.append(view)
+        tail = int(np.prod(arr.shape[3:])) if arr.ndim > 3 else 1
+        for peer in sorted(out_by):
+            sends.append((peer, torch.cat([view(arr, b).reshape(-1) for b in out_by[peer]])))
+        for peer in sorted(in_by):
+            n = sum((b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]) for b in in_by[peer]) * tail
+            like.append((peer, torch.empty(n, dtype=arr.dtype, device=arr.device)))
+            dst_views.append([view(arr, b) for b in in_by[peer]])
     got = comm.exchange(sends, like)
-    for view, t in zip(dst, got):
-        view.copy_(t)
+    for views, flat in zip(dst_views, got):
+        at = 0
+        for v in views:
+            v.copy_(flat[at:at + v.numel()].view(v.shape))
+            at += v.numel()
 
 
 class ShardedVolume:
@@ -189,6 +219,7 @@ class ShardedVolume:
         self.shape = tuple(int(v) for v in shape)
         self.rank, self.world = rank, world
         self.device = torch.device(device)
+        self.halo = halo
         self.slabs = slab_bounds(self.shape[2], world)
         self.windows = [window_of(s, self.shape[2], world, halo) for s in self.slabs]
         self.slab, self.window = self.slabs[rank], self.windows[rank]
@@ -223,7 +254,8 @@ class ShardedVolume:
 
         # ---- stage 1 --------------------------------------------------------------------
         t0 = time.perf_counter()
-        origins, eff = tiles_for_slab(self.shape, tile, tile_overlap, self.slab)
+        plan, eff = tile_plan(self.shape, tile, tile_overlap, self.world, halo=self.halo)
+        origins = plan[self.rank]
         for (_, _, oz) in origins:
             assert wlo <= oz and oz + eff[2] <= whi, "tile outside the rank's window: increase the halo"
         owners = [cropper.owner_table(dm, c, o) for dm, c, o in zip(self.shape, eff, tile_overlap)]
@@ -265,11 +297,9 @@ class ShardedVolume:
         for c in ctxs:
             if c is not None:
                 c.profile = None
-        if self.world > 1:  # hand the planes of slab-straddling tiles to the next rank
-            ext = straddle_extent(self.shape, tile, tile_overlap, self.slabs)
-            for e, (lo, hi), (wl, wh) in zip(ext, self.slabs, self.windows):
-                assert hi + e <= wh, "a straddling tile writes outside its rank's window"
-            exchange_straddle([state.vec4, state.skeleton], ext, self.slabs, self.windows, self.rank, comm)
+        if self.world > 1:  # what this rank's tiles wrote into other ranks' slabs goes to them
+            blocks = block_plan(self.shape, eff, tile_overlap, plan)
+            exchange_blocks([state.vec4, state.skeleton], blocks, self.windows, self.rank, comm)
         self._tick("stage1", t0)
 
         # ---- stage 2 --------------------------------------------------------------------

@@ -30,33 +30,112 @@ def test_slabs_and_windows_cover_the_volume():
             assert w[0] <= s[0] and s[1] <= w[1] and 0 <= w[0] and w[1] <= Z
 
 
-@pytest.mark.parametrize("shape,world", [((1024, 1024, 256), 2), ((2048, 2048, 512), 8), ((640, 333, 250), 3)])
-def test_every_tile_runs_once_and_every_plane_is_delivered(shape, world):
+def _global_writer_map(shape, eff, ov):
+    """tile index (in distinct_origins order) that writes each voxel last, -1 = never written."""
+    tiles = cropper.distinct_origins(shape, list(eff), ov)
+    own = [cropper.owner_table(d, c, o) for d, c, o in zip(shape, eff, ov)]
+    idx = {t: i for i, t in enumerate(tiles)}
+    G = np.full(shape, -1, dtype=np.int32)
+    for t in tiles:
+        r = [np.nonzero(o == v)[0] for o, v in zip(own, t)]
+        if all(len(a) for a in r):
+            G[r[0][0]:r[0][-1] + 1, r[1][0]:r[1][-1] + 1, r[2][0]:r[2][-1] + 1] = idx[t]
+    return G, tiles, idx
+
+
+@pytest.mark.parametrize("shape,world", [((1024, 1024, 256), 2), ((2048, 1024, 256), 2), ((2048, 2048, 256), 4),
+                                         ((2048, 2048, 512), 8), ((640, 333, 250), 3)])
+def test_every_tile_runs_once_and_the_split_is_balanced(shape, world):
     tile, ov = (300, 300, 20), (50, 50, 5)
-    eff = list(tile)
-    all_tiles = cropper.distinct_origins(shape, eff, ov)
-    own_z = cropper.owner_table(shape[2], eff[2], ov[2])
+    plan, eff = P.tile_plan(shape, tile, ov, world)
+    all_tiles = cropper.distinct_origins(shape, list(tile), ov)
+    assert sorted(t for p in plan for t in p) == sorted(all_tiles)  # each tile exactly once
+    n = [len(p) for p in plan]
+    assert max(n) - min(n) <= 1, n  # 2048x2048x512 on 8 ranks: 637 or 638 tiles each, not 600 / 700
     slabs = P.slab_bounds(shape[2], world)
-    ext = P.straddle_extent(shape, tile, ov, slabs)
-    union = []
-    for r in range(world):
-        mine, eff_r = P.tiles_for_slab(shape, tile, ov, slabs[r])
-        assert eff_r == eff
-        zs = {o[2] for o in mine}
+    for r, p in enumerate(plan):
         w = P.window_of(slabs[r], shape[2], world)
-        assert all(w[0] <= o[2] and o[2] + eff[2] <= w[1] for o in mine)  # tiles fit the window
-        assert mine == [o for o in all_tiles if o[2] in zs]  # reference order preserved
-        # every owned plane is written by one of this rank's tiles or delivered by rank r-1
-        prev = {o[2] for o in P.tiles_for_slab(shape, tile, ov, slabs[r - 1])[0]} if r else set()
-        for z in range(*slabs[r]):
-            if own_z[z] < 0:
-                continue
-            if own_z[z] in zs:
-                continue
-            assert own_z[z] in prev and z < slabs[r][0] + ext[r - 1], (r, z)
-        assert slabs[r][1] + ext[r] <= w[1]
-        union += mine
-    assert sorted(union) == sorted(all_tiles)  # each tile exactly once
+        assert all(w[0] <= o[2] and o[2] + eff[2] <= w[1] for o in p)  # tiles fit the window
+    # every box a tile writes outside its rank's slab is scheduled exactly once, inside both windows
+    for src, dst, (x0, x1, y0, y1, z0, z1) in P.block_plan(shape, eff, ov, plan):
+        assert src != dst and slabs[dst][0] <= z0 < z1 <= slabs[dst][1]
+        ws = P.window_of(slabs[src], shape[2], world)
+        assert ws[0] <= z0 and z1 <= ws[1]
+
+
+def test_thin_slabs_are_refused():
+    with pytest.raises(ValueError, match="too thin"):
+        P.tile_plan((300, 300, 64), (300, 300, 20), (50, 50, 5), 4, halo=4)
+
+
+@pytest.mark.parametrize("shape,tile,ov,world", [((30, 26, 40), (12, 12, 8), (2, 2, 2), 2),
+                                                 ((30, 26, 41), (12, 12, 8), (2, 2, 2), 3),
+                                                 ((25, 12, 64), (12, 12, 8), (2, 3, 1), 4)])
+def test_block_plan_delivers_every_slab_voxel(shape, tile, ov, world):
+    """Simulated ranks (no process group): scatter own tiles into the window, apply the block plan,
+    compare every slab with the single-rank writer map."""
+    G, tiles, idx = _global_writer_map(shape, tile, ov)
+    plan, eff = P.tile_plan(shape, tile, ov, world, halo=10)
+    slabs = P.slab_bounds(shape[2], world)
+    own = [cropper.owner_table(d, c, o) for d, c, o in zip(shape, eff, ov)]
+    local = []
+    for r in range(world):
+        L = np.full(shape, -1, dtype=np.int32)  # full-size array, only the window is ever touched
+        for t in plan[r]:
+            rr = [np.nonzero(o == v)[0] for o, v in zip(own, t)]
+            if all(len(a) for a in rr):
+                L[rr[0][0]:rr[0][-1] + 1, rr[1][0]:rr[1][-1] + 1, rr[2][0]:rr[2][-1] + 1] = idx[t]
+        local.append(L)
+    for src, dst, (x0, x1, y0, y1, z0, z1) in P.block_plan(shape, eff, ov, plan):
+        local[dst][x0:x1, y0:y1, z0:z1] = local[src][x0:x1, y0:y1, z0:z1]
+    for r, (lo, hi) in enumerate(slabs):
+        assert np.array_equal(local[r][:, :, lo:hi], G[:, :, lo:hi]), r
+
+
+def _blocks_worker(rank, world, port, shape, tile, ov, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        G, tiles, idx = _global_writer_map(shape, tile, ov)
+        plan, eff = P.tile_plan(shape, tile, ov, world, halo=10)
+        slabs = P.slab_bounds(shape[2], world)
+        wins = [P.window_of(s, shape[2], world, halo=10) for s in slabs]
+        (zlo, zhi), (wlo, whi) = slabs[rank], wins[rank]
+        own = [cropper.owner_table(d, c, o) for d, c, o in zip(shape, eff, ov)]
+        a = torch.full((shape[0], shape[1], whi - wlo), -1, dtype=torch.int32)
+        b = torch.full((shape[0], shape[1], whi - wlo, 4), -1, dtype=torch.int16)
+        for t in plan[rank]:
+            rr = [np.nonzero(o == v)[0] for o, v in zip(own, t)]
+            if all(len(x) for x in rr):
+                sl = (slice(rr[0][0], rr[0][-1] + 1), slice(rr[1][0], rr[1][-1] + 1),
+                      slice(rr[2][0] - wlo, rr[2][-1] + 1 - wlo))
+                a[sl] = idx[t]
+                b[sl] = idx[t]
+        P.exchange_blocks([a, b], P.block_plan(shape, eff, ov, plan), wins, rank, P.Comm(rank, world))
+        want = torch.from_numpy(G[:, :, zlo:zhi])
+        ok_a = torch.equal(a[:, :, zlo - wlo:zhi - wlo], want)
+        ok_b = torch.equal(b[:, :, zlo - wlo:zhi - wlo], want.to(torch.int16).unsqueeze(-1).expand(-1, -1, -1, 4))
+        q.put((rank, ok_a, ok_b))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape", [(2, (30, 26, 40)), (3, (30, 26, 41))])
+def test_block_exchange_gloo(world, shape):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_blocks_worker, args=(r, world, port, shape, (12, 12, 8), (2, 2, 2), q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_a, ok_b in results:
+        assert ok_a and ok_b, (rank, ok_a, ok_b)
 
 
 def _worker(rank, world, port, shape, q):
