@@ -100,11 +100,11 @@ def label_skeleton(skeleton_u8: Tensor, crop=FLOOD_CROP, reference_ids: bool = T
     return labels
 
 
-def label_slab(skeleton_win: Tensor, shape, slab, window, slabs, rank: int, comm):
+def label_slab(skeleton_win: Tensor, shape, slab, window, slabs, rank: int, comm, sparse=None):
     """Z-sharded labelling.  ``skeleton_win``: this rank's (X, Y, window) uint8 mask.
     Labels the rank's slab, merges components across slab boundaries (exchange of the
     boundary label planes + all-gather of the seam equivalences) and all-gathers the
-    slabs.  Returns (full (X, Y, Z) int32 label volume, number of labels before merging).
+    slabs (``sparse``: as foreground (position, label) lists; None = when that is smaller).  Returns (full (X, Y, Z) int32 label volume, number of labels before merging).
     Ids are 1..K in rank order, not the single-GPU flood-grid numbering; the partition
     (what stage 3 and renumber consume) is identical."""
     X, Y, Z = shape
@@ -146,8 +146,11 @@ def label_slab(skeleton_win: Tensor, shape, slab, window, slabs, rank: int, comm
         n = int(count.item())
         if n:
             pairs_np = np.unique(pairs[:n].cpu().numpy(), axis=0)
-    # all-gather the (few) seam equivalences, padded to a common length
-    lens = [int(t.item()) for t in comm.all_gather(torch.tensor([len(pairs_np)], dtype=torch.int64, device=dev))]
+    # all-gather the (few) seam equivalences, padded to a common length (+ the slab's foreground count)
+    nz = torch.nonzero(mine.reshape(-1)).flatten()  # positions do not change under the relabelling below
+    meta = comm.all_gather(torch.tensor([len(pairs_np), nz.numel()], dtype=torch.int64, device=dev))
+    lens = [int(t[0].item()) for t in meta]
+    nnz = [int(t[1].item()) for t in meta]
     mx = max(max(lens), 1)
     pad = np.zeros((mx, 2), dtype=np.int32)
     pad[:len(pairs_np)] = pairs_np
@@ -170,8 +173,21 @@ def label_slab(skeleton_win: Tensor, shape, slab, window, slabs, rank: int, comm
         lut_d = torch.from_numpy(my_lut).to(dev)
         _ffi.check(_ffi.lib.sk_relabel_lut(_ffi.ptr(mine), mine.numel(), _ffi.ptr(lut_d), k_local + 1, st))
         torch.cuda.current_stream(dev).synchronize()
-    # all-gather the slabs into the full label volume (slabs may differ in thickness by one plane)
+    # every rank needs the full label volume (a 10-step follow ends up to ~165 planes away).  Skeletons are
+    # sparse: ship (global position, label) of the foreground voxels -- 8 B each -- instead of 4 B for every voxel
+    # (2048x2048x512: 8 GiB dense over xGMI against a few tens of MB); dense all-gather only for dense masks.
     zmax = max(b - a for a, b in slabs)
+    if (max(nnz) * 8 <= X * Y * zmax * 2) if sparse is None else sparse:
+        xy, zz = torch.div(nz, zl, rounding_mode="floor"), nz % zl
+        packed = ((xy * Z + zz + zlo) << 32) | mine.reshape(-1)[nz].to(torch.int64)
+        cap = max(max(nnz), 1)
+        if packed.numel() < cap:
+            packed = torch.cat([packed, torch.zeros(cap - packed.numel(), dtype=torch.int64, device=dev)])
+        full = torch.zeros(X * Y * Z, dtype=torch.int32, device=dev)
+        for part, n_r in zip(comm.all_gather(packed), nnz):
+            part = part[:n_r]
+            full[part >> 32] = (part & 0xFFFFFFFF).to(torch.int32)
+        return full.view(X, Y, Z), total
     if zl < zmax:
         padded = torch.zeros((X, Y, zmax), dtype=torch.int32, device=dev)
         padded[:, :, :zl] = mine

@@ -167,9 +167,10 @@ class Comm:
         return [b.to(t.device) for b, (_, t) in zip(staged_recv, recv_like)]
 
 
-def exchange_halo(arr: Tensor, slabs, windows, rank: int, comm: Comm) -> None:
-    """Fill the halo planes of a window-shaped array (X, Y, Zl, ...) from their owners."""
-    sends, recvs = halo_plan(slabs, windows, rank)
+def exchange_halo(arr: Tensor, slabs, windows, rank: int, comm: Comm, needs=None) -> None:
+    """Fill the halo planes of a window-shaped array (X, Y, Zl, ...) from their owners.  ``needs``:
+    per-rank plane ranges (inside the windows) that are actually read afterwards; default: the windows."""
+    sends, recvs = halo_plan(slabs, windows if needs is None else needs, rank)
     w0 = windows[rank][0]
     out = [(q, arr[:, :, lo - w0:hi - w0]) for q, lo, hi in sends]
     like = [(q, torch.empty((arr.shape[0], arr.shape[1], hi - lo) + tuple(arr.shape[3:]), dtype=arr.dtype,
@@ -177,6 +178,21 @@ def exchange_halo(arr: Tensor, slabs, windows, rank: int, comm: Comm) -> None:
     got = comm.exchange(out, like)
     for (q, lo, hi), t in zip(recvs, got):
         arr[:, :, lo - w0:hi - w0] = t
+
+
+def assign_reach(shape: Sequence[int], crop: Sequence[int], overlap: Sequence[int], slabs, windows):
+    """Per rank: the plane range stage 3 reads vectors from -- the union of the 500x500x50 crops
+    (eval.py:248-284) that write the rank's planes last, clipped to its window.  Less than the
+    full halo on most ranks (2048x2048x512 / 8: 24-42 planes a side instead of 48)."""
+    eff = cropper.clamp_crop_(list(crop), shape)
+    own_z = cropper.owner_table(shape[2], eff[2], overlap[2])
+    out = []
+    for (lo, hi), (wl, wh) in zip(slabs, windows):
+        oz = own_z[lo:hi]
+        oz = oz[oz >= 0]
+        a, b = (int(oz.min()), int(oz.max()) + eff[2]) if oz.size else (lo, hi)
+        out.append((max(wl, min(a, lo)), min(wh, max(b, hi))))
+    return out
 
 
 def exchange_blocks(arrays: Sequence[Tensor], blocks, windows, rank: int, comm: "Comm") -> None:
@@ -220,6 +236,7 @@ class ShardedVolume:
         self.rank, self.world = rank, world
         self.device = torch.device(device)
         self.halo = halo
+        self.sparse_labels = None  # label all-gather as sparse lists: None = automatic (tests force either)
         self.slabs = slab_bounds(self.shape[2], world)
         self.windows = [window_of(s, self.shape[2], world, halo) for s in self.slabs]
         self.slab, self.window = self.slabs[rank], self.windows[rank]
@@ -309,14 +326,15 @@ class ShardedVolume:
             n_labels_hint = None
         else:
             labels, n_labels_hint = label_slab(state.skeleton, self.shape, self.slab, self.window,
-                                               self.slabs, self.rank, comm)
+                                               self.slabs, self.rank, comm, sparse=self.sparse_labels)
         state.labels = labels
         self._tick("stage2", t0)
 
         # ---- stage 3 --------------------------------------------------------------------
         t0 = time.perf_counter()
         if self.world > 1:
-            exchange_halo(state.vec4, self.slabs, self.windows, self.rank, comm)
+            exchange_halo(state.vec4, self.slabs, self.windows, self.rank, comm,
+                          needs=assign_reach(self.shape, ASSIGN_CROP, ASSIGN_OVERLAP, self.slabs, self.windows))
         inst = state.assign(scale, n=n, decay=decay, crop=ASSIGN_CROP, overlap=ASSIGN_OVERLAP,
                             labels=labels, z_range=self.slab)
         self._tick("stage3", t0)

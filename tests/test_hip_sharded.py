@@ -25,7 +25,7 @@ def _field():
     return blob_field(SHAPE, seed=11, n_blobs=120, rmax=(9, 9, 3))
 
 
-def _run_rank(rank, world, port, q):
+def _run_rank(rank, world, port, q, sparse=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -35,6 +35,7 @@ def _run_rank(rank, world, port, q):
         torch.cuda.set_device(dev)
         out_vol, _ = _field()
         sv = ShardedVolume(SHAPE, rank, world, dev)
+        sv.sparse_labels = sparse
         wlo, whi = sv.window
         out_dev = out_vol[:, :, :, wlo:whi].contiguous().to(dev)
         image = torch.zeros((SHAPE[0], SHAPE[1], whi - wlo), dtype=torch.float16, device=dev)
@@ -49,8 +50,8 @@ def _run_rank(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_equals_single(world):
+@pytest.mark.parametrize("world,sparse", [(2, None), (3, None), (2, False)])
+def test_sharded_equals_single(world, sparse):
     from skoots_amd.lib import eval as E
     out_vol, k = _field()
     dev = "cuda:0"
@@ -68,7 +69,7 @@ def test_sharded_equals_single(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_rank, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run_rank, args=(r, world, port, q, sparse)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in range(world)]

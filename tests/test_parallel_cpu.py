@@ -154,6 +154,14 @@ def _worker(rank, world, port, shape, q):
         local[:, :, zlo - wlo:zhi - wlo] = G[:, :, zlo:zhi]
         P.exchange_halo(local, slabs, wins, rank, comm)
         ok_halo = torch.equal(local, G[:, :, wlo:whi])
+        # trimmed exchange: only the planes each rank says it needs are filled
+        needs = [(max(w[0], s_[0] - 2), min(w[1], s_[1] + 3)) for s_, w in zip(slabs, wins)]
+        local2 = torch.full((X, Y, whi - wlo, 4), -1, dtype=torch.int32)
+        local2[:, :, zlo - wlo:zhi - wlo] = G[:, :, zlo:zhi]
+        P.exchange_halo(local2, slabs, wins, rank, comm, needs=needs)
+        nlo, nhi = needs[rank]
+        ok_halo = ok_halo and torch.equal(local2[:, :, nlo - wlo:nhi - wlo], G[:, :, nlo:nhi]) and \
+            bool((local2[:, :, :nlo - wlo] == -1).all()) and bool((local2[:, :, nhi - wlo:] == -1).all())
         parts = comm.all_gather(torch.tensor([rank * 10 + 1]))
         ok_gather = [int(p.item()) for p in parts] == [r * 10 + 1 for r in range(world)]
         m = comm.all_reduce_min(torch.tensor([5 + rank, 100 - rank], dtype=torch.int64))
@@ -177,6 +185,20 @@ def test_halo_exchange_gloo(world, shape):
         assert p.exitcode == 0
     for rank, ok_halo, ok_gather, ok_min in results:
         assert ok_halo and ok_gather and ok_min, (rank, ok_halo, ok_gather, ok_min)
+
+
+def test_assign_reach_covers_the_owning_crops():
+    from skoots_amd.lib.eval import ASSIGN_CROP, ASSIGN_OVERLAP
+    for shape, world in (((2048, 2048, 512), 8), ((2048, 1024, 256), 2), ((320, 304, 180), 3), ((64, 64, 40), 2)):
+        slabs = P.slab_bounds(shape[2], world)
+        wins = [P.window_of(s_, shape[2], world) for s_ in slabs]
+        eff = cropper.clamp_crop_(list(ASSIGN_CROP), shape)
+        own = cropper.owner_table(shape[2], eff[2], ASSIGN_OVERLAP[2])
+        for (lo, hi), (wl, wh), (a, b) in zip(slabs, wins, P.assign_reach(shape, ASSIGN_CROP, ASSIGN_OVERLAP, slabs, wins)):
+            assert wl <= a <= lo and hi <= b <= wh
+            for z in range(lo, hi):
+                if own[z] >= 0:
+                    assert a <= own[z] and own[z] + eff[2] <= b
 
 
 def test_halo_plan_is_symmetric():
