@@ -869,10 +869,11 @@ struct GatherArgs {
     int nblk;
 };
 
-template <int COUT, int PV>
+template <int COUT, int PV, int D>
 __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
     constexpr int NT = COUT / 32;
     __shared__ float red[4 * NT * 16];
+    __shared__ float aff[2 * 128];   // silu(a*x + b) coefficients of this batch item (RAW input only)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
     const int b = blockIdx.x / a.nblk;
@@ -880,6 +881,7 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
     const long long nvox = (long long)a.Xo * a.Yo * a.Zo;
     const int ntaps = a.ksize * a.ksize * a.ksize;
     const int nks = a.Cin / 16;
+    const int nsteps = ntaps * nks;      // K steps of 16 channels; host guarantees nsteps % D == 0
 
     f32x16 acc[PV][NT];
     long long vin[PV];   // input voxel index of tap (0,0,0)
@@ -907,42 +909,63 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
             }
         }
     }
-    const char* inb = a.in + (long long)b * a.Xi * a.Yi * a.Zi * a.Cin * 2;
-    for (int tap = 0; tap < ntaps; ++tap) {
-        int dx = tap / (a.ksize * a.ksize), dy = (tap / a.ksize) % a.ksize, dz = tap % a.ksize;
-        long long toff = ((long long)dx * a.Yi + dy) * a.Zi + dz;
-        for (int ks = 0; ks < nks; ++ks) {
-            half8 afr[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                afr[nt] = *reinterpret_cast<const half8*>(
-                    a.wpk + ((long long)(tap * nks + ks) * NT + nt) * 1024 + lane * 16);
-            float ga[8], gb[8];
-            if (a.affine) {  // this lane's 8 input channels of the K step
-                const float* ap = a.affine + (long long)b * 2 * a.Cin + ks * 16 + 8 * h;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    ga[j] = ap[j];
-                    gb[j] = ap[a.Cin + j];
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < PV; ++p) {
-                half8 bfr = *reinterpret_cast<const half8*>(
-                    inb + ((vin[p] + toff) * a.Cin + ks * 16 + 8 * h) * 2);
-                if (a.affine) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float y = fmaf(ga[j], (float)bfr[j], gb[j]);
-                        bfr[j] = (_Float16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));
-                    }
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[nt], bfr, acc[p][nt], 0, 0, 0);
-            }
-        }
+    const bool raw = a.affine != nullptr;
+    if (raw) {
+        for (int i = tid; i < 2 * a.Cin; i += 256) aff[i] = a.affine[(long long)b * 2 * a.Cin + i];
+        __syncthreads();
     }
+    const char* inb = a.in + (long long)b * a.Xi * a.Yi * a.Zi * a.Cin * 2;
+    // Software pipeline, D steps deep: the B fragments (16 B per lane straight from HBM, no reuse) and the weight
+    // fragments of step s + D are requested before step s is multiplied -- a wave keeps D*(PV + NT) KiB in flight
+    // instead of one load -> wait -> MFMA round trip per step.
+    half8 afr[D][NT], bfr[D][PV];
+#define SK_GATHER_ISSUE(S, SLOT)                                                                              \
+    {                                                                                                         \
+        const int s_ = (S);                                                                                   \
+        const int tap_ = s_ / nks, ks_ = s_ - tap_ * nks;                                                     \
+        const int dx_ = tap_ / (a.ksize * a.ksize), dy_ = (tap_ / a.ksize) % a.ksize, dz_ = tap_ % a.ksize;   \
+        const long long toff_ = ((long long)dx_ * a.Yi + dy_) * a.Zi + dz_;                                   \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) afr[SLOT][nt] =                                     \
+            *reinterpret_cast<const half8*>(a.wpk + ((long long)s_ * NT + nt) * 1024 + lane * 16);            \
+        _Pragma("unroll") for (int p = 0; p < PV; ++p) bfr[SLOT][p] = *reinterpret_cast<const half8*>(        \
+            inb + ((vin[p] + toff_) * a.Cin + ks_ * 16 + 8 * h) * 2);                                         \
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) SK_GATHER_ISSUE(d, d)
+    // no branch around the requests of the steady state: a conditional issue makes the compiler's vmcnt
+    // bookkeeping fall back to vmcnt(0) at the join, i.e. one round trip per step again
+#define SK_GATHER_STEP(S, SLOT, PREFETCH)                                                                     \
+    {                                                                                                         \
+        const int s = (S);                                                                                    \
+        half8 av[NT], bv[PV];                                                                                 \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) av[nt] = afr[SLOT][nt];                             \
+        _Pragma("unroll") for (int p = 0; p < PV; ++p) bv[p] = bfr[SLOT][p];                                  \
+        if (PREFETCH) SK_GATHER_ISSUE(s + D, SLOT)                                                            \
+        if (raw) { /* this lane's 8 input channels of the K step */                                           \
+            const int c0 = (s % nks) * 16 + 8 * h;                                                            \
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(aff + c0);                                       \
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(aff + c0 + 4);                                   \
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(aff + a.Cin + c0);                               \
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(aff + a.Cin + c0 + 4);                           \
+            const float ga[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};                     \
+            const float gb[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};                     \
+            _Pragma("unroll") for (int p = 0; p < PV; ++p) _Pragma("unroll") for (int j = 0; j < 8; ++j) {    \
+                float y = fmaf(ga[j], (float)bv[p][j], gb[j]);                                                \
+                bv[p][j] = (_Float16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));                         \
+            }                                                                                                 \
+        }                                                                                                     \
+        _Pragma("unroll") for (int p = 0; p < PV; ++p) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)      \
+            acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[nt], bv[p], acc[p][nt], 0, 0, 0);          \
+    }
+    int s0 = 0;
+    for (; s0 + D < nsteps; s0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) SK_GATHER_STEP(s0 + d, d, true)
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) SK_GATHER_STEP(s0 + d, d, false)
+#undef SK_GATHER_STEP
+#undef SK_GATHER_ISSUE
     float gsum[NT][4], gsq[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -1218,12 +1241,15 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
     g.ksize = ksize;
     g.nblk = sk_conv3d_num_blocks(B, ox, oy, oz, cout, ksize);
     unsigned grid = (unsigned)(g.nblk * B);
+    const int nsteps = ksize * ksize * ksize * (g.Cin / 16);
+    SK_CHECK_ARG(g.Cin <= 128 && nsteps % 2 == 0, "sk_conv3d: ksize %d needs 32 <= cin <= 128 (got %d)", ksize, g.Cin);
+    const bool deep = nsteps % 4 == 0;  // pipeline depth 4 (2 only for the 32-channel pointwise case)
     if (cout == 32)
-        gather_gemm_kernel<32, 2><<<grid, 256, 0, stream>>>(g);
+        deep ? gather_gemm_kernel<32, 2, 4><<<grid, 256, 0, stream>>>(g) : gather_gemm_kernel<32, 2, 2><<<grid, 256, 0, stream>>>(g);
     else if (cout == 64)
-        gather_gemm_kernel<64, 2><<<grid, 256, 0, stream>>>(g);
+        deep ? gather_gemm_kernel<64, 2, 4><<<grid, 256, 0, stream>>>(g) : gather_gemm_kernel<64, 2, 2><<<grid, 256, 0, stream>>>(g);
     else
-        gather_gemm_kernel<128, 1><<<grid, 256, 0, stream>>>(g);
+        deep ? gather_gemm_kernel<128, 1, 4><<<grid, 256, 0, stream>>>(g) : gather_gemm_kernel<128, 1, 2><<<grid, 256, 0, stream>>>(g);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
