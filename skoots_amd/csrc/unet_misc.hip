@@ -34,6 +34,7 @@ struct StemArgs {
     float* partial;        // (B, nblk, 8, 2)     (stats pass)
     const float* affine;   // (B, 2, 32)           (apply pass)
     int nblk;
+    int rows;              // y rows per workgroup (stem_rows)
 };
 
 
@@ -66,7 +67,19 @@ __global__ void __launch_bounds__(256) stem_norm_kernel(StemArgs a) {
 // write + read-modify-write pass: the conv is 4 MFMAs per 32 voxels, the tensor is 64 B/voxel.
 // Weights are split w = hi + lo (two fp16 values, 22 significant bits) and the input is exactly
 // fp16, so the products are exact and the sums match an fp32 conv to ~1e-7 relative.
-constexpr int kStemRows = 48;   // y rows of one x plane per workgroup
+// y rows of one x plane per workgroup: up to 150, within 40 KiB of LDS for the three staged planes.  The per-block
+// prologue (weight split, tap offsets, staging latency) is amortised over rows*Zt/32 tiles; statistics pass per 8
+// tiles of 300x300x20, rocprofv3: 60 rows 189 us, 100: 165, 150: 151, 300: 149 (apply pass 332 / 327 / 324 / 338).
+static int stem_rows(int Yt, int Zt) {
+    int r = (40 * 1024) / (3 * (Zt + 2) * (int)sizeof(__half)) - 2;
+    if (r > 150) r = 150;
+    if (const char* e = getenv("SK_STEM_ROWS")) r = atoi(e);
+    if (r > Yt) r = Yt;
+    // even split of Yt
+    int n = (Yt + r - 1) / r;
+    r = (Yt + n - 1) / n;
+    return r < 1 ? 1 : r;
+}
 
 template <bool STATS>
 __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
@@ -74,17 +87,17 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned int stem_lds[];  // [3][rows+2][Zt+2] halves
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
-    const int nyc = (a.Yt + kStemRows - 1) / kStemRows;
+    const int nyc = (a.Yt + a.rows - 1) / a.rows;
     int blk = blockIdx.x % a.nblk;
     const int b = blockIdx.x / a.nblk;
-    const int x = blk / nyc, y0 = (blk % nyc) * kStemRows;
-    const int rows = min(kStemRows, a.Yt - y0);
+    const int x = blk / nyc, y0 = (blk % nyc) * a.rows;
+    const int rows = min(a.rows, a.Yt - y0);
     const long long nvox = (long long)a.Xt * a.Yt * a.Zt;
     const int py = a.Yt + 2, pz = a.Zt + 2;
     const __half* nb = a.norm + (long long)b * (a.Xt + 2) * py * pz;
 
     // stage the three padded x planes' rows [y0, y0 + rows + 2): contiguous (rows+2)*pz halves each
-    const int seg_halves = (kStemRows + 2) * pz;          // LDS pitch per plane (halves, even)
+    const int seg_halves = (a.rows + 2) * pz;          // LDS pitch per plane (halves, even)
     const int seg_dw = (rows + 2) * pz / 2;               // dwords to copy (pz is even: Zt % 4 == 0)
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
@@ -369,11 +382,11 @@ __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
 extern "C" {
 
 int sk_conv3d_stem_num_blocks(int X, int Y, int Z) {
-    (void)Z;
-    return X * ((Y + kStemRows - 1) / kStemRows);
+    const int r = stem_rows(Y, Z);
+    return X * ((Y + r - 1) / r);
 }
 
-static size_t stem_lds_bytes(int Zt) { return (size_t)3 * (kStemRows + 2) * (Zt + 2) * sizeof(__half); }
+static size_t stem_lds_bytes(int Yt, int Zt) { return (size_t)3 * (stem_rows(Yt, Zt) + 2) * (Zt + 2) * sizeof(__half); }
 
 size_t sk_conv3d_stem_workspace_bytes(int B, int Xt, int Yt, int Zt) {
     return (size_t)B * (Xt + 2) * (Yt + 2) * (Zt + 2) * sizeof(__half);
@@ -412,6 +425,7 @@ static int fill_stem_args(StemArgs& a, const void* image, int X, int Y, int Z, c
     a.bias = bias;
     a.norm = (__half*)workspace;
     a.nblk = sk_conv3d_stem_num_blocks(Xt, Yt, Zt);
+    a.rows = stem_rows(Yt, Zt);
     return SK_OK;
 }
 
@@ -427,11 +441,11 @@ int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origin
     long long np = (long long)(Xt + 2) * (Yt + 2) * (Zt + 2);
     dim3 g1(sk::cdiv(np, 256), B);
     stem_norm_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(a);
-    SK_CHECK_ARG(Zt % 2 == 0 && stem_lds_bytes(Zt) <= 60 * 1024, "sk_conv3d_stem: tile depth %d unsupported", Zt);
-    if (stem_lds_bytes(Zt) > 40 * 1024)
+    SK_CHECK_ARG(Zt % 2 == 0 && stem_lds_bytes(Yt, Zt) <= 60 * 1024, "sk_conv3d_stem: tile depth %d unsupported", Zt);
+    if (stem_lds_bytes(Yt, Zt) > 40 * 1024)
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)stem_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)stem_lds_bytes(Zt)));
-    stem_kernel<true><<<(unsigned)(a.nblk * B), 256, stem_lds_bytes(Zt), (hipStream_t)stream>>>(a);
+                                         (int)stem_lds_bytes(Yt, Zt)));
+    stem_kernel<true><<<(unsigned)(a.nblk * B), 256, stem_lds_bytes(Yt, Zt), (hipStream_t)stream>>>(a);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
@@ -451,10 +465,11 @@ int sk_conv3d_stem_apply(int B, int Xt, int Yt, int Zt, const float* weight, con
     a.norm = (__half*)workspace;
     a.out = (__half*)out;
     a.nblk = sk_conv3d_stem_num_blocks(Xt, Yt, Zt);
-    if (stem_lds_bytes(Zt) > 40 * 1024)
+    a.rows = stem_rows(Yt, Zt);
+    if (stem_lds_bytes(Yt, Zt) > 40 * 1024)
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)stem_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)stem_lds_bytes(Zt)));
-    stem_kernel<false><<<(unsigned)(a.nblk * B), 256, stem_lds_bytes(Zt), (hipStream_t)stream>>>(a);
+                                         (int)stem_lds_bytes(Yt, Zt)));
+    stem_kernel<false><<<(unsigned)(a.nblk * B), 256, stem_lds_bytes(Yt, Zt), (hipStream_t)stream>>>(a);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
