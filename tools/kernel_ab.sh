@@ -23,6 +23,7 @@ import glob, re, sqlite3, sys
 tag, pat = sys.argv[1], re.compile(sys.argv[2])
 db = sqlite3.connect(glob.glob(f"/tmp/kernel_ab/{tag}_results.db")[0])
 rows = [(n, c, a) for n, c, a in db.execute("select name, total_calls, average from top_kernels order by name") if pat.search(n)]
-print(tag, "  ".join(f"{re.sub(r'.*::|\(.*', '', n)}x{c}={a:.1f}us" for n, c, a in rows), flush=True)
+short = lambda n: re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "").replace("void ", ""))
+print(tag, "  ".join(f"{short(n)} x{c} = {a:.1f} us" for n, c, a in rows), flush=True)
 PY
 done
