@@ -46,7 +46,8 @@ __global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const float* __restric
 //   dgamma = sum_b S2, dbeta = sum_b S1
 //   dy = rstd * (gamma*du - m1 - xh*m2),  m1 = sum_{c in g} gamma*S1 / n,  m2 = sum_{c in g} gamma*S2 / n
 // ------------------------------------------------------------------------------------------
-constexpr int kGnbVox = 2048;  // voxels per reduction block
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+constexpr int kGnbVox = 8192;  // voxels per reduction block (partials per layer: 2048 at 256^3 -> the one-block finalize stays short)
 
 __device__ inline float silu_grad(float u) {
     float s = sigmoid_(u);
@@ -672,43 +673,61 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce16_kernel(const float* __res
                                                               const float* __restrict__ affine,
                                                               const float* __restrict__ stats, int C, int groups,
                                                               long long voxels, int nblk, float* __restrict__ partial) {
-    __shared__ float red[256 * 4];
+    // a lane owns 8 consecutive channels of a voxel: one 16-byte load of y, two of dz per voxel (the scalar version --
+    // one channel per lane, constants re-read per element -- ran at half of the HBM rate)
+    __shared__ float red[256 * 9];
     const int b = blockIdx.y, tid = threadIdx.x;
-    const int c = tid % C, row = tid / C, rows = 256 / C;
-    const int g = c / (C / groups);
-    const float a = affine[(long long)b * 2 * C + c], bb = affine[(long long)b * 2 * C + C + c];
-    const float mean = stats[((long long)b * groups + g) * 2], rstd = stats[((long long)b * groups + g) * 2 + 1];
+    const int nq = C / 8, q = tid % nq, row = tid / nq, rows = 256 / nq;
+    const int c0 = q * 8, gs = C / groups;
+    float a[8], bb[8], mean[8], rstd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (c0 + j) / gs;
+        a[j] = affine[(long long)b * 2 * C + c0 + j];
+        bb[j] = affine[(long long)b * 2 * C + C + c0 + j];
+        mean[j] = stats[((long long)b * groups + g) * 2];
+        rstd[j] = stats[((long long)b * groups + g) * 2 + 1];
+    }
     const long long v0 = (long long)blockIdx.x * kGnbVox;
     long long v1 = v0 + kGnbVox;
     if (v1 > voxels) v1 = voxels;
-    float s1 = 0.0f, s2 = 0.0f, m1 = 0.0f, m2 = 0.0f;
+    float s1[8], s2[8], m1[8], m2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = m1[j] = m2[j] = 0.0f;
     for (long long v = v0 + row; v < v1; v += rows) {
-        const long long i = ((long long)b * voxels + v) * C + c;
-        const float yv = __half2float(y[i]);
-        const float du = dz[i] * silu_grad(fmaf(a, yv, bb));
-        const float xh = (yv - mean) * rstd;
-        s1 += du;
-        s2 += du * xh;
-        m1 = fmaxf(m1, fabsf(du));
-        m2 = fmaxf(m2, fabsf(xh));
-    }
-    red[tid * 4] = s1;
-    red[tid * 4 + 1] = s2;
-    red[tid * 4 + 2] = m1;
-    red[tid * 4 + 3] = m2;
-    __syncthreads();
-    if (tid < C) {
-        for (int r = 1; r < rows; ++r) {
-            s1 += red[(r * C + tid) * 4];
-            s2 += red[(r * C + tid) * 4 + 1];
-            m1 = fmaxf(m1, red[(r * C + tid) * 4 + 2]);
-            m2 = fmaxf(m2, red[(r * C + tid) * 4 + 3]);
+        const long long i = ((long long)b * voxels + v) * C + c0;
+        const half8_t yv8 = *reinterpret_cast<const half8_t*>(y + i);
+        const float4 d0 = *reinterpret_cast<const float4*>(dz + i), d1 = *reinterpret_cast<const float4*>(dz + i + 4);
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float yv = (float)yv8[j];
+            const float du = dv[j] * silu_grad(fmaf(a[j], yv, bb[j]));
+            const float xh = (yv - mean[j]) * rstd[j];
+            s1[j] += du;
+            s2[j] += du * xh;
+            m1[j] = fmaxf(m1[j], fabsf(du));
+            m2[j] = fmaxf(m2[j], fabsf(xh));
         }
-        float* o = partial + (((long long)b * nblk + blockIdx.x) * C + tid) * 4;
-        o[0] = s1;
-        o[1] = s2;
-        o[2] = m1;
-        o[3] = m2;
+    }
+    // block reduction over the rows, one quantity at a time (fixed order: deterministic)
+    float* o = partial + ((long long)b * nblk + blockIdx.x) * C * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float* src = k == 0 ? s1 : k == 1 ? s2 : k == 2 ? m1 : m2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 9 + j] = src[j];
+        __syncthreads();
+        if (tid < C) {
+            const int qq = tid / 8, jj = tid % 8;
+            float t = 0.0f;
+            for (int r = 0; r < rows; ++r) {
+                const float v = red[(r * nq + qq) * 9 + jj];
+                t = k < 2 ? t + v : fmaxf(t, v);
+            }
+            o[tid * 4 + k] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -799,25 +818,46 @@ __global__ void __launch_bounds__(256) gn_bwd_apply16_kernel(const float* __rest
                                                              const float* __restrict__ stats, const float* __restrict__ coef,
                                                              const float* __restrict__ scale, __half* __restrict__ dy16, int C,
                                                              int groups, long long n_per_batch) {
+    // 8 consecutive channels per lane (16-byte y load / dy store, two 16-byte dz loads); the grid stride is a multiple
+    // of C/8 vectors, so a lane keeps its channels and their coefficients in registers
     const int b = blockIdx.y;
     const float sc = scale[0];
     const long long off = (long long)b * n_per_batch;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_per_batch; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const int g = c / (C / groups);
-        const float a = affine[(long long)b * 2 * C + c], bb = affine[(long long)b * 2 * C + C + c];
-        const float mean = stats[((long long)b * groups + g) * 2], rstd = stats[((long long)b * groups + g) * 2 + 1];
+    const long long nvec = n_per_batch / 8;
+    long long i8 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c0 = (int)(i8 % (C / 8)) * 8, gs = C / groups;
+    float a[8], bb[8], mean[8], rstd[8], k0[8], k1[8], k2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j, g = c / gs;
+        a[j] = affine[(long long)b * 2 * C + c];
+        bb[j] = affine[(long long)b * 2 * C + C + c];
+        mean[j] = stats[((long long)b * groups + g) * 2];
+        rstd[j] = stats[((long long)b * groups + g) * 2 + 1];
         const float* k = coef + ((long long)b * C + c) * 3;
-        const float yv = __half2float(y[off + i]);
-        const float du = dz[off + i] * silu_grad(fmaf(a, yv, bb));
-        dy16[off + i] = __float2half_rn((k[0] * du - k[1] - ((yv - mean) * rstd) * k[2]) * sc);
+        k0[j] = k[0];
+        k1[j] = k[1];
+        k2[j] = k[2];
+    }
+    for (; i8 < nvec; i8 += (long long)gridDim.x * 256) {
+        const long long i = off + i8 * 8;
+        const half8_t yv8 = *reinterpret_cast<const half8_t*>(y + i);
+        const float4 d0 = *reinterpret_cast<const float4*>(dz + i), d1 = *reinterpret_cast<const float4*>(dz + i + 4);
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        half8_t out;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float yv = (float)yv8[j];
+            const float du = dv[j] * silu_grad(fmaf(a[j], yv, bb[j]));
+            out[j] = (_Float16)((k0[j] * du - k1[j] - ((yv - mean[j]) * rstd[j]) * k2[j]) * sc);
+        }
+        *reinterpret_cast<half8_t*>(dy16 + i) = out;
     }
 }
 
 // Weight gradient on v_mfma_f32_32x32x16_f16: as wgrad_kernel, with K = 16 voxels per instruction.  A lane's
 // eight K slots are eight consecutive voxels (lane half h: voxels q + 8h .. q + 8h + 7) of one channel, fetched
 // as 16-bit buffer loads (masked lanes read 0 through the bounds check) and packed in registers.
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 
 struct Wg16Src {
     const __half* data;  // (B, xs, ys, zs, C) activated input, fp16
@@ -1774,7 +1814,7 @@ int sk_train_gn_silu_bwd_f16(const float* dz, const void* y16, const float* affi
                                                  scale);
     SK_CHECK_LAUNCH();
     long long n = voxels * C;
-    gn_bwd_apply16_kernel<<<dim3(sk::stream_grid(n, 256, 4), B), 256, 0, st>>>(dz, (const __half*)y16, affine, stats, coef, scale,
+    gn_bwd_apply16_kernel<<<dim3(sk::stream_grid(n / 8, 256, 4), B), 256, 0, st>>>(dz, (const __half*)y16, affine, stats, coef, scale,
                                                                                (__half*)dy16, C, groups, n);
     SK_CHECK_LAUNCH();
     return SK_OK;
