@@ -632,17 +632,46 @@ __global__ void scale_from_absmax_kernel(const unsigned* __restrict__ mx, float*
     scale[1] = ldexpf(1.0f, -e);
 }
 
+// 8 elements per lane where the length and the pointers allow (n % 8 == 0: every tensor of the network), else scalar
 __global__ void __launch_bounds__(256) cast_f32_f16_kernel(const float* __restrict__ x, __half* __restrict__ y, long long n,
-                                                           const float* __restrict__ scale) {
+                                                           const float* __restrict__ scale, int vec) {
     const float s = scale ? scale[0] : 1.0f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        y[i] = __float2half_rn(x[i] * s);
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        for (; i < n / 8; i += stride) {
+            const float4 a = *reinterpret_cast<const float4*>(x + 8 * i), c = *reinterpret_cast<const float4*>(x + 8 * i + 4);
+            half8_t o = {(_Float16)(a.x * s), (_Float16)(a.y * s), (_Float16)(a.z * s), (_Float16)(a.w * s),
+                         (_Float16)(c.x * s), (_Float16)(c.y * s), (_Float16)(c.z * s), (_Float16)(c.w * s)};
+            *reinterpret_cast<half8_t*>(y + 8 * i) = o;
+        }
+        return;
+    }
+    for (; i < n; i += stride) y[i] = __float2half_rn(x[i] * s);
 }
 
 __global__ void __launch_bounds__(256) cast_f16_f32_kernel(const __half* __restrict__ x, float* __restrict__ y, long long n,
-                                                           const float* __restrict__ scale, int accumulate) {
+                                                           const float* __restrict__ scale, int accumulate, int vec) {
     const float s = scale ? scale[1] : 1.0f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        for (; i < n / 8; i += stride) {
+            const half8_t h = *reinterpret_cast<const half8_t*>(x + 8 * i);
+            float4 a = {(float)h[0] * s, (float)h[1] * s, (float)h[2] * s, (float)h[3] * s};
+            float4 c = {(float)h[4] * s, (float)h[5] * s, (float)h[6] * s, (float)h[7] * s};
+            float4* o = reinterpret_cast<float4*>(y + 8 * i);
+            if (accumulate) {
+                const float4 p0 = o[0], p1 = o[1];
+                a = {p0.x + a.x, p0.y + a.y, p0.z + a.z, p0.w + a.w};
+                c = {p1.x + c.x, p1.y + c.y, p1.z + c.z, p1.w + c.w};
+            }
+            o[0] = a;
+            o[1] = c;
+        }
+        return;
+    }
+    for (; i < n; i += stride) {
         const float v = __half2float(x[i]) * s;
         y[i] = accumulate ? y[i] + v : v;
     }
@@ -658,14 +687,34 @@ __global__ void __launch_bounds__(256) cast_f16_f32_kernel(const __half* __restr
 __global__ void __launch_bounds__(256) gn_silu_f16_kernel(const __half* __restrict__ y16, const float* __restrict__ affine,
                                                           __half* __restrict__ z16, float* __restrict__ z32, int C,
                                                           long long n_per_batch) {
+    // 8 consecutive channels per lane; the grid stride is a multiple of C/8 vectors: coefficients stay in registers
     const int b = blockIdx.y;
     const long long off = (long long)b * n_per_batch;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_per_batch; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const float u = fmaf(affine[(long long)b * 2 * C + c], __half2float(y16[off + i]), affine[(long long)b * 2 * C + C + c]);
-        const float z = u / (1.0f + expf(-u));
-        z16[off + i] = __float2half_rn(z);
-        if (z32) z32[off + i] = z;
+    const long long nvec = n_per_batch / 8;
+    long long i8 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c0 = (int)(i8 % (C / 8)) * 8;
+    float ga[8], gb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ga[j] = affine[(long long)b * 2 * C + c0 + j];
+        gb[j] = affine[(long long)b * 2 * C + C + c0 + j];
+    }
+    for (; i8 < nvec; i8 += (long long)gridDim.x * 256) {
+        const long long i = off + 8 * i8;
+        const half8_t yv = *reinterpret_cast<const half8_t*>(y16 + i);
+        half8_t o;
+        float z[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float u = fmaf(ga[j], (float)yv[j], gb[j]);
+            z[j] = u / (1.0f + expf(-u));
+            o[j] = (_Float16)z[j];
+        }
+        *reinterpret_cast<half8_t*>(z16 + i) = o;
+        if (z32) {
+            *reinterpret_cast<float4*>(z32 + i) = make_float4(z[0], z[1], z[2], z[3]);
+            *reinterpret_cast<float4*>(z32 + i + 4) = make_float4(z[4], z[5], z[6], z[7]);
+        }
     }
 }
 
@@ -1787,7 +1836,8 @@ int sk_train_gn_silu_f16(const void* y16, const float* affine, void* z16, float*
                          void* stream) {
     SK_CHECK_ARG(y16 && affine && z16 && C > 0, "sk_train_gn_silu_f16: bad arguments");
     long long n = voxels * C;
-    gn_silu_f16_kernel<<<dim3(sk::stream_grid(n, 256, 4), B), 256, 0, (hipStream_t)stream>>>((const __half*)y16, affine,
+    SK_CHECK_ARG(C % 8 == 0 && 256 % (C / 8) == 0, "sk_train_gn_silu_f16: C=%d unsupported", C);
+    gn_silu_f16_kernel<<<dim3(sk::stream_grid(n / 8, 256, 4), B), 256, 0, (hipStream_t)stream>>>((const __half*)y16, affine,
                                                                                              (__half*)z16, z32, C, n);
     SK_CHECK_LAUNCH();
     return SK_OK;
@@ -1834,15 +1884,17 @@ int sk_train_absmax_scale(const float* x, int64_t n, float* scale, void* stream)
 
 int sk_train_cast_f32_f16(const float* x, void* y, int64_t n, const float* scale, void* stream) {
     SK_CHECK_ARG(x && y && n >= 1, "sk_train_cast_f32_f16: bad arguments");
-    cast_f32_f16_kernel<<<sk::stream_grid(n, 256, 4), 256, 0, (hipStream_t)stream>>>(x, (__half*)y, n, scale);
+    const int vec = n % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    cast_f32_f16_kernel<<<sk::stream_grid(vec ? n / 8 : n, 256, 4), 256, 0, (hipStream_t)stream>>>(x, (__half*)y, n, scale, vec);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
 
 int sk_train_cast_f16_f32(const void* x, float* y, int64_t n, const float* scale, int accumulate, void* stream) {
     SK_CHECK_ARG(x && y && n >= 1, "sk_train_cast_f16_f32: bad arguments");
-    cast_f16_f32_kernel<<<sk::stream_grid(n, 256, 4), 256, 0, (hipStream_t)stream>>>((const __half*)x, y, n, scale,
-                                                                                     accumulate ? 1 : 0);
+    const int vec = n % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    cast_f16_f32_kernel<<<sk::stream_grid(vec ? n / 8 : n, 256, 4), 256, 0, (hipStream_t)stream>>>((const __half*)x, y, n, scale,
+                                                                                     accumulate ? 1 : 0, vec);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
