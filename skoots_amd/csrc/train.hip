@@ -47,7 +47,21 @@ __global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const float* __restric
 //   dy = rstd * (gamma*du - m1 - xh*m2),  m1 = sum_{c in g} gamma*S1 / n,  m2 = sum_{c in g} gamma*S2 / n
 // ------------------------------------------------------------------------------------------
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-constexpr int kGnbVox = 8192;  // voxels per reduction block (partials per layer: 2048 at 256^3 -> the one-block finalize stays short)
+// voxels per reduction block: about 2048 blocks per sample (the one-block finalize stays short), but never fewer than
+// 512 voxels a block -- a quarter-resolution layer (262 k voxels) still gets 512 blocks (with a fixed 8192 it got 32)
+__host__ __device__ inline int gnb_vox(long long voxels) {
+    long long v = (voxels + 2047) / 2048;
+    v = (v + 511) / 512 * 512;
+    return (int)(v < 512 ? 512 : v);
+}
+
+// mixed-precision kernels: hardware exp2 / rcp (relative error ~1e-6, far below the fp16 operands they feed); the
+// fp32 parity kernels keep expf and the IEEE division
+__device__ inline float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ inline float silu_grad_fast(float u) {
+    const float s = sigmoid_fast(u);
+    return s * (1.0f + u * (1.0f - s));
+}
 
 __device__ inline float silu_grad(float u) {
     float s = sigmoid_(u);
@@ -64,8 +78,9 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restr
     const int g = c / (C / groups);
     const float a = affine[(long long)b * 2 * C + c], bb = affine[(long long)b * 2 * C + C + c];
     const float mean = stats[((long long)b * groups + g) * 2], rstd = stats[((long long)b * groups + g) * 2 + 1];
-    const long long v0 = (long long)blockIdx.x * kGnbVox;
-    long long v1 = v0 + kGnbVox;
+    const int vpb = gnb_vox(voxels);
+    const long long v0 = (long long)blockIdx.x * vpb;
+    long long v1 = v0 + vpb;
     if (v1 > voxels) v1 = voxels;
     float s1 = 0.0f, s2 = 0.0f;
     for (long long v = v0 + row; v < v1; v += rows) {
@@ -707,7 +722,7 @@ __global__ void __launch_bounds__(256) gn_silu_f16_kernel(const __half* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float u = fmaf(ga[j], (float)yv[j], gb[j]);
-            z[j] = u / (1.0f + expf(-u));
+            z[j] = u * sigmoid_fast(u);
             o[j] = (_Float16)z[j];
         }
         *reinterpret_cast<half8_t*>(z16 + i) = o;
@@ -737,8 +752,9 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce16_kernel(const float* __res
         mean[j] = stats[((long long)b * groups + g) * 2];
         rstd[j] = stats[((long long)b * groups + g) * 2 + 1];
     }
-    const long long v0 = (long long)blockIdx.x * kGnbVox;
-    long long v1 = v0 + kGnbVox;
+    const int vpb = gnb_vox(voxels);
+    const long long v0 = (long long)blockIdx.x * vpb;
+    long long v1 = v0 + vpb;
     if (v1 > voxels) v1 = voxels;
     float s1[8], s2[8], m1[8], m2[8];
 #pragma unroll
@@ -751,7 +767,7 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce16_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float yv = (float)yv8[j];
-            const float du = dv[j] * silu_grad(fmaf(a[j], yv, bb[j]));
+            const float du = dv[j] * silu_grad_fast(fmaf(a[j], yv, bb[j]));
             const float xh = (yv - mean[j]) * rstd[j];
             s1[j] += du;
             s2[j] += du * xh;
@@ -897,7 +913,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply16_kernel(const float* __rest
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float yv = (float)yv8[j];
-            const float du = dv[j] * silu_grad(fmaf(a[j], yv, bb[j]));
+            const float du = dv[j] * silu_grad_fast(fmaf(a[j], yv, bb[j]));
             out[j] = (_Float16)((k0[j] * du - k1[j] - ((yv - mean[j]) * rstd[j]) * k2[j]) * sc);
         }
         *reinterpret_cast<half8_t*>(dy16 + i) = out;
@@ -1542,7 +1558,10 @@ int sk_train_gn_silu(const float* y, const float* affine, float* z, int B, int64
     return SK_OK;
 }
 
-int sk_train_gn_bwd_num_blocks(int64_t voxels) { return (int)((voxels + kGnbVox - 1) / kGnbVox); }
+int sk_train_gn_bwd_num_blocks(int64_t voxels) {
+    const int vpb = gnb_vox(voxels);
+    return (int)((voxels + vpb - 1) / vpb);
+}
 
 int sk_train_gn_silu_bwd(const float* dz, const float* y, const float* affine, const float* stats,
                          const float* gamma, int B, int64_t voxels, int C, int groups, float* dy, float* dgamma,
