@@ -359,6 +359,14 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
 /* coarse (B, cx, cy, cz, C) = 2x2x2 block sums of fine (B, 2cx, 2cy, 2cz, C). */
 int sk_train_sumpool2(const float* fine, float* coarse, int B, int cx, int cy, int cz, int C,
                       void* stream);
+/* sk_train_gn_silu_bwd_f16h: sk_train_gn_silu_bwd_f16 with the incoming gradient itself a scaled fp16 tensor (the
+ *   output of the consumer's fast data-gradient conv): true dz = dz16 * dz_scale[1].  No fp32 copy in between.
+ * sk_train_sumpool2_f16: sk_train_sumpool2 from a scaled fp16 fine tensor: coarse = scale[1] * sum of the 8 children. */
+int sk_train_gn_silu_bwd_f16h(const void* dz16, const float* dz_scale, const void* y16, const float* affine,
+                              const float* stats, const float* gamma, int B, int64_t voxels, int C, int groups,
+                              void* dy16, float* scale, float* dgamma, float* dbeta, float* workspace, void* stream);
+int sk_train_sumpool2_f16(const void* fine16, const float* scale, float* coarse, int B, int cx, int cy, int cz, int C,
+                          void* stream);
 
 /* One AdamW update (torch.optim.AdamW semantics; engine.py:281-285, config.py:96-101) over a
  * flat parameter buffer; step counts from 1. */

@@ -100,6 +100,8 @@ _SIGS = {
     "sk_train_cast_f16_f32": (i32, [vp, vp, i64, vp, i32, vp]),
     "sk_train_conv_wgrad_f16": (i32, [C.POINTER(ConvSrc), i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "sk_train_sumpool2": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "sk_train_gn_silu_bwd_f16h": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "sk_train_sumpool2_f16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "sk_bake_skeleton": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, fp, vp, vp, vp]),
     "sk_average_baked_skeletons": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "sk_mask_iou_workspace_bytes": (sz, [i32, i32]),

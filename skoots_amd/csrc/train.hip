@@ -733,10 +733,29 @@ __global__ void __launch_bounds__(256) gn_silu_f16_kernel(const __half* __restri
     }
 }
 
-__global__ void __launch_bounds__(256) gn_bwd_reduce16_kernel(const float* __restrict__ dz, const __half* __restrict__ y,
+// DZH: the incoming gradient is itself a scaled fp16 tensor (the data gradient of the consumer's fast conv, scale
+// dz_scale[0]): read 2 bytes and multiply by dz_scale[1] instead of going through an fp32 copy
+template <bool DZH>
+__device__ inline void load_dz8(const void* __restrict__ dz, long long i, float s, float (&dv)[8]) {
+    if constexpr (DZH) {
+        const half8_t h = *reinterpret_cast<const half8_t*>(reinterpret_cast<const __half*>(dz) + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[j] = (float)h[j] * s;
+    } else {
+        const float* p = reinterpret_cast<const float*>(dz) + i;
+        const float4 d0 = *reinterpret_cast<const float4*>(p), d1 = *reinterpret_cast<const float4*>(p + 4);
+        dv[0] = d0.x; dv[1] = d0.y; dv[2] = d0.z; dv[3] = d0.w;
+        dv[4] = d1.x; dv[5] = d1.y; dv[6] = d1.z; dv[7] = d1.w;
+    }
+}
+
+template <bool DZH>
+__global__ void __launch_bounds__(256) gn_bwd_reduce16_kernel(const void* __restrict__ dz, const float* __restrict__ dz_scale,
+                                                              const __half* __restrict__ y,
                                                               const float* __restrict__ affine,
                                                               const float* __restrict__ stats, int C, int groups,
                                                               long long voxels, int nblk, float* __restrict__ partial) {
+    const float dzs = DZH ? dz_scale[1] : 1.0f;
     // a lane owns 8 consecutive channels of a voxel: one 16-byte load of y, two of dz per voxel (the scalar version --
     // one channel per lane, constants re-read per element -- ran at half of the HBM rate)
     __shared__ float red[256 * 9];
@@ -762,8 +781,8 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce16_kernel(const float* __res
     for (long long v = v0 + row; v < v1; v += rows) {
         const long long i = ((long long)b * voxels + v) * C + c0;
         const half8_t yv8 = *reinterpret_cast<const half8_t*>(y + i);
-        const float4 d0 = *reinterpret_cast<const float4*>(dz + i), d1 = *reinterpret_cast<const float4*>(dz + i + 4);
-        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        float dv[8];
+        load_dz8<DZH>(dz, i, dzs, dv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float yv = (float)yv8[j];
@@ -878,7 +897,9 @@ __global__ void __launch_bounds__(1024) gn_bwd_finalize16_kernel(const float* __
     }
 }
 
-__global__ void __launch_bounds__(256) gn_bwd_apply16_kernel(const float* __restrict__ dz, const __half* __restrict__ y,
+template <bool DZH>
+__global__ void __launch_bounds__(256) gn_bwd_apply16_kernel(const void* __restrict__ dz, const float* __restrict__ dz_scale,
+                                                             const __half* __restrict__ y,
                                                              const float* __restrict__ affine,
                                                              const float* __restrict__ stats, const float* __restrict__ coef,
                                                              const float* __restrict__ scale, __half* __restrict__ dy16, int C,
@@ -887,6 +908,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply16_kernel(const float* __rest
     // of C/8 vectors, so a lane keeps its channels and their coefficients in registers
     const int b = blockIdx.y;
     const float sc = scale[0];
+    const float dzs = DZH ? dz_scale[1] : 1.0f;
     const long long off = (long long)b * n_per_batch;
     const long long nvec = n_per_batch / 8;
     long long i8 = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -907,8 +929,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply16_kernel(const float* __rest
     for (; i8 < nvec; i8 += (long long)gridDim.x * 256) {
         const long long i = off + i8 * 8;
         const half8_t yv8 = *reinterpret_cast<const half8_t*>(y + i);
-        const float4 d0 = *reinterpret_cast<const float4*>(dz + i), d1 = *reinterpret_cast<const float4*>(dz + i + 4);
-        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        float dv[8];
+        load_dz8<DZH>(dz, i, dzs, dv);
         half8_t out;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1509,6 +1531,37 @@ __global__ void __launch_bounds__(256) sumpool2_kernel(const float* __restrict__
     }
 }
 
+// the same from a scaled fp16 fine tensor (the fast data-gradient conv's output), 8 channels per lane: no fp32 copy of
+// the fine gradient is ever written
+__global__ void __launch_bounds__(256) sumpool2_f16_kernel(const __half* __restrict__ fine, const float* __restrict__ scale,
+                                                           float* __restrict__ coarse, int B, int cx, int cy, int cz, int C) {
+    const float s = scale[1];
+    const int nq = C / 8;
+    const long long n = (long long)B * cx * cy * cz * nq;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int q = (int)(i % nq);
+        long long t = i / nq;
+        const int z = (int)(t % cz);
+        t /= cz;
+        const int y = (int)(t % cy);
+        t /= cy;
+        const int x = (int)(t % cx);
+        const int b = (int)(t / cx);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const long long fi = (((long long)b * 2 * cx + 2 * x + (d >> 2)) * 2 * cy + 2 * y + ((d >> 1) & 1)) * 2 * cz +
+                                 2 * z + (d & 1);
+            const half8_t h = *reinterpret_cast<const half8_t*>(fine + fi * C + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)h[j];
+        }
+        float* o = coarse + i * 8;
+        *reinterpret_cast<float4*>(o) = make_float4(acc[0] * s, acc[1] * s, acc[2] * s, acc[3] * s);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4] * s, acc[5] * s, acc[6] * s, acc[7] * s);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // AdamW (torch.optim.AdamW semantics: decoupled decay, bias-corrected moments)
 // ------------------------------------------------------------------------------------------
@@ -1866,9 +1919,9 @@ int64_t sk_train_gn_bwd_f16_workspace_floats(int B, int64_t voxels, int C) {
     return (int64_t)B * sk_train_gn_bwd_num_blocks(voxels) * C * 4 + (int64_t)B * C * 3;
 }
 
-int sk_train_gn_silu_bwd_f16(const float* dz, const void* y16, const float* affine, const float* stats, const float* gamma,
-                             int B, int64_t voxels, int C, int groups, void* dy16, float* scale, float* dgamma, float* dbeta,
-                             float* workspace, void* stream) {
+static int gn_silu_bwd_f16_impl(const void* dz, const float* dz_scale, const void* y16, const float* affine,
+                                const float* stats, const float* gamma, int B, int64_t voxels, int C, int groups,
+                                void* dy16, float* scale, float* dgamma, float* dbeta, float* workspace, void* stream) {
     SK_CHECK_ARG(dz && y16 && affine && stats && gamma && dy16 && scale && dgamma && dbeta && workspace,
                  "sk_train_gn_silu_bwd_f16: NULL pointer");
     SK_CHECK_ARG((C == 32 || C == 64 || C == 128) && groups > 0 && groups <= 16 && C % groups == 0,
@@ -1877,16 +1930,41 @@ int sk_train_gn_silu_bwd_f16(const float* dz, const void* y16, const float* affi
     float* partial = workspace;                              // (B, nblk, C, 4)
     float* coef = workspace + (long long)B * nblk * C * 4;   // (B, C, 3)
     hipStream_t st = (hipStream_t)stream;
-    gn_bwd_reduce16_kernel<<<dim3(nblk, B), 256, 0, st>>>(dz, (const __half*)y16, affine, stats, C, groups, voxels, nblk, partial);
+    if (dz_scale)
+        gn_bwd_reduce16_kernel<true><<<dim3(nblk, B), 256, 0, st>>>(dz, dz_scale, (const __half*)y16, affine, stats, C, groups,
+                                                                    voxels, nblk, partial);
+    else
+        gn_bwd_reduce16_kernel<false><<<dim3(nblk, B), 256, 0, st>>>(dz, nullptr, (const __half*)y16, affine, stats, C, groups,
+                                                                     voxels, nblk, partial);
     SK_CHECK_LAUNCH();
     gn_bwd_finalize16_kernel<<<1, 1024, 0, st>>>(partial, B, nblk, C, groups, (double)voxels, gamma, stats, coef, dgamma, dbeta,
                                                  scale);
     SK_CHECK_LAUNCH();
     long long n = voxels * C;
-    gn_bwd_apply16_kernel<<<dim3(sk::stream_grid(n / 8, 256, 4), B), 256, 0, st>>>(dz, (const __half*)y16, affine, stats, coef, scale,
-                                                                               (__half*)dy16, C, groups, n);
+    const dim3 grid(sk::stream_grid(n / 8, 256, 4), B);
+    if (dz_scale)
+        gn_bwd_apply16_kernel<true><<<grid, 256, 0, st>>>(dz, dz_scale, (const __half*)y16, affine, stats, coef, scale,
+                                                          (__half*)dy16, C, groups, n);
+    else
+        gn_bwd_apply16_kernel<false><<<grid, 256, 0, st>>>(dz, nullptr, (const __half*)y16, affine, stats, coef, scale,
+                                                           (__half*)dy16, C, groups, n);
     SK_CHECK_LAUNCH();
     return SK_OK;
+}
+
+int sk_train_gn_silu_bwd_f16(const float* dz, const void* y16, const float* affine, const float* stats, const float* gamma,
+                             int B, int64_t voxels, int C, int groups, void* dy16, float* scale, float* dgamma, float* dbeta,
+                             float* workspace, void* stream) {
+    return gn_silu_bwd_f16_impl(dz, nullptr, y16, affine, stats, gamma, B, voxels, C, groups, dy16, scale, dgamma, dbeta,
+                                workspace, stream);
+}
+
+int sk_train_gn_silu_bwd_f16h(const void* dz16, const float* dz_scale, const void* y16, const float* affine,
+                              const float* stats, const float* gamma, int B, int64_t voxels, int C, int groups, void* dy16,
+                              float* scale, float* dgamma, float* dbeta, float* workspace, void* stream) {
+    SK_CHECK_ARG(dz_scale, "sk_train_gn_silu_bwd_f16h: dz_scale is NULL");
+    return gn_silu_bwd_f16_impl(dz16, dz_scale, y16, affine, stats, gamma, B, voxels, C, groups, dy16, scale, dgamma, dbeta,
+                                workspace, stream);
 }
 
 int sk_train_absmax_scale(const float* x, int64_t n, float* scale, void* stream) {
@@ -1922,6 +2000,17 @@ int sk_train_sumpool2(const float* fine, float* coarse, int B, int cx, int cy, i
     SK_CHECK_ARG(fine && coarse && B >= 1 && cx >= 1 && cy >= 1 && cz >= 1 && C >= 1, "sk_train_sumpool2: bad arguments");
     long long n = (long long)B * cx * cy * cz * C;
     sumpool2_kernel<<<sk::stream_grid(n, 256, 2), 256, 0, (hipStream_t)stream>>>(fine, coarse, B, cx, cy, cz, C);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_train_sumpool2_f16(const void* fine16, const float* scale, float* coarse, int B, int cx, int cy, int cz, int C,
+                          void* stream) {
+    SK_CHECK_ARG(fine16 && scale && coarse && B >= 1 && cx >= 1 && cy >= 1 && cz >= 1 && C >= 8 && C % 8 == 0,
+                 "sk_train_sumpool2_f16: bad arguments");
+    long long n = (long long)B * cx * cy * cz * (C / 8);
+    sumpool2_f16_kernel<<<sk::stream_grid(n, 256, 2), 256, 0, (hipStream_t)stream>>>((const __half*)fine16, scale, coarse, B, cx, cy,
+                                                                                     cz, C);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }

@@ -19,6 +19,8 @@ and logging of the reference's loop are out of scope.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -271,23 +273,41 @@ class TrainUNet:
         if not self._tape:
             raise RuntimeError("backward() needs a preceding forward()")
         st = _ffi.stream_ptr(self.device)
-        grads: Dict[int, Tensor] = {self._tape[-1][5].data_ptr(): dlogits}
+        grads: Dict[int, object] = {self._tape[-1][5].data_ptr(): dlogits}
+        # a tensor read by ONE fast conv and produced by a fast block receives its gradient as the scaled fp16 output of
+        # that conv's data-gradient kernel and hands it to the GroupNorm backward as it is: (dx16, scale), no fp32 copy
+        n_readers: Dict[int, int] = {}
+        for _, srcs_, *_rest in self._tape:
+            for t_, _up in srcs_:
+                n_readers[t_.data_ptr()] = n_readers.get(t_.data_ptr(), 0) + 1
+        fast_out = {e[5].data_ptr() for e in self._tape if e[2].dtype == torch.float16}
         for layer, srcs, y, affine, stats, out in reversed(self._tape):
             dz = grads.pop(out.data_ptr())
             B, ox, oy, oz, cout = y.shape
             vox = ox * oy * oz
             fast = y.dtype == torch.float16   # recorded by _block_mixed
             ws = None
+            dz_scale = None
+            if isinstance(dz, tuple):
+                dz, dz_scale = dz
+                assert fast
             if fast:
                 # GroupNorm + SiLU backward straight to the scaled fp16 output gradient (no fp32 dy, no max / cast passes)
                 ws = self._workspace(max(_ffi.lib.sk_train_gn_bwd_f16_workspace_floats(B, vox, cout),
                                          _ffi.lib.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, cout, layer.cin, layer.ksize)))
                 scale = torch.empty(3, dtype=torch.float32, device=self.device)
                 dy16 = torch.empty(y.shape, dtype=torch.float16, device=self.device)
-                _ffi.check(_ffi.lib.sk_train_gn_silu_bwd_f16(_ffi.ptr(dz), _ffi.ptr(y), _ffi.ptr(affine), _ffi.ptr(stats),
-                                                             _ffi.ptr(layer.gamma), B, vox, cout, GN_GROUPS, _ffi.ptr(dy16),
-                                                             _ffi.ptr(scale), _ffi.ptr(layer.g_gamma), _ffi.ptr(layer.g_beta),
-                                                             _ffi.ptr(ws), st))
+                if dz_scale is None:
+                    _ffi.check(_ffi.lib.sk_train_gn_silu_bwd_f16(_ffi.ptr(dz), _ffi.ptr(y), _ffi.ptr(affine), _ffi.ptr(stats),
+                                                                 _ffi.ptr(layer.gamma), B, vox, cout, GN_GROUPS,
+                                                                 _ffi.ptr(dy16), _ffi.ptr(scale), _ffi.ptr(layer.g_gamma),
+                                                                 _ffi.ptr(layer.g_beta), _ffi.ptr(ws), st))
+                else:
+                    _ffi.check(_ffi.lib.sk_train_gn_silu_bwd_f16h(_ffi.ptr(dz), _ffi.ptr(dz_scale), _ffi.ptr(y),
+                                                                  _ffi.ptr(affine), _ffi.ptr(stats), _ffi.ptr(layer.gamma), B,
+                                                                  vox, cout, GN_GROUPS, _ffi.ptr(dy16), _ffi.ptr(scale),
+                                                                  _ffi.ptr(layer.g_gamma), _ffi.ptr(layer.g_beta),
+                                                                  _ffi.ptr(ws), st))
                 dy = None
                 srcs16 = [(self._h(t), up) for t, up in srcs]
                 _ffi.check(_ffi.lib.sk_train_conv_wgrad_f16(self._srcs(srcs16), len(srcs16), _ffi.ptr(dy16), _ffi.ptr(scale), B,
@@ -341,12 +361,11 @@ class TrainUNet:
                     if up:
                         if key in grads:
                             raise RuntimeError("an upsampled tensor has one consumer in this graph")
-                        fine = torch.empty((B, ox, oy, oz, c), dtype=torch.float32, device=self.device)
-                        _ffi.check(_ffi.lib.sk_train_cast_f16_f32(_ffi.ptr(dx16), _ffi.ptr(fine), fine.numel(), _ffi.ptr(scale),
-                                                                  0, st))
                         grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
-                        _ffi.check(_ffi.lib.sk_train_sumpool2(_ffi.ptr(fine), _ffi.ptr(grads[key]), B, ox // 2, oy // 2,
-                                                              oz // 2, c, st))
+                        _ffi.check(_ffi.lib.sk_train_sumpool2_f16(_ffi.ptr(dx16), _ffi.ptr(scale), _ffi.ptr(grads[key]), B,
+                                                                  ox // 2, oy // 2, oz // 2, c, st))
+                    elif n_readers.get(key, 0) == 1 and key in fast_out and os.environ.get("SK_TRAIN_F32_GRADS") is None:
+                        grads[key] = (dx16, scale)
                     else:
                         have = key in grads
                         if not have:

@@ -363,6 +363,28 @@ def test_training_step_is_deterministic(precision):
     assert torch.equal(grads[0], grads[1])
 
 
+def test_fp16_gradient_handoff_equals_the_fp32_copies(monkeypatch):
+    """Mixed mode hands a fast conv's scaled fp16 data gradient straight to the producer's GroupNorm backward (and pools
+    an upsampled one without an fp32 fine tensor).  The values are the same numbers as with the fp32 copies in between
+    (SK_TRAIN_F32_GRADS=1): the gradients agree to fp32 summation-order noise."""
+    from skoots_amd.train import TrainStep, TrainUNet
+    from skoots_amd.unet import random_state_dict
+    model = TrainUNet(random_state_dict(), DEV, precision="mixed")
+    step = TrainStep(model)
+    images, masks, skele, baked = (t.to(DEV) for t in _synthetic_batch(1, 32, 20, 16, 11))
+    grads = []
+    for copies in (False, True):
+        if copies:
+            monkeypatch.setenv("SK_TRAIN_F32_GRADS", "1")
+        logits = model.forward(images)
+        _, dl = step.fused_loss(logits, masks, skele, baked, [20.0, 20.0, 20.0])
+        model.backward(dl)
+        grads.append(model.flat_grad.clone())
+    scale = grads[1].abs().max().item()
+    assert (grads[0] - grads[1]).abs().max().item() <= 1e-5 * scale
+    assert not torch.equal(grads[0], torch.zeros_like(grads[0]))
+
+
 def test_trained_weights_feed_the_eval_path(tmp_path):
     """The trainer's checkpoint (cfg, model_state_dict, optimizer_state_dict) loads with the safe loader and
     drives the inference runner; the optimizer state restores into a fresh TrainStep."""
