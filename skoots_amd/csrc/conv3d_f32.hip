@@ -354,6 +354,44 @@ __global__ void __launch_bounds__(256) gn_silu_f32_kernel(float* __restrict__ x,
     }
 }
 
+// Data gradient of a pointwise conv with FEW output channels (the heads: K = 5 logits -> 32 features): HBM-bound
+// (20 B in, 128 B out per voxel), so no matrix instruction -- a lane owns 4 consecutive input channels of a voxel
+// (K x 4 weights in registers), 16-byte loads of dy are shared by the voxel's lanes, one 16-byte store per lane.
+template <int K>
+__global__ void __launch_bounds__(256) pointwise_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                              float* __restrict__ dx, long long nvox, int cin_total,
+                                                              int c_lo, int c_n, int accumulate) {
+    const int nq = c_n / 4;                       // lanes per voxel
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int q = (int)(i % nq);                  // fixed per lane: 256 and the grid stride are multiples of nq
+    float wk[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wk[k][j] = w[(long long)k * cin_total + c_lo + 4 * q + j];  // (K, cin, 1, 1, 1)
+    for (; i < nvox * nq; i += stride) {
+        const long long v = i / nq;
+        float g[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) g[k] = dy[v * K + k];
+        float4 r = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            r.x = fmaf(g[k], wk[k][0], r.x);
+            r.y = fmaf(g[k], wk[k][1], r.y);
+            r.z = fmaf(g[k], wk[k][2], r.z);
+            r.w = fmaf(g[k], wk[k][3], r.w);
+        }
+        float4* o = reinterpret_cast<float4*>(dx + v * c_n + 4 * q);
+        if (accumulate) {
+            const float4 p = *o;
+            r = {p.x + r.x, p.y + r.y, p.z + r.z, p.w + r.w};
+        }
+        *o = r;
+    }
+}
+
 }  // namespace
 
 // every source a multiple of 32 channels -> LDS-staged kernel, else the plain gather kernel
@@ -442,6 +480,14 @@ int sk_train_conv_dgrad(const float* dy, const float* weight, float* dx, int B, 
         a.accumulate = accumulate ? 1 : 0;
         dim3 grid((unsigned)(a.nblk * B * ((cin_total + 31) / 32)), 8);
         conv_t2_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+        SK_CHECK_LAUNCH();
+        return SK_OK;
+    }
+    if (ksize == 1 && cout == 5 && cin_n % 4 == 0 && 256 % (cin_n / 4) == 0 && ((uintptr_t)dx % 16 == 0)) {
+        const long long nvox = (long long)B * ox * oy * oz;
+        const unsigned grid = sk::stream_grid(nvox * (cin_n / 4), 256, 4);
+        pointwise_dgrad_kernel<5><<<grid, 256, 0, (hipStream_t)stream>>>(dy, weight, dx, nvox, cin_total, cin_lo, cin_n,
+                                                                        accumulate ? 1 : 0);
         SK_CHECK_LAUNCH();
         return SK_OK;
     }
