@@ -47,12 +47,18 @@ __global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const float* __restric
 //   dy = rstd * (gamma*du - m1 - xh*m2),  m1 = sum_{c in g} gamma*S1 / n,  m2 = sum_{c in g} gamma*S2 / n
 // ------------------------------------------------------------------------------------------
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-// voxels per reduction block: about 2048 blocks per sample (the one-block finalize stays short), but never fewer than
-// 512 voxels a block -- a quarter-resolution layer (262 k voxels) still gets 512 blocks (with a fixed 8192 it got 32)
-__host__ __device__ inline int gnb_vox(long long voxels) {
-    long long v = (voxels + 2047) / 2048;
+// voxels per reduction block: about 65536 / C blocks per sample (2048 for 32 channels; the one-block finalize reads
+// blocks x 4C floats, so wide layers get fewer), but never fewer than 512 voxels a block -- a quarter-resolution layer
+// (262 k voxels, 128 channels) still gets 512 blocks (with a fixed 8192 voxels it got 32)
+__host__ __device__ inline int gnb_vox(long long voxels, int C) {
+    const long long target = 65536 / (C < 32 ? 32 : C);
+    long long v = (voxels + target - 1) / target;
     v = (v + 511) / 512 * 512;
     return (int)(v < 512 ? 512 : v);
+}
+__host__ __device__ inline int gnb_blocks(long long voxels, int C) {
+    const int vpb = gnb_vox(voxels, C);
+    return (int)((voxels + vpb - 1) / vpb);
 }
 
 // mixed-precision kernels: hardware exp2 / rcp (relative error ~1e-6, far below the fp16 operands they feed); the
@@ -78,7 +84,7 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restr
     const int g = c / (C / groups);
     const float a = affine[(long long)b * 2 * C + c], bb = affine[(long long)b * 2 * C + C + c];
     const float mean = stats[((long long)b * groups + g) * 2], rstd = stats[((long long)b * groups + g) * 2 + 1];
-    const int vpb = gnb_vox(voxels);
+    const int vpb = gnb_vox(voxels, C);
     const long long v0 = (long long)blockIdx.x * vpb;
     long long v1 = v0 + vpb;
     if (v1 > voxels) v1 = voxels;
@@ -771,7 +777,7 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce16_kernel(const void* __rest
         mean[j] = stats[((long long)b * groups + g) * 2];
         rstd[j] = stats[((long long)b * groups + g) * 2 + 1];
     }
-    const int vpb = gnb_vox(voxels);
+    const int vpb = gnb_vox(voxels, C);
     const long long v0 = (long long)blockIdx.x * vpb;
     long long v1 = v0 + vpb;
     if (v1 > voxels) v1 = voxels;
@@ -1611,8 +1617,8 @@ int sk_train_gn_silu(const float* y, const float* affine, float* z, int B, int64
     return SK_OK;
 }
 
-int sk_train_gn_bwd_num_blocks(int64_t voxels) {
-    const int vpb = gnb_vox(voxels);
+int sk_train_gn_bwd_num_blocks(int64_t voxels) {  // upper bound over the channel counts (workspace sizing)
+    const int vpb = gnb_vox(voxels, 32);
     return (int)((voxels + vpb - 1) / vpb);
 }
 
@@ -1623,7 +1629,7 @@ int sk_train_gn_silu_bwd(const float* dz, const float* y, const float* affine, c
                  "sk_train_gn_silu_bwd: NULL pointer");
     SK_CHECK_ARG((C == 32 || C == 64 || C == 128) && groups > 0 && groups <= 16 && C % groups == 0,
                  "sk_train_gn_silu_bwd: C=%d groups=%d unsupported", C, groups);
-    const int nblk = sk_train_gn_bwd_num_blocks(voxels);
+    const int nblk = gnb_blocks(voxels, C);                  // <= sk_train_gn_bwd_num_blocks: the workspace fits
     float* partial = workspace;                              // (B, nblk, C, 2)
     float* coef = workspace + (long long)B * nblk * C * 2;   // (B, C, 3)
     gn_bwd_reduce_kernel<<<dim3(nblk, B), 256, 0, (hipStream_t)stream>>>(dz, y, affine, stats, C, groups, voxels, nblk,
@@ -1926,7 +1932,7 @@ static int gn_silu_bwd_f16_impl(const void* dz, const float* dz_scale, const voi
                  "sk_train_gn_silu_bwd_f16: NULL pointer");
     SK_CHECK_ARG((C == 32 || C == 64 || C == 128) && groups > 0 && groups <= 16 && C % groups == 0,
                  "sk_train_gn_silu_bwd_f16: C=%d groups=%d unsupported", C, groups);
-    const int nblk = sk_train_gn_bwd_num_blocks(voxels);
+    const int nblk = gnb_blocks(voxels, C);                  // <= sk_train_gn_bwd_num_blocks: the workspace fits
     float* partial = workspace;                              // (B, nblk, C, 4)
     float* coef = workspace + (long long)B * nblk * C * 4;   // (B, C, 3)
     hipStream_t st = (hipStream_t)stream;
