@@ -221,8 +221,10 @@ int sk_conv3d_stem_num_blocks(int X, int Y, int Z);
 size_t sk_conv3d_stem_workspace_bytes(int B, int Xt, int Yt, int Zt);
 
 /* GroupNorm statistics -> per-channel affine, reduced in a fixed order (deterministic):
- * gn_partial (B, nblocks, C/4, 2); affine (B, 2, C): a = gamma*rstd, b = beta - mean*a. */
-int sk_groupnorm_finalize(const float* gn_partial, int B, int nblocks, int groups, int C,
+ * gn_partial (B, nblocks, C/4, 2); affine (B, 2, C): a = gamma*rstd, b = beta - mean*a.
+ * With more than 4096 rows per sample gn_partial is first compacted IN PLACE (a second kernel level instead of
+ * one block reading every row); it is consumed by this call either way. */
+int sk_groupnorm_finalize(float* gn_partial, int B, int nblocks, int groups, int C,
                           int64_t voxels, const float* gamma, const float* beta, float eps,
                           float* affine, void* stream);
 
@@ -255,7 +257,7 @@ int sk_groupnorm_silu_f32(float* x, const float* affine, int B, int64_t voxels, 
  * ------------------------------------------------------------------------ */
 
 /* sk_groupnorm_finalize that also keeps stats (B, groups, 2) = (mean, rstd) for the backward. */
-int sk_groupnorm_finalize_stats(const float* gn_partial, int B, int nblocks, int groups, int C,
+int sk_groupnorm_finalize_stats(float* gn_partial, int B, int nblocks, int groups, int C,
                                 int64_t voxels, const float* gamma, const float* beta, float eps,
                                 float* affine, float* stats, void* stream);
 

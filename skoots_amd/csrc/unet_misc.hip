@@ -207,7 +207,27 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
 // partial: (B, nblk, C/4, 2) fp32 -> affine (B, 2, C): a = gamma*rstd, b = beta - mean*a
 constexpr int kFinThreads = 1024;
 
-__global__ void __launch_bounds__(kFinThreads) gn_finalize_kernel(const float* __restrict__ partial, int nblk,
+// Many rows (a 256^3 training crop leaves 131 072 per sample): one block per sample would read them all.  First
+// pass: block g sums rows [g*S, (g+1)*S) in double and stores the result (as float) in ITS OWN first row g*S -- no
+// other block reads that row -- then the finalize below walks the rows with stride S.  Fixed order: deterministic.
+__global__ void __launch_bounds__(256) gn_prereduce_kernel(float* __restrict__ partial, int nblk, int nv, int S) {
+    __shared__ double accv[256];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int r0 = blockIdx.x * S, r1 = min(nblk, r0 + S);
+    const int val = tid % nv, sl = tid / nv, nsl = 256 / nv;
+    float* base = partial + (long long)b * nblk * nv;
+    double s = 0.0;
+    for (int k = r0 + sl; k < r1; k += nsl) s += (double)base[(long long)k * nv + val];
+    accv[tid] = s;
+    __syncthreads();
+    if (tid < nv) {
+        double a = 0.0;
+        for (int k = 0; k < nsl; ++k) a += accv[k * nv + tid];
+        base[(long long)r0 * nv + tid] = (float)a;
+    }
+}
+
+__global__ void __launch_bounds__(kFinThreads) gn_finalize_kernel(const float* __restrict__ partial, int nblk, int stride,
                                                                   int groups, int C, double count,
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float eps,
@@ -223,7 +243,8 @@ __global__ void __launch_bounds__(kFinThreads) gn_finalize_kernel(const float* _
     const int val = tid % nv, sl = tid / nv, nsl = kFinThreads / nv;
     double s = 0.0;
     const float* base = partial + (long long)b * nblk * nv + val;
-    for (int k = sl; k < nblk; k += nsl) s += (double)base[(long long)k * nv];
+    const int nrows = (nblk + stride - 1) / stride;
+    for (int k = sl; k < nrows; k += nsl) s += (double)base[(long long)k * stride * nv];
     accv[tid] = s;
     __syncthreads();
     if (tid < nv) {
@@ -474,25 +495,31 @@ int sk_conv3d_stem_apply(int B, int Xt, int Yt, int Zt, const float* weight, con
     return SK_OK;
 }
 
-static int groupnorm_finalize_impl(const float* gn_partial, int B, int nblocks, int groups, int C,
+static int groupnorm_finalize_impl(float* gn_partial, int B, int nblocks, int groups, int C,
                           int64_t voxels, const float* gamma, const float* beta, float eps,
                           float* affine, float* stats, void* stream) {
     SK_CHECK_ARG(gn_partial && gamma && beta && affine, "sk_groupnorm_finalize: NULL pointer");
     SK_CHECK_ARG(C % 4 == 0 && C <= 128 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0,
                  "sk_groupnorm_finalize: C=%d groups=%d unsupported", C, groups);
     SK_CHECK_ARG(kFinThreads % (C / 2) == 0, "sk_groupnorm_finalize: C/2 must divide %d", kFinThreads);
-    gn_finalize_kernel<<<B, kFinThreads, 0, (hipStream_t)stream>>>(gn_partial, nblocks, groups, C, (double)voxels,
+    int stride = 1;
+    if (nblocks > 4096) {  // two passes (see gn_prereduce_kernel); compacts gn_partial in place
+        stride = (nblocks + 255) / 256;
+        gn_prereduce_kernel<<<dim3((nblocks + stride - 1) / stride, B), 256, 0, (hipStream_t)stream>>>(
+            gn_partial, nblocks, C / 2, stride);
+    }
+    gn_finalize_kernel<<<B, kFinThreads, 0, (hipStream_t)stream>>>(gn_partial, nblocks, stride, groups, C, (double)voxels,
                                                             gamma, beta, eps, affine, stats);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
 
-int sk_groupnorm_finalize(const float* gn_partial, int B, int nblocks, int groups, int C, int64_t voxels,
+int sk_groupnorm_finalize(float* gn_partial, int B, int nblocks, int groups, int C, int64_t voxels,
                           const float* gamma, const float* beta, float eps, float* affine, void* stream) {
     return groupnorm_finalize_impl(gn_partial, B, nblocks, groups, C, voxels, gamma, beta, eps, affine, nullptr, stream);
 }
 
-int sk_groupnorm_finalize_stats(const float* gn_partial, int B, int nblocks, int groups, int C, int64_t voxels,
+int sk_groupnorm_finalize_stats(float* gn_partial, int B, int nblocks, int groups, int C, int64_t voxels,
                                 const float* gamma, const float* beta, float eps, float* affine, float* stats,
                                 void* stream) {
     SK_CHECK_ARG(stats, "sk_groupnorm_finalize_stats: NULL stats");

@@ -95,6 +95,36 @@ def test_conv_exact_integer_layout(U):
     assert torch.equal(_cf(got.cpu().float()), want)  # all values are small integers: exact in fp16
 
 
+@pytest.mark.parametrize("nblk,C", [(423, 32), (5000, 32), (131072, 32), (9000, 128)])
+def test_groupnorm_finalize_many_rows(U, nblk, C):
+    """More than 4096 partial rows per sample (256^3 training crops) take the two-level reduction: same statistics as
+    a double-precision sum of the rows."""
+    from skoots_amd import _ffi
+    gen = torch.Generator().manual_seed(nblk + C)
+    B, groups, vox = 2, 8, 1000
+    part = torch.rand((B, nblk, C // 4, 2), generator=gen) * 3.0
+    part[..., 1] += 5.0  # sum of squares > (sum)^2 / n
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+    n = float(nblk * vox) * (C // groups)
+    tot = part.double().sum(dim=1)                                    # (B, C/4, 2)
+    gq = C // groups // 4                                              # quads per group
+    gsum = tot.reshape(B, groups, gq, 2).sum(dim=2)                    # (B, groups, 2)
+    mean = gsum[..., 0] / n
+    var = (gsum[..., 1] / n - mean * mean).clamp_min(0)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    a_want = gamma.double().view(1, C) * rstd.repeat_interleave(C // groups, dim=1)
+    b_want = beta.double().view(1, C) - mean.repeat_interleave(C // groups, dim=1) * a_want
+    dev = torch.device(DEV)
+    pd = part.to(dev).contiguous()
+    affine = torch.empty((B, 2, C), dtype=torch.float32, device=dev)
+    gd, bd = gamma.to(dev), beta.to(dev)   # keep the device copies alive across the call
+    _ffi.check(_ffi.lib.sk_groupnorm_finalize(_ffi.ptr(pd), B, nblk, groups, C, nblk * vox, _ffi.ptr(gd),
+                                              _ffi.ptr(bd), 1e-5, _ffi.ptr(affine), _ffi.stream_ptr(dev)))
+    got = affine.cpu().double()
+    assert torch.allclose(got[:, 0], a_want, rtol=2e-5, atol=0)
+    assert torch.allclose(got[:, 1], b_want, rtol=2e-5, atol=2e-5)
+
+
 def test_groupnorm_silu_vs_torch(U):
     gen = torch.Generator().manual_seed(5)
     for C_, sp in ((32, (8, 12, 20)), (64, (6, 10, 10)), (128, (5, 9, 5))):
