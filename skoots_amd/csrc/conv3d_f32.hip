@@ -354,6 +354,108 @@ __global__ void __launch_bounds__(256) gn_silu_f32_kernel(float* __restrict__ x,
     }
 }
 
+// First conv of the network in fp32 (Cin = 1, 27 taps, Cout = 32; the training forward and the fp32 parity mode).  The
+// generic kernel above spends one scalar load pair and one half-used MFMA per tap (2.7 ms at 256^3).  Here a block
+// stages the three x planes' rows [y0 - 1, y0 + rows] in LDS (zero frame included), a wave tile = 32 voxels x 32 couts
+// takes 14 v_mfma_f32_32x32x2f32 (two taps per instruction: lane half h holds tap 2m + h), the B values are ds_read_b32
+// at per-lane precomputed tap offsets, the weights sit in 14 registers.  rows*Z is a multiple of 128 and the plane
+// starts are 128-aligned, so a block covers whole rows of the (nvox / 128) GroupNorm partial table: it writes its sums
+// into the first and zeros into the others.
+struct StemF32Args {
+    const float* x;      // (B, X, Y, Z)
+    const float* w;      // (32, 1, 3, 3, 3)
+    const float* bias;   // (32)
+    float* out;          // (B, X, Y, Z, 32) raw
+    float* partial;      // (B, nblk, 8, 2) or NULL
+    int B, X, Y, Z, rows, nblk;
+};
+
+__global__ void __launch_bounds__(256) stem_f32_kernel(StemF32Args a) {
+    __shared__ float red[4 * 16];
+    extern __shared__ __attribute__((aligned(16))) float stem32_lds[];  // [3][rows + 2][Z + 2]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int nyc = (a.Y + a.rows - 1) / a.rows;
+    int blk = blockIdx.x;
+    const int yc = blk % nyc;
+    blk /= nyc;
+    const int x = blk % a.X, b = blk / a.X;
+    const int y0 = yc * a.rows, rows = min(a.rows, a.Y - y0);
+    const int pz = a.Z + 2, seg = (a.rows + 2) * pz;
+    const float* xb = a.x + (long long)b * a.X * a.Y * a.Z;
+    // stage: plane dx, row r (y = y0 - 1 + r), column c (z = c - 1); zero outside the volume
+    for (int i = tid; i < 3 * (rows + 2) * pz; i += 256) {
+        const int dx = i / ((rows + 2) * pz), rem = i - dx * (rows + 2) * pz;
+        const int r = rem / pz, c = rem - r * pz;
+        const int xi = x + dx - 1, yi = y0 - 1 + r, zi = c - 1;
+        float v = 0.0f;
+        if (xi >= 0 && xi < a.X && yi >= 0 && yi < a.Y && zi >= 0 && zi < a.Z)
+            v = xb[((long long)xi * a.Y + yi) * a.Z + zi];
+        stem32_lds[dx * seg + r * pz + c] = v;
+    }
+    float wreg[14];
+    int toff[14];
+#pragma unroll
+    for (int m = 0; m < 14; ++m) {
+        const int tap = 2 * m + h;
+        wreg[m] = tap < 27 ? a.w[col * 27 + tap] : 0.0f;   // A row = cout = col
+        const int tt = tap < 27 ? tap : 0;
+        toff[m] = (tt / 9) * seg + ((tt / 3) % 3) * pz + tt % 3;
+    }
+    f32x16 binit;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) binit[4 * q + j] = a.bias ? a.bias[8 * q + 4 * h + j] : 0.0f;
+    __syncthreads();
+    float gs[4] = {0, 0, 0, 0}, gq[4] = {0, 0, 0, 0};
+    const int nloc = rows * a.Z, ntile = (nloc + 31) / 32;
+    const long long v0 = ((long long)x * a.Y + y0) * a.Z;       // first voxel of the block (in-sample index)
+    float* ob = a.out + ((long long)b * a.X * a.Y * a.Z + v0) * 32;
+    for (int t = w; t < ntile; t += 4) {
+        const int i = t * 32 + col;
+        const bool ok = i < nloc;
+        const int ii = ok ? i : 0;
+        const int yl = ii / a.Z, z = ii - yl * a.Z;
+        const float* p = stem32_lds + yl * pz + z;
+        f32x16 acc = binit;
+#pragma unroll
+        for (int m = 0; m < 14; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[m], p[toff[m]], acc, 0, 0, 0);
+        if (ok) {
+            float* op = ob + (long long)i * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 r = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                *reinterpret_cast<f32x4*>(op + 8 * q) = r;
+                gs[q] += (r[0] + r[1]) + (r[2] + r[3]);
+                gq[q] += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+            }
+        }
+    }
+    if (a.partial) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float s = gs[q], ss = gq[q];
+#pragma unroll
+            for (int m = 16; m > 0; m >>= 1) {
+                s += __shfl_xor(s, m);
+                ss += __shfl_xor(ss, m);
+            }
+            if (col == 0) {
+                red[(w * 8 + 2 * q + h) * 2] = s;
+                red[(w * 8 + 2 * q + h) * 2 + 1] = ss;
+            }
+        }
+        __syncthreads();
+        // partial rows [v0 / 128, (v0 + nloc) / 128) belong to this block
+        const long long r0 = v0 / 128;
+        const int nrow = nloc / 128;
+        float* pr = a.partial + ((long long)b * a.nblk + r0) * 16;
+        if (tid < 16) pr[tid] = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+        for (int i = 16 + tid; i < nrow * 16; i += 256) pr[i] = 0.0f;
+    }
+}
+
 // Data gradient of a pointwise conv with FEW output channels (the heads: K = 5 logits -> 32 features): HBM-bound
 // (20 B in, 128 B out per voxel), so no matrix instruction -- a lane owns 4 consecutive input channels of a voxel
 // (K x 4 weights in registers), 16-byte loads of dy are shared by the voxel's lanes, one 16-byte store per lane.
@@ -395,7 +497,40 @@ __global__ void __launch_bounds__(256) pointwise_dgrad_kernel(const float* __res
 }  // namespace
 
 // every source a multiple of 32 channels -> LDS-staged kernel, else the plain gather kernel
+// rows per block of stem_f32_kernel, or 0 when the shape does not fit its partial-row scheme
+static int stem_f32_rows(int Y, int Z) {
+    if (((long long)Y * Z) % 128) return 0;
+    int gran = 1;
+    while ((gran * Z) % 128) gran *= 2;                       // rows * Z must be a multiple of 128
+    int r = (40 * 1024) / (3 * (Z + 2) * 4) - 2;              // three staged planes within 40 KiB
+    r = r / gran * gran;
+    if (r > 64) r = 64 / gran * gran;
+    if (r < gran || Y % gran) return 0;
+    return r;
+}
+
 static int launch_conv_f32(const ConvF32Args& a, hipStream_t st) {
+    if (a.nsrc == 1 && a.src[0].C == 1 && a.ksize == 3 && a.cout == 32 && !a.transposed && !a.accumulate && !a.src[0].up) {
+        const int rows = stem_f32_rows(a.oy, a.oz);
+        if (rows > 0) {
+            StemF32Args s{};
+            s.x = a.src[0].data;
+            s.w = a.w;
+            s.bias = a.bias;
+            s.out = a.out;
+            s.partial = a.partial;
+            s.B = a.B;
+            s.X = a.ox;
+            s.Y = a.oy;
+            s.Z = a.oz;
+            s.rows = rows;
+            s.nblk = a.nblk;
+            const size_t lds = (size_t)3 * (rows + 2) * (a.oz + 2) * sizeof(float);
+            const unsigned grid = (unsigned)(a.B * a.ox * ((a.oy + rows - 1) / rows));
+            stem_f32_kernel<<<grid, 256, lds, st>>>(s);
+            return SK_OK;
+        }
+    }
     bool lds = true;
     for (int i = 0; i < a.nsrc; ++i) lds = lds && (a.src[i].C % 32 == 0);
     for (int i = 0; i < a.nsrc && lds; ++i)

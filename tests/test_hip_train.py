@@ -147,6 +147,33 @@ BWD_CASES = [
 ]
 
 
+@pytest.mark.parametrize("B,osp", [(2, (6, 16, 16)), (1, (5, 24, 32)), (1, (3, 8, 256)), (1, (4, 7, 5))])
+def test_stem_forward_fp32(ffi, B, osp):
+    """First conv (Cin = 1) in fp32: shapes whose planes are multiples of 128 voxels take the LDS-staged kernel with
+    two taps per MFMA (the last shape falls back to the generic one).  Output and GroupNorm partial totals vs torch."""
+    gen = torch.Generator().manual_seed(osp[1])
+    x = torch.randn((B, 1) + osp, generator=gen)
+    w = torch.randn((32, 1, 3, 3, 3), generator=gen) / 27 ** 0.5
+    bias = torch.randn(32, generator=gen)
+    want = F.conv3d(x, w, bias, padding=1)
+    dev = torch.device(DEV)
+    xd, wd, bd = _cl(x).to(dev), w.to(dev).contiguous(), bias.to(dev)
+    ox, oy, oz = osp
+    nblk = ffi.lib.sk_conv3d_f32_num_blocks(ox, oy, oz)
+    out = torch.empty((B, ox, oy, oz, 32), device=dev)
+    partial = torch.full((B, nblk, 8, 2), 7.0, device=dev)   # every row must be overwritten
+    arr = (ffi.ConvSrc * 1)()
+    arr[0].data, arr[0].affine, arr[0].c, arr[0].upsample = xd.data_ptr(), None, 1, 0
+    ffi.check(ffi.lib.sk_conv3d_f32(arr, 1, ffi.ptr(wd), ffi.ptr(bd), ffi.ptr(out), B, ox, oy, oz, 32, 3, ffi.ptr(partial),
+                                    ffi.stream_ptr(dev)))
+    got = out.cpu().permute(0, 4, 1, 2, 3)
+    assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    tot = partial.sum(dim=1).cpu()                              # (B, 8, 2)
+    wq = want.reshape(B, 8, 4, -1)
+    assert torch.allclose(tot[..., 0], wq.sum(dim=(2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(tot[..., 1], (wq ** 2).sum(dim=(2, 3)), rtol=1e-4)
+
+
 @pytest.mark.parametrize("B,osp,srcdef,cout,ksize", BWD_CASES)
 def test_conv_backward(ffi, B, osp, srcdef, cout, ksize):
     gen = torch.Generator().manual_seed(cout * 5 + ksize + osp[0])
