@@ -1487,19 +1487,34 @@ __global__ void __launch_bounds__(256) interleave2_kernel(const __half* __restri
 // out = sum over chunks of part[c] (fixed order -> deterministic): 64 elements per block, four chunk slices.
 // k3 > 0: the partials are tap-major (tap, cout, cin) -- written with the lanes (cin) contiguous -- and the result
 // goes to the torch layout (cout, cin, k3); k3 == 0: same layout in and out.
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int nchunk, long long n,
-                                                           float* __restrict__ out, const float* __restrict__ scale, int cout,
-                                                           int cin, int k3) {
-    __shared__ double red[256];
+constexpr int kWredSlices = 16;  // chunk slices per block (x 64 elements = 1024 threads)
+__global__ void __launch_bounds__(64 * kWredSlices) wgrad_reduce_kernel(const float* __restrict__ part, int nchunk, long long n,
+                                                                        float* __restrict__ out, const float* __restrict__ scale,
+                                                                        int cout, int cin, int k3) {
+    __shared__ double red[64 * kWredSlices];
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 64 + e;
-    double s = 0.0;
-    if (i < n)
-        for (int c = sl; c < nchunk; c += 4) s += (double)part[(long long)c * n + i];
-    red[threadIdx.x] = s;
+    // four independent loads in flight per lane (a single dependent chain over nchunk / 4 strided loads made the
+    // 30 launches of a step latency-bound: 82 us each)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (i < n) {
+        int c = sl;
+        for (; c + 3 * kWredSlices < nchunk; c += 4 * kWredSlices) {
+            const float v0 = part[(long long)c * n + i], v1 = part[(long long)(c + kWredSlices) * n + i];
+            const float v2 = part[(long long)(c + 2 * kWredSlices) * n + i], v3 = part[(long long)(c + 3 * kWredSlices) * n + i];
+            s0 += (double)v0;
+            s1 += (double)v1;
+            s2 += (double)v2;
+            s3 += (double)v3;
+        }
+        for (; c < nchunk; c += kWredSlices) s0 += (double)part[(long long)c * n + i];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (sl == 0 && i < n) {
-        s = ((red[e] + red[64 + e]) + red[128 + e]) + red[192 + e];
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < kWredSlices; ++k) s += red[64 * k + e];
         long long o = i;
         if (k3 > 0) {
             const int ci = (int)(i % cin);
@@ -1783,10 +1798,10 @@ int sk_train_conv_wgrad(const sk_conv_src* srcs, int n_src, const float* dy, int
     else
         wgrad_kernel<1><<<grid, 64, 0, st>>>(a);
     SK_CHECK_LAUNCH();
-    wgrad_reduce_kernel<<<sk::cdiv(nw, 64), 256, 0, st>>>(a.part, a.nchunk, nw, dweight, nullptr, cout, a.cin, stem ? 0 : ksize * ksize * ksize);
+    wgrad_reduce_kernel<<<sk::cdiv(nw, 64), 64 * kWredSlices, 0, st>>>(a.part, a.nchunk, nw, dweight, nullptr, cout, a.cin, stem ? 0 : ksize * ksize * ksize);
     SK_CHECK_LAUNCH();
     if (dbias) {
-        wgrad_reduce_kernel<<<sk::cdiv(cout, 64), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, nullptr, 0, 0, 0);
+        wgrad_reduce_kernel<<<sk::cdiv(cout, 64), 64 * kWredSlices, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, nullptr, 0, 0, 0);
         SK_CHECK_LAUNCH();
     }
     return SK_OK;
@@ -1866,10 +1881,10 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
     else
         wgrad16_kernel<1><<<grid, 64, 0, st>>>(a);
     SK_CHECK_LAUNCH();
-    wgrad_reduce_kernel<<<sk::cdiv(nw, 64), 256, 0, st>>>(a.part, a.nchunk, nw, dweight, dy_scale, cout, a.cin, ksize * ksize * ksize);
+    wgrad_reduce_kernel<<<sk::cdiv(nw, 64), 64 * kWredSlices, 0, st>>>(a.part, a.nchunk, nw, dweight, dy_scale, cout, a.cin, ksize * ksize * ksize);
     SK_CHECK_LAUNCH();
     if (dbias) {
-        wgrad_reduce_kernel<<<sk::cdiv(cout, 64), 256, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, dy_scale, 0, 0, 0);
+        wgrad_reduce_kernel<<<sk::cdiv(cout, 64), 64 * kWredSlices, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, dy_scale, 0, 0, 0);
         SK_CHECK_LAUNCH();
     }
     return SK_OK;
