@@ -1465,12 +1465,14 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(PackArgs a) {
 __global__ void __launch_bounds__(256) interleave2_kernel(const __half* __restrict__ t16, float* __restrict__ dx, int B,
                                                           int cx, int cy, int cz, int C, const float* __restrict__ scale,
                                                           int accumulate) {
+    // 8 channels per lane: one 16-byte load of the parity tensor, two 16-byte stores (+ loads when accumulating)
     const float s = scale ? scale[1] : 1.0f;
+    const int nq = C / 8;
     const long long ncoarse = (long long)B * cx * cy * cz * C;
-    const long long n = ncoarse * 8;
+    const long long n = (long long)B * cx * cy * cz * 8 * nq;   // fine voxels x channel octets
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        long long t = i / C;
+        const int q = (int)(i % nq);
+        long long t = i / nq;
         const int z = (int)(t % (2 * cz));
         t /= 2 * cz;
         const int y = (int)(t % (2 * cy));
@@ -1478,9 +1480,18 @@ __global__ void __launch_bounds__(256) interleave2_kernel(const __half* __restri
         const int x = (int)(t % (2 * cx));
         const int b = (int)(t / (2 * cx));
         const int p = ((x & 1) << 2) | ((y & 1) << 1) | (z & 1);
-        const long long ci = ((((long long)b * cx + (x >> 1)) * cy + (y >> 1)) * cz + (z >> 1)) * C + c;
-        const float v = __half2float(t16[(long long)p * ncoarse + ci]) * s;
-        dx[i] = accumulate ? dx[i] + v : v;
+        const long long ci = ((((long long)b * cx + (x >> 1)) * cy + (y >> 1)) * cz + (z >> 1)) * C + 8 * q;
+        const half8_t h = *reinterpret_cast<const half8_t*>(t16 + (long long)p * ncoarse + ci);
+        float4 v0 = {(float)h[0] * s, (float)h[1] * s, (float)h[2] * s, (float)h[3] * s};
+        float4 v1 = {(float)h[4] * s, (float)h[5] * s, (float)h[6] * s, (float)h[7] * s};
+        float4* o = reinterpret_cast<float4*>(dx + i * 8);
+        if (accumulate) {
+            const float4 p0 = o[0], p1 = o[1];
+            v0 = {p0.x + v0.x, p0.y + v0.y, p0.z + v0.z, p0.w + v0.w};
+            v1 = {p1.x + v1.x, p1.y + v1.y, p1.z + v1.z, p1.w + v1.w};
+        }
+        o[0] = v0;
+        o[1] = v1;
     }
 }
 
@@ -1917,9 +1928,10 @@ int sk_train_pack_weight(const float* weight, int Co, int Ci, int ksize, int tra
 
 int sk_train_interleave2(const void* t16, float* dx, int B, int cx, int cy, int cz, int C, const float* scale, int accumulate,
                          void* stream) {
-    SK_CHECK_ARG(t16 && dx && B >= 1 && cx >= 1 && cy >= 1 && cz >= 1 && C >= 1, "sk_train_interleave2: bad arguments");
-    long long n = (long long)B * cx * cy * cz * C * 8;
-    interleave2_kernel<<<sk::stream_grid(n, 256, 4), 256, 0, (hipStream_t)stream>>>((const __half*)t16, dx, B, cx, cy, cz, C, scale,
+    SK_CHECK_ARG(t16 && dx && B >= 1 && cx >= 1 && cy >= 1 && cz >= 1 && C >= 8 && C % 8 == 0,
+                 "sk_train_interleave2: bad arguments (C must be a multiple of 8)");
+    long long n = (long long)B * cx * cy * cz * C;   // fine voxels x channel octets = coarse voxels x C
+    interleave2_kernel<<<sk::stream_grid(n, 256, 2), 256, 0, (hipStream_t)stream>>>((const __half*)t16, dx, B, cx, cy, cz, C, scale,
                                                                                     accumulate ? 1 : 0);
     SK_CHECK_LAUNCH();
     return SK_OK;
