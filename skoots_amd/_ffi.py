@@ -102,6 +102,8 @@ _SIGS = {
     "sk_train_sumpool2": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "sk_train_gn_silu_bwd_f16h": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp, vp]),
     "sk_train_sumpool2_f16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "sk_train_stem_fwd_f16": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, C.c_size_t, vp]),
+    "sk_train_stem_wgrad_f16": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "sk_bake_skeleton": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, fp, vp, vp, vp]),
     "sk_average_baked_skeletons": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "sk_mask_iou_workspace_bytes": (sz, [i32, i32]),

@@ -549,9 +549,15 @@ __global__ void __launch_bounds__(64) wgrad_kernel(WgradArgs a) {
     }
 }
 
+__device__ inline _Float16 buf_load_f16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, 0));
+}
+
 // Weight gradient of the stem (Cin = 1, k = 3): with one input channel the 27 taps take the place of the input
 // channels -- D[cout][tap] += dY[v][cout] * x[v + tap] -- so ONE MFMA per two voxels covers all taps (the generic
 // kernel would spend 27 MFMAs with 1 of 32 columns in use).  Partial layout as wgrad_kernel: (chunk, cout, 1, 27).
+// DYH: dy is a (scaled) fp16 tensor -- the mixed-precision step; the reduction multiplies by scale[1]
+template <bool DYH>
 __global__ void __launch_bounds__(64) wgrad_stem_kernel(WgradArgs a) {
     const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
     int blk = blockIdx.x;
@@ -563,7 +569,9 @@ __global__ void __launch_bounds__(64) wgrad_stem_kernel(WgradArgs a) {
     const bool cook = co < a.cout, tapok = col < 27;
     const int dx = col / 9 - 1, dy = (col / 3) % 3 - 1, dz = col % 3 - 1;  // this lane's tap (B column)
     const long long nvox = (long long)a.ox * a.oy * a.oz;
-    const __amdgpu_buffer_rsrc_t rdy = sk::make_rsrc(a.dy + (long long)b * nvox * a.cout, (unsigned)(nvox * a.cout * 4));
+    constexpr int kDyB = DYH ? 2 : 4;  // bytes per dy element
+    const __amdgpu_buffer_rsrc_t rdy = sk::make_rsrc(reinterpret_cast<const char*>(a.dy) + (long long)b * nvox * a.cout * kDyB,
+                                                     (unsigned)(nvox * a.cout * kDyB));
     const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(S.data + (long long)b * nvox, (unsigned)(nvox * 4));
     f32x16 acc;
 #pragma unroll
@@ -579,7 +587,10 @@ __global__ void __launch_bounds__(64) wgrad_stem_kernel(WgradArgs a) {
     const long long ntrip = (q1 - q0 + 1) / 2;
     auto fetch = [&](float& av, float& bv) {
         const bool ok = q < q1;
-        av = sk::buf_load_f32(rdy, (ok && cook) ? (unsigned)(q * a.cout + co) * 4u : sk::kOob);
+        if constexpr (DYH)
+            av = (float)buf_load_f16(rdy, (ok && cook) ? (unsigned)(q * a.cout + co) * 2u : sk::kOob);
+        else
+            av = sk::buf_load_f32(rdy, (ok && cook) ? (unsigned)(q * a.cout + co) * 4u : sk::kOob);
         const int xi = x + dx, yi = y + dy, zi = z + dz;
         const bool inb = ok && tapok && xi >= 0 && xi < a.ox && yi >= 0 && yi < a.oy && zi >= 0 && zi < a.oz;
         bv = sk::buf_load_f32(rsrc, inb ? (unsigned)((xi * a.oy + yi) * a.oz + zi) * 4u : sk::kOob);
@@ -968,9 +979,6 @@ struct Wgrad16Args {
     long long chunk;   // voxels per chunk, multiple of 16
 };
 
-__device__ inline _Float16 buf_load_f16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return __builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, 0));
-}
 
 template <int NT>
 __global__ void __launch_bounds__(64) wgrad16_kernel(Wgrad16Args a) {
@@ -1801,7 +1809,7 @@ int sk_train_conv_wgrad(const sk_conv_src* srcs, int n_src, const float* dy, int
     const unsigned grid = (unsigned)((long long)a.nchunk * a.ncot * a.ncit * a.ngroup);
     const bool stem = ksize == 3 && n_src == 1 && a.cin == 1 && !a.src[0].up;
     if (stem)
-        wgrad_stem_kernel<<<(unsigned)((long long)a.nchunk * a.ncot), 64, 0, st>>>(a);
+        wgrad_stem_kernel<false><<<(unsigned)((long long)a.nchunk * a.ncot), 64, 0, st>>>(a);
     else if (ksize == 3)
         wgrad_kernel<9><<<grid, 64, 0, st>>>(a);
     else if (ksize == 2)
@@ -1813,6 +1821,46 @@ int sk_train_conv_wgrad(const sk_conv_src* srcs, int n_src, const float* dy, int
     SK_CHECK_LAUNCH();
     if (dbias) {
         wgrad_reduce_kernel<<<sk::cdiv(cout, 64), 64 * kWredSlices, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, nullptr, 0, 0, 0);
+        SK_CHECK_LAUNCH();
+    }
+    return SK_OK;
+}
+
+int sk_train_stem_wgrad_f16(const float* image, const void* dy16, const float* dy_scale, int B, int X, int Y, int Z,
+                            float* dweight, float* dbias, float* workspace, void* stream) {
+    SK_CHECK_ARG(image && dy16 && dy_scale && dweight && workspace, "sk_train_stem_wgrad_f16: NULL pointer");
+    SK_CHECK_ARG(B >= 1 && X >= 1 && Y >= 1 && Z >= 1, "sk_train_stem_wgrad_f16: bad extents");
+    const int cout = 32;
+    WgradArgs a{};
+    a.nsrc = 1;
+    a.src[0].data = image;
+    a.src[0].C = 1;
+    a.src[0].up = 0;
+    a.src[0].Xs = X;
+    a.src[0].Ys = Y;
+    a.src[0].Zs = Z;
+    a.dy = reinterpret_cast<const float*>(dy16);
+    a.B = B;
+    a.ox = X;
+    a.oy = Y;
+    a.oz = Z;
+    a.cout = cout;
+    a.cin = 1;
+    a.ksize = 3;
+    a.ncot = 1;
+    a.ncit = 1;
+    wgrad_plan(B, X, Y, Z, cout, 1, 3, &a.nchunk, &a.nchunk_b, &a.chunk, &a.ngroup);
+    SK_CHECK_ARG((long long)X * Y * Z * cout * 2 < (1LL << 32), "sk_train_stem_wgrad_f16: dy of one batch item must be < 4 GiB");
+    const long long nw = (long long)cout * 27;
+    a.part = workspace;
+    a.part_bias = dbias ? workspace + (long long)a.nchunk * nw : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    wgrad_stem_kernel<true><<<(unsigned)((long long)a.nchunk * a.ncot), 64, 0, st>>>(a);
+    SK_CHECK_LAUNCH();
+    wgrad_reduce_kernel<<<sk::cdiv(nw, 64), 64 * kWredSlices, 0, st>>>(a.part, a.nchunk, nw, dweight, dy_scale, cout, 1, 0);
+    SK_CHECK_LAUNCH();
+    if (dbias) {
+        wgrad_reduce_kernel<<<sk::cdiv(cout, 64), 64 * kWredSlices, 0, st>>>(a.part_bias, a.nchunk, cout, dbias, dy_scale, 0, 0, 0);
         SK_CHECK_LAUNCH();
     }
     return SK_OK;

@@ -81,8 +81,11 @@ static int stem_rows(int Yt, int Zt) {
     return r < 1 ? 1 : r;
 }
 
-template <bool STATS>
+// MODE 0: statistics only; 1: recompute + affine + SiLU, store the activation; 2 (training, mixed precision):
+// statistics AND the raw fp16 result in one pass (the backward needs the raw tensor anyway)
+template <int MODE>
 __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
+    constexpr bool STATS = MODE != 1;
     __shared__ float red[4 * 16];
     extern __shared__ __attribute__((aligned(16))) unsigned int stem_lds[];  // [3][rows+2][Zt+2] halves
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -164,6 +167,11 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
                     float v0 = acc[4 * q], v1 = acc[4 * q + 1], v2 = acc[4 * q + 2], v3 = acc[4 * q + 3];
                     gsum[q] += (v0 + v1) + (v2 + v3);
                     gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                    if (MODE == 2) {
+                        const long long v = ((long long)x * a.Yt + (y0 + yl)) * a.Zt + z;
+                        half4v hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+                        *reinterpret_cast<half4v*>(a.out + ((long long)b * nvox + v) * 32 + 8 * q + 4 * h) = hv;
+                    }
                 }
             } else {
                 const long long v = ((long long)x * a.Yt + (y0 + yl)) * a.Zt + z;
@@ -464,9 +472,9 @@ int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origin
     stem_norm_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(a);
     SK_CHECK_ARG(Zt % 2 == 0 && stem_lds_bytes(Yt, Zt) <= 60 * 1024, "sk_conv3d_stem: tile depth %d unsupported", Zt);
     if (stem_lds_bytes(Yt, Zt) > 40 * 1024)
-        SK_CHECK_HIP(hipFuncSetAttribute((const void*)stem_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        SK_CHECK_HIP(hipFuncSetAttribute((const void*)stem_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)stem_lds_bytes(Yt, Zt)));
-    stem_kernel<true><<<(unsigned)(a.nblk * B), 256, stem_lds_bytes(Yt, Zt), (hipStream_t)stream>>>(a);
+    stem_kernel<0><<<(unsigned)(a.nblk * B), 256, stem_lds_bytes(Yt, Zt), (hipStream_t)stream>>>(a);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
@@ -488,9 +496,58 @@ int sk_conv3d_stem_apply(int B, int Xt, int Yt, int Zt, const float* weight, con
     a.nblk = sk_conv3d_stem_num_blocks(Xt, Yt, Zt);
     a.rows = stem_rows(Yt, Zt);
     if (stem_lds_bytes(Yt, Zt) > 40 * 1024)
-        SK_CHECK_HIP(hipFuncSetAttribute((const void*)stem_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        SK_CHECK_HIP(hipFuncSetAttribute((const void*)stem_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)stem_lds_bytes(Yt, Zt)));
-    stem_kernel<false><<<(unsigned)(a.nblk * B), 256, stem_lds_bytes(Yt, Zt), (hipStream_t)stream>>>(a);
+    stem_kernel<1><<<(unsigned)(a.nblk * B), 256, stem_lds_bytes(Yt, Zt), (hipStream_t)stream>>>(a);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+// ---- training, mixed precision: the stem as a fast block -------------------------------------------------------
+// image (B, X, Y, Z) fp32 -> zero-framed fp16 copy (the MFMA operand; the weights stay exact through the hi + lo split)
+__global__ void __launch_bounds__(256) stem_frame_f32_kernel(const float* __restrict__ image, __half* __restrict__ norm, int B,
+                                                            int X, int Y, int Z) {
+    const int px = X + 2, py = Y + 2, pz = Z + 2;
+    const long long n = (long long)B * px * py * pz;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int z = (int)(i % pz);
+        long long t = i / pz;
+        const int y = (int)(t % py);
+        t /= py;
+        const int x = (int)(t % px), b = (int)(t / px);
+        float v = 0.0f;
+        if (x >= 1 && x <= X && y >= 1 && y <= Y && z >= 1 && z <= Z)
+            v = image[(((long long)b * X + (x - 1)) * Y + (y - 1)) * Z + (z - 1)];
+        norm[i] = __float2half_rn(v);
+    }
+}
+
+int sk_train_stem_fwd_f16(const float* image, int B, int X, int Y, int Z, const float* weight_t, const float* bias,
+                          void* y16, float* gn_partial, void* workspace, size_t workspace_bytes, void* stream) {
+    SK_CHECK_ARG(image && weight_t && bias && y16 && gn_partial && workspace, "sk_train_stem_fwd_f16: NULL pointer");
+    SK_CHECK_ARG(B >= 1 && B <= 16 && X >= 1 && Y >= 1 && Z >= 2 && Z % 2 == 0, "sk_train_stem_fwd_f16: bad extents");
+    SK_CHECK_ARG(workspace_bytes >= sk_conv3d_stem_workspace_bytes(B, X, Y, Z), "sk_train_stem_fwd_f16: workspace too small");
+    SK_CHECK_ARG(stem_lds_bytes(Y, Z) <= 60 * 1024, "sk_train_stem_fwd_f16: depth %d unsupported", Z);
+    StemArgs a{};
+    a.B = B;
+    a.Xt = X;
+    a.Yt = Y;
+    a.Zt = Z;
+    a.weight = weight_t;
+    a.bias = bias;
+    a.norm = (__half*)workspace;
+    a.out = (__half*)y16;
+    a.partial = gn_partial;
+    a.nblk = sk_conv3d_stem_num_blocks(X, Y, Z);
+    a.rows = stem_rows(Y, Z);
+    hipStream_t st = (hipStream_t)stream;
+    const long long np = (long long)B * (X + 2) * (Y + 2) * (Z + 2);
+    stem_frame_f32_kernel<<<sk::stream_grid(np, 256, 4), 256, 0, st>>>(image, a.norm, B, X, Y, Z);
+    SK_CHECK_LAUNCH();
+    if (stem_lds_bytes(Y, Z) > 40 * 1024)
+        SK_CHECK_HIP(hipFuncSetAttribute((const void*)stem_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)stem_lds_bytes(Y, Z)));
+    stem_kernel<2><<<(unsigned)(a.nblk * B), 256, stem_lds_bytes(Y, Z), st>>>(a);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }

@@ -199,8 +199,41 @@ class TrainUNet:
         self._tape.append((layer, srcs, y16, affine, stats, out))
         return out
 
+    def _stem_fast(self, layer: _Layer, srcs, out_shape) -> bool:
+        """The stem (Cin = 1, 27 taps, Cout 32) as a fast block: fp16 image operand, exact weights (hi + lo split)."""
+        B = srcs[0][0].shape[0]
+        return (self.precision == "mixed" and layer.norm and layer.cin == 1 and layer.cout == 32 and layer.ksize == 3 and
+                len(srcs) == 1 and B <= 16 and out_shape[2] % 2 == 0 and os.environ.get("SK_TRAIN_STEM_F32") is None)
+
+    def _block_stem_mixed(self, layer: _Layer, srcs, out_shape) -> Tensor:
+        image = srcs[0][0]                       # (B, X, Y, Z, 1) fp32
+        B = image.shape[0]
+        X, Y, Z = out_shape
+        st = _ffi.stream_ptr(self.device)
+        nblk = _ffi.lib.sk_conv3d_stem_num_blocks(X, Y, Z)
+        partial = torch.empty((B, nblk, 8, 2), dtype=torch.float32, device=self.device)
+        wsb = int(_ffi.lib.sk_conv3d_stem_workspace_bytes(B, X, Y, Z))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=self.device)
+        w_t = layer.weight.reshape(32, 27).t().contiguous()   # (27, 32) tap-major, the stem kernel's layout
+        y16 = torch.empty((B, X, Y, Z, 32), dtype=torch.float16, device=self.device)
+        _ffi.check(_ffi.lib.sk_train_stem_fwd_f16(_ffi.ptr(image), B, X, Y, Z, _ffi.ptr(w_t), _ffi.ptr(layer.bias),
+                                                  _ffi.ptr(y16), _ffi.ptr(partial), _ffi.ptr(ws), wsb, st))
+        vox = X * Y * Z
+        affine = torch.empty((B, 2, 32), dtype=torch.float32, device=self.device)
+        stats = torch.empty((B, GN_GROUPS, 2), dtype=torch.float32, device=self.device)
+        _ffi.check(_ffi.lib.sk_groupnorm_finalize_stats(_ffi.ptr(partial), B, nblk, GN_GROUPS, 32, vox,
+                                                        _ffi.ptr(layer.gamma), _ffi.ptr(layer.beta), GN_EPS,
+                                                        _ffi.ptr(affine), _ffi.ptr(stats), st))
+        z16 = torch.empty_like(y16)
+        _ffi.check(_ffi.lib.sk_train_gn_silu_f16(_ffi.ptr(y16), _ffi.ptr(affine), _ffi.ptr(z16), None, B, vox, 32, st))
+        self._keep = getattr(self, "_keep", []) + [ws, w_t]   # alive until the stream has consumed them
+        self._tape.append((layer, srcs, y16, affine, stats, z16))
+        return z16
+
     def _block(self, layer: _Layer, srcs: List[Tuple[Tensor, int]], out_shape: Tuple[int, int, int],
                want32: bool = False) -> Tensor:
+        if self._stem_fast(layer, srcs, out_shape):
+            return self._block_stem_mixed(layer, srcs, out_shape)
         if self._fast(layer, srcs):
             return self._block_mixed(layer, srcs, out_shape, want32)
         z = self._block_fp32(layer, srcs, out_shape)
@@ -309,10 +342,16 @@ class TrainUNet:
                                                                   _ffi.ptr(layer.g_gamma), _ffi.ptr(layer.g_beta),
                                                                   _ffi.ptr(ws), st))
                 dy = None
-                srcs16 = [(self._h(t), up) for t, up in srcs]
-                _ffi.check(_ffi.lib.sk_train_conv_wgrad_f16(self._srcs(srcs16), len(srcs16), _ffi.ptr(dy16), _ffi.ptr(scale), B,
-                                                            ox, oy, oz, cout, layer.ksize, _ffi.ptr(layer.g_weight),
-                                                            _ffi.ptr(layer.g_bias), _ffi.ptr(ws), _ffi.ptr(self._zero_page), st))
+                if layer.cin == 1:   # the stem: taps as the GEMM's N, fp32 image x scaled fp16 dy
+                    _ffi.check(_ffi.lib.sk_train_stem_wgrad_f16(_ffi.ptr(srcs[0][0]), _ffi.ptr(dy16), _ffi.ptr(scale), B, ox,
+                                                                oy, oz, _ffi.ptr(layer.g_weight), _ffi.ptr(layer.g_bias),
+                                                                _ffi.ptr(ws), st))
+                else:
+                    srcs16 = [(self._h(t), up) for t, up in srcs]
+                    _ffi.check(_ffi.lib.sk_train_conv_wgrad_f16(self._srcs(srcs16), len(srcs16), _ffi.ptr(dy16), _ffi.ptr(scale),
+                                                                B, ox, oy, oz, cout, layer.ksize, _ffi.ptr(layer.g_weight),
+                                                                _ffi.ptr(layer.g_bias), _ffi.ptr(ws), _ffi.ptr(self._zero_page),
+                                                                st))
             else:
                 if layer.norm:
                     ws = self._workspace(_ffi.lib.sk_train_gn_bwd_workspace_floats(B, vox, cout))
@@ -390,6 +429,7 @@ class TrainUNet:
                 lo += c
         self._tape = []
         self._half = {}
+        self._keep = []
 
 
 def fused_loss(logits: Tensor, masks: Tensor, skele_masks: Tensor, baked: Tensor, sigma: Sequence[float],
