@@ -605,20 +605,21 @@ __global__ void __launch_bounds__(64) wgrad_stem_kernel(WgradArgs a) {
             ++x;
         }
     };
-    float av_n[4], bv_n[4];  // four steps in flight
+    constexpr int kDepth = 8;   // steps in flight
+    float av_n[kDepth], bv_n[kDepth];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) fetch(av_n[u], bv_n[u]);
-    for (long long it = 0; it < ntrip; it += 4) {
-        float av[4], bv[4];
+    for (int u = 0; u < kDepth; ++u) fetch(av_n[u], bv_n[u]);
+    for (long long it = 0; it < ntrip; it += kDepth) {
+        float av[kDepth], bv[kDepth];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kDepth; ++u) {
             av[u] = av_n[u];
             bv[u] = bv_n[u];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) fetch(av_n[u], bv_n[u]);  // past the chunk end: masked, zeros
+        for (int u = 0; u < kDepth; ++u) fetch(av_n[u], bv_n[u]);  // past the chunk end: masked, zeros
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kDepth; ++u) {
             bsum += av[u];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
         }
