@@ -379,6 +379,14 @@ int sk_train_stem_fwd_f16(const float* image, int B, int X, int Y, int Z, const 
                           void* y16, float* gn_partial, void* workspace, size_t workspace_bytes, void* stream);
 int sk_train_stem_wgrad_f16(const float* image, const void* dy16, const float* dy_scale, int B, int X, int Y, int Z,
                             float* dweight, float* dbias, float* workspace, void* stream);
+/* Heads of the mixed step on the fp16 activation z16 (nvox, 32): logits (nvox, 5) fp32 = z W^T + b with W (5, 32);
+ * weight / bias gradients from z16 and dlogits (nvox, 5) fp32 (deterministic two-stage reduction; workspace:
+ * sk_train_heads_wgrad_workspace_floats(nvox) floats).  nvox counts the voxels of all batch items. */
+int sk_train_heads_fwd_f16(const void* z16, const float* weight, const float* bias, float* logits, int64_t nvox,
+                           void* stream);
+int64_t sk_train_heads_wgrad_workspace_floats(int64_t nvox);
+int sk_train_heads_wgrad_f16(const void* z16, const float* dlogits, float* dweight, float* dbias, int64_t nvox,
+                             float* workspace, void* stream);
 
 /* One AdamW update (torch.optim.AdamW semantics; engine.py:281-285, config.py:96-101) over a
  * flat parameter buffer; step counts from 1. */

@@ -102,6 +102,9 @@ _SIGS = {
     "sk_train_sumpool2": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "sk_train_gn_silu_bwd_f16h": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp, vp]),
     "sk_train_sumpool2_f16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "sk_train_heads_fwd_f16": (i32, [vp, vp, vp, vp, i64, vp]),
+    "sk_train_heads_wgrad_workspace_floats": (i64, [i64]),
+    "sk_train_heads_wgrad_f16": (i32, [vp, vp, vp, vp, i64, vp, vp]),
     "sk_train_stem_fwd_f16": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "sk_train_stem_wgrad_f16": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "sk_bake_skeleton": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, fp, vp, vp, vp]),

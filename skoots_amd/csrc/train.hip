@@ -1604,6 +1604,101 @@ __global__ void __launch_bounds__(256) sumpool2_f16_kernel(const __half* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// Heads (1x1x1 conv, 32 features -> 5 logits) of the mixed step, straight on the fp16 activation: both are pure
+// HBM streams (64 B in, 20 B out per voxel), so no matrix instruction.  Four lanes share a voxel (8 channels = 16 bytes
+// each), partial dot products are combined with two xor-shuffles.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) heads_fwd_f16_kernel(const __half* __restrict__ z, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ logits,
+                                                            long long nvox) {
+    const int q = threadIdx.x & 3;
+    float wk[5][8];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wk[k][j] = w[k * 32 + 8 * q + j];
+    const long long stride = (long long)gridDim.x * 64;
+    for (long long v = (long long)blockIdx.x * 64 + (threadIdx.x >> 2); v < nvox; v += stride) {
+        const half8_t h = *reinterpret_cast<const half8_t*>(z + v * 32 + 8 * q);
+        float acc[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = (float)h[j];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc[k] = fmaf(x, wk[k][j], acc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            acc[k] += __shfl_xor(acc[k], 1);
+            acc[k] += __shfl_xor(acc[k], 2);
+        }
+        // lane q of the voxel writes logit q; lane 0 also logit 4
+        float* o = logits + v * 5;
+        const float mine = q == 0 ? acc[0] : q == 1 ? acc[1] : q == 2 ? acc[2] : acc[3];
+        o[q] = mine + bias[q];
+        if (q == 0) o[4] = acc[4] + bias[4];
+    }
+}
+
+// dW[k][c] = sum_v dl[v][k] z[v][c], db[k] = sum_v dl[v][k]: per block partials (fixed order), reduced by wgrad_reduce_kernel
+constexpr int kHeadsVox = 8192;  // voxels per block
+__global__ void __launch_bounds__(256) heads_wgrad_f16_kernel(const __half* __restrict__ z, const float* __restrict__ dl,
+                                                              float* __restrict__ part, float* __restrict__ part_b,
+                                                              long long nvox) {
+    __shared__ float red[64][41];   // 41: odd pitch, conflict-free column sums
+    const int q = threadIdx.x & 3, row = threadIdx.x >> 2;
+    const long long v0 = (long long)blockIdx.x * kHeadsVox;
+    long long v1 = v0 + kHeadsVox;
+    if (v1 > nvox) v1 = nvox;
+    float acc[5][8];
+    float accb[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0.0f;
+    for (long long v = v0 + row; v < v1; v += 64) {
+        const half8_t h = *reinterpret_cast<const half8_t*>(z + v * 32 + 8 * q);
+        float g[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) g[k] = dl[v * 5 + k];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            accb[k] += g[k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[k][j] = fmaf(g[k], (float)h[j], acc[k][j]);
+        }
+    }
+    // reduce over the 64 rows, one lane quarter (8 channels) per pass, through LDS in a fixed order
+    for (int pass = 0; pass < 4; ++pass) {
+        __syncthreads();
+        if (q == pass) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[row][k * 8 + j] = acc[k][j];
+        }
+        __syncthreads();
+        if (threadIdx.x < 40) {
+            float t = 0.0f;
+            for (int r = 0; r < 64; ++r) t += red[r][threadIdx.x];
+            const int k = threadIdx.x / 8, j = threadIdx.x % 8;
+            part[(long long)blockIdx.x * 160 + k * 32 + 8 * pass + j] = t;
+        }
+    }
+    __syncthreads();
+    if (q == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) red[row][k] = accb[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        float t = 0.0f;
+        for (int r = 0; r < 64; ++r) t += red[r][threadIdx.x];
+        part_b[(long long)blockIdx.x * 5 + threadIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // AdamW (torch.optim.AdamW semantics: decoupled decay, bias-corrected moments)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -2093,6 +2188,33 @@ int sk_train_sumpool2_f16(const void* fine16, const float* scale, float* coarse,
     long long n = (long long)B * cx * cy * cz * (C / 8);
     sumpool2_f16_kernel<<<sk::stream_grid(n, 256, 2), 256, 0, (hipStream_t)stream>>>((const __half*)fine16, scale, coarse, B, cx, cy,
                                                                                      cz, C);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_train_heads_fwd_f16(const void* z16, const float* weight, const float* bias, float* logits, int64_t nvox,
+                           void* stream) {
+    SK_CHECK_ARG(z16 && weight && bias && logits && nvox >= 1, "sk_train_heads_fwd_f16: bad arguments");
+    heads_fwd_f16_kernel<<<sk::stream_grid(nvox, 64, 4), 256, 0, (hipStream_t)stream>>>((const __half*)z16, weight, bias, logits,
+                                                                                      nvox);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int64_t sk_train_heads_wgrad_workspace_floats(int64_t nvox) { return ((nvox + kHeadsVox - 1) / kHeadsVox) * 165; }
+
+int sk_train_heads_wgrad_f16(const void* z16, const float* dlogits, float* dweight, float* dbias, int64_t nvox,
+                             float* workspace, void* stream) {
+    SK_CHECK_ARG(z16 && dlogits && dweight && dbias && workspace && nvox >= 1, "sk_train_heads_wgrad_f16: bad arguments");
+    const int nb = (int)((nvox + kHeadsVox - 1) / kHeadsVox);
+    float* part = workspace;
+    float* part_b = workspace + (long long)nb * 160;
+    hipStream_t st = (hipStream_t)stream;
+    heads_wgrad_f16_kernel<<<nb, 256, 0, st>>>((const __half*)z16, dlogits, part, part_b, nvox);
+    SK_CHECK_LAUNCH();
+    wgrad_reduce_kernel<<<sk::cdiv(160, 64), 64 * kWredSlices, 0, st>>>(part, nb, 160, dweight, nullptr, 0, 0, 0);
+    SK_CHECK_LAUNCH();
+    wgrad_reduce_kernel<<<1, 64 * kWredSlices, 0, st>>>(part_b, nb, 5, dbias, nullptr, 0, 0, 0);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }

@@ -230,10 +230,27 @@ class TrainUNet:
         self._tape.append((layer, srcs, y16, affine, stats, z16))
         return z16
 
+    def _heads_fast(self, layer: _Layer) -> bool:
+        return (self.precision == "mixed" and not layer.norm and layer.ksize == 1 and layer.cout == 5 and layer.cin == 32 and
+                os.environ.get("SK_TRAIN_HEADS_F32") is None)
+
+    def _block_heads_mixed(self, layer: _Layer, srcs, out_shape) -> Tensor:
+        """1x1x1 heads straight on the fp16 activation (an HBM stream: no fp32 copy of the last feature map)."""
+        z16 = srcs[0][0]
+        B = z16.shape[0]
+        ox, oy, oz = out_shape
+        logits = torch.empty((B, ox, oy, oz, 5), dtype=torch.float32, device=self.device)
+        _ffi.check(_ffi.lib.sk_train_heads_fwd_f16(_ffi.ptr(z16), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
+                                                   _ffi.ptr(logits), B * ox * oy * oz, _ffi.stream_ptr(self.device)))
+        self._tape.append((layer, srcs, logits, None, None, logits))
+        return logits
+
     def _block(self, layer: _Layer, srcs: List[Tuple[Tensor, int]], out_shape: Tuple[int, int, int],
                want32: bool = False) -> Tensor:
         if self._stem_fast(layer, srcs, out_shape):
             return self._block_stem_mixed(layer, srcs, out_shape)
+        if self._heads_fast(layer) and srcs[0][0].dtype == torch.float16:
+            return self._block_heads_mixed(layer, srcs, out_shape)
         if self._fast(layer, srcs):
             return self._block_mixed(layer, srcs, out_shape, want32)
         z = self._block_fp32(layer, srcs, out_shape)
@@ -298,7 +315,8 @@ class TrainUNet:
             a = self._block(l, [(s1, 0), (r1, 1)] if i == 0 else [(a, 0)], L1)
         r0 = self._block(self.red0, [(a, 0)], L1)
         for i, l in enumerate(self.dec0):
-            a = self._block(l, [(s0, 0), (r0, 1)] if i == 0 else [(a, 0)], L0, want32=(i == len(self.dec0) - 1))
+            a = self._block(l, [(s0, 0), (r0, 1)] if i == 0 else [(a, 0)], L0,
+                            want32=(i == len(self.dec0) - 1 and not self._heads_fast(self.heads)))
         return self._block(self.heads, [(a, 0)], L0)
 
     def backward(self, dlogits: Tensor) -> None:
@@ -359,10 +377,17 @@ class TrainUNet:
                                                              _ffi.ptr(layer.gamma), B, vox, cout, GN_GROUPS, _ffi.ptr(dz),
                                                              _ffi.ptr(layer.g_gamma), _ffi.ptr(layer.g_beta), _ffi.ptr(ws), st))
                 dy = dz
-                ws = self._workspace(_ffi.lib.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, cout, layer.cin, layer.ksize))
-                _ffi.check(_ffi.lib.sk_train_conv_wgrad(self._srcs(srcs), len(srcs), _ffi.ptr(dy), B, ox, oy, oz, cout,
-                                                        layer.ksize, _ffi.ptr(layer.g_weight), _ffi.ptr(layer.g_bias),
-                                                        _ffi.ptr(ws), st))
+                if srcs[0][0].dtype == torch.float16:   # the heads on the fp16 activation (_block_heads_mixed)
+                    nv = B * vox
+                    ws = self._workspace(_ffi.lib.sk_train_heads_wgrad_workspace_floats(nv))
+                    _ffi.check(_ffi.lib.sk_train_heads_wgrad_f16(_ffi.ptr(srcs[0][0]), _ffi.ptr(dy), _ffi.ptr(layer.g_weight),
+                                                                 _ffi.ptr(layer.g_bias), nv, _ffi.ptr(ws), st))
+                else:
+                    ws = self._workspace(_ffi.lib.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, cout, layer.cin,
+                                                                                       layer.ksize))
+                    _ffi.check(_ffi.lib.sk_train_conv_wgrad(self._srcs(srcs), len(srcs), _ffi.ptr(dy), B, ox, oy, oz, cout,
+                                                            layer.ksize, _ffi.ptr(layer.g_weight), _ffi.ptr(layer.g_bias),
+                                                            _ffi.ptr(ws), st))
             lo = 0
             for t, up in srcs:
                 c = t.shape[-1]
