@@ -129,6 +129,57 @@ def test_gn_silu_backward(ffi, B, sp, Cc):
     _close(db, beta.grad, 2e-4, "dbeta")
 
 
+@pytest.mark.parametrize("B,sp,Cc,dzh", [(1, (40, 30, 8), 32, False), (1, (40, 30, 8), 32, True), (2, (12, 10, 8), 64, True),
+                                         (1, (9, 8, 8), 128, False)])
+def test_gn_silu_backward_fp16(ffi, B, sp, Cc, dzh):
+    """Mixed-precision GroupNorm + SiLU backward (8 channels per lane, several reduction blocks): raw fp16 y, dz fp32 or
+    itself a scaled fp16 tensor (the hand-off between fast blocks) -> scaled fp16 dy, dgamma, dbeta vs torch autograd."""
+    gen = torch.Generator().manual_seed(Cc + sp[0] + int(dzh))
+    y = ((torch.randn((B, Cc) + sp, generator=gen) * 1.5 + 0.3).half().float()).requires_grad_(True)   # exactly fp16
+    gamma = (torch.rand(Cc, generator=gen) + 0.5).requires_grad_(True)
+    beta = (torch.rand(Cc, generator=gen) * 0.6 - 0.3).requires_grad_(True)
+    dz = torch.randn((B, Cc) + sp, generator=gen) * 1e-3
+    k = 2.0 ** 12
+    if dzh:
+        dz = (dz * k).half().float() / k          # exactly representable as a scaled fp16 tensor
+    z = F.silu(F.group_norm(y, 8, gamma, beta, 1e-5))
+    z.backward(dz)
+    dev = torch.device(DEV)
+    y16 = _cl(y.detach()).half().to(dev)
+    g = y.detach().double().reshape(B, 8, -1)
+    mean = g.mean(-1)
+    rstd = 1.0 / (g.var(-1, unbiased=False) + 1e-5).sqrt()
+    stats = torch.stack([mean, rstd], dim=-1).float().to(dev).contiguous()
+    a = (gamma.detach().double().reshape(1, 8, -1) * rstd[:, :, None]).reshape(B, Cc)
+    b = beta.detach().double()[None] - (mean[:, :, None].expand(B, 8, Cc // 8).reshape(B, Cc)) * a
+    affine = torch.stack([a, b], dim=1).float().to(dev).contiguous()
+    vox = sp[0] * sp[1] * sp[2]
+    st = ffi.stream_ptr(dev)
+    gd = gamma.detach().to(dev)
+    dy16 = torch.empty_like(y16)
+    scale = torch.empty(3, device=dev)
+    dg, db = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+    ws = torch.empty(int(ffi.lib.sk_train_gn_bwd_f16_workspace_floats(B, vox, Cc)), device=dev)
+    if dzh:
+        dz16 = (_cl(dz) * k).half().to(dev)
+        dzs = torch.tensor([k, 1.0 / k, 0.0], device=dev)
+        ffi.check(ffi.lib.sk_train_gn_silu_bwd_f16h(ffi.ptr(dz16), ffi.ptr(dzs), ffi.ptr(y16), ffi.ptr(affine), ffi.ptr(stats),
+                                                    ffi.ptr(gd), B, vox, Cc, 8, ffi.ptr(dy16), ffi.ptr(scale), ffi.ptr(dg),
+                                                    ffi.ptr(db), ffi.ptr(ws), st))
+    else:
+        dzc = _cl(dz).to(dev)
+        ffi.check(ffi.lib.sk_train_gn_silu_bwd_f16(ffi.ptr(dzc), ffi.ptr(y16), ffi.ptr(affine), ffi.ptr(stats), ffi.ptr(gd), B,
+                                                   vox, Cc, 8, ffi.ptr(dy16), ffi.ptr(scale), ffi.ptr(dg), ffi.ptr(db),
+                                                   ffi.ptr(ws), st))
+    sc = scale.cpu()
+    assert sc[0].item() * sc[1].item() == 1.0 and sc[0].item() >= 1.0      # a power of two and its inverse
+    got = _cf(dy16.float().cpu()) * sc[1].item()
+    assert dy16.float().abs().max().item() < 65504 / 4                      # the bound kept the scaled tensor in range
+    _close(got, y.grad, 2e-3, "dy (fp16, unscaled)")
+    _close(dg, gamma.grad, 3e-4, "dgamma")
+    _close(db, beta.grad, 3e-4, "dbeta")
+
+
 # ----------------------------------------------------------------------------- conv backward
 BWD_CASES = [
     # (B, out spatial, [(c, up)], cout, ksize)
