@@ -382,6 +382,10 @@ int sk_train_stem_wgrad_f16(const float* image, const void* dy16, const float* d
 /* Heads of the mixed step on the fp16 activation z16 (nvox, 32): logits (nvox, 5) fp32 = z W^T + b with W (5, 32);
  * weight / bias gradients from z16 and dlogits (nvox, 5) fp32 (deterministic two-stage reduction; workspace:
  * sk_train_heads_wgrad_workspace_floats(nvox) floats).  nvox counts the voxels of all batch items. */
+/* sk_train_interleave2_add16: sk_train_interleave2 (no accumulate) plus a second scaled fp16 gradient of the same fine
+ * tensor, add16 (B, 2cx, 2cy, 2cz, C) * add_scale[1] -- the two contributions to a skip tensor in one pass. */
+int sk_train_interleave2_add16(const void* t16, const void* add16, const float* add_scale, float* dx, int B, int cx,
+                               int cy, int cz, int C, const float* scale, void* stream);
 int sk_train_heads_fwd_f16(const void* z16, const float* weight, const float* bias, float* logits, int64_t nvox,
                            void* stream);
 int64_t sk_train_heads_wgrad_workspace_floats(int64_t nvox);

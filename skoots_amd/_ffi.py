@@ -102,6 +102,7 @@ _SIGS = {
     "sk_train_sumpool2": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "sk_train_gn_silu_bwd_f16h": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp, vp]),
     "sk_train_sumpool2_f16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "sk_train_interleave2_add16": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "sk_train_heads_fwd_f16": (i32, [vp, vp, vp, vp, i64, vp]),
     "sk_train_heads_wgrad_workspace_floats": (i64, [i64]),
     "sk_train_heads_wgrad_f16": (i32, [vp, vp, vp, vp, i64, vp, vp]),

@@ -1471,9 +1471,12 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(PackArgs a) {
 
 // Data gradient of a k = 2, stride-2 conv from its eight per-parity pointwise products: t16 (8, B, cx, cy, cz, C)
 // holds T_p[c] = W_p^T dY[c]; dX[2c + p] (+)= T_p[c] * scale[1].
+// add16 (optional): another scaled fp16 gradient of the same fine tensor (the decoder's contribution to a skip tensor,
+// scale add_scale), summed in here instead of through an fp32 copy + accumulate pass
 __global__ void __launch_bounds__(256) interleave2_kernel(const __half* __restrict__ t16, float* __restrict__ dx, int B,
                                                           int cx, int cy, int cz, int C, const float* __restrict__ scale,
-                                                          int accumulate) {
+                                                          int accumulate, const __half* __restrict__ add16,
+                                                          const float* __restrict__ add_scale) {
     // 8 channels per lane: one 16-byte load of the parity tensor, two 16-byte stores (+ loads when accumulating)
     const float s = scale ? scale[1] : 1.0f;
     const int nq = C / 8;
@@ -1494,6 +1497,12 @@ __global__ void __launch_bounds__(256) interleave2_kernel(const __half* __restri
         float4 v0 = {(float)h[0] * s, (float)h[1] * s, (float)h[2] * s, (float)h[3] * s};
         float4 v1 = {(float)h[4] * s, (float)h[5] * s, (float)h[6] * s, (float)h[7] * s};
         float4* o = reinterpret_cast<float4*>(dx + i * 8);
+        if (add16) {
+            const float as = add_scale[1];
+            const half8_t g = *reinterpret_cast<const half8_t*>(add16 + i * 8);
+            v0 = {fmaf((float)g[0], as, v0.x), fmaf((float)g[1], as, v0.y), fmaf((float)g[2], as, v0.z), fmaf((float)g[3], as, v0.w)};
+            v1 = {fmaf((float)g[4], as, v1.x), fmaf((float)g[5], as, v1.y), fmaf((float)g[6], as, v1.z), fmaf((float)g[7], as, v1.w)};
+        }
         if (accumulate) {
             const float4 p0 = o[0], p1 = o[1];
             v0 = {p0.x + v0.x, p0.y + v0.y, p0.z + v0.z, p0.w + v0.w};
@@ -2070,15 +2079,28 @@ int sk_train_pack_weight(const float* weight, int Co, int Ci, int ksize, int tra
     return SK_OK;
 }
 
-int sk_train_interleave2(const void* t16, float* dx, int B, int cx, int cy, int cz, int C, const float* scale, int accumulate,
-                         void* stream) {
+static int interleave2_impl(const void* t16, const void* add16, const float* add_scale, float* dx, int B, int cx, int cy, int cz,
+                            int C, const float* scale, int accumulate, void* stream) {
     SK_CHECK_ARG(t16 && dx && B >= 1 && cx >= 1 && cy >= 1 && cz >= 1 && C >= 8 && C % 8 == 0,
                  "sk_train_interleave2: bad arguments (C must be a multiple of 8)");
+    SK_CHECK_ARG(!add16 || add_scale, "sk_train_interleave2_add16: add_scale is NULL");
     long long n = (long long)B * cx * cy * cz * C;   // fine voxels x channel octets = coarse voxels x C
     interleave2_kernel<<<sk::stream_grid(n, 256, 2), 256, 0, (hipStream_t)stream>>>((const __half*)t16, dx, B, cx, cy, cz, C, scale,
-                                                                                    accumulate ? 1 : 0);
+                                                                                    accumulate ? 1 : 0, (const __half*)add16,
+                                                                                    add_scale);
     SK_CHECK_LAUNCH();
     return SK_OK;
+}
+
+int sk_train_interleave2(const void* t16, float* dx, int B, int cx, int cy, int cz, int C, const float* scale, int accumulate,
+                         void* stream) {
+    return interleave2_impl(t16, nullptr, nullptr, dx, B, cx, cy, cz, C, scale, accumulate, stream);
+}
+
+int sk_train_interleave2_add16(const void* t16, const void* add16, const float* add_scale, float* dx, int B, int cx, int cy,
+                               int cz, int C, const float* scale, void* stream) {
+    SK_CHECK_ARG(add16, "sk_train_interleave2_add16: add16 is NULL");
+    return interleave2_impl(t16, add16, add_scale, dx, B, cx, cy, cz, C, scale, 0, stream);
 }
 
 int sk_train_gn_silu_f16(const void* y16, const float* affine, void* z16, float* z32, int B, int64_t voxels, int C,

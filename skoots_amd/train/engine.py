@@ -332,6 +332,8 @@ class TrainUNet:
             for t_, _up in srcs_:
                 n_readers[t_.data_ptr()] = n_readers.get(t_.data_ptr(), 0) + 1
         fast_out = {e[5].data_ptr() for e in self._tape if e[2].dtype == torch.float16}
+        k2_read = {t_.data_ptr() for l_, srcs_, y_, *_r in self._tape if l_.ksize == 2 and y_.dtype == torch.float16
+                   for t_, _u in srcs_}
         for layer, srcs, y, affine, stats, out in reversed(self._tape):
             dz = grads.pop(out.data_ptr())
             B, ox, oy, oz, cout = y.shape
@@ -341,7 +343,7 @@ class TrainUNet:
             dz_scale = None
             if isinstance(dz, tuple):
                 dz, dz_scale = dz
-                assert fast
+                assert fast and n_readers.get(out.data_ptr(), 0) == 1, "a pending fp16 gradient was never summed"
             if fast:
                 # GroupNorm + SiLU backward straight to the scaled fp16 output gradient (no fp32 dy, no max / cast passes)
                 ws = self._workspace(max(_ffi.lib.sk_train_gn_bwd_f16_workspace_floats(B, vox, cout),
@@ -400,7 +402,9 @@ class TrainUNet:
                 if layer.ksize == 2 and fast:
                     # stride-2 data gradient: eight pointwise products W_p^T dY on the fast kernel, one per parity of the
                     # fine voxel, then interleaved into the fine grid
-                    have = key in grads
+                    pend = grads.get(key)
+                    pend = pend if isinstance(pend, tuple) else None   # the decoder's fp16 contribution, not yet summed
+                    have = key in grads and pend is None
                     if not have:
                         grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
                     packed = self._pack(layer, 2, 0, c)
@@ -410,8 +414,13 @@ class TrainUNet:
                         _ffi.check(_ffi.lib.sk_conv3d(self._srcs([(dy16, 0)]), 1, _ffi.ptr(packed[par * per:(par + 1) * per]),
                                                       _ffi.ptr(self._zero_bias), _ffi.ptr(t16[par]), B, ox, oy, oz, c, 1, None,
                                                       _ffi.ptr(self._zero_page), st))
-                    _ffi.check(_ffi.lib.sk_train_interleave2(_ffi.ptr(t16), _ffi.ptr(grads[key]), B, ox, oy, oz, c,
-                                                             _ffi.ptr(scale), int(have), st))
+                    if pend is not None:
+                        _ffi.check(_ffi.lib.sk_train_interleave2_add16(_ffi.ptr(t16), _ffi.ptr(pend[0]), _ffi.ptr(pend[1]),
+                                                                       _ffi.ptr(grads[key]), B, ox, oy, oz, c, _ffi.ptr(scale),
+                                                                       st))
+                    else:
+                        _ffi.check(_ffi.lib.sk_train_interleave2(_ffi.ptr(t16), _ffi.ptr(grads[key]), B, ox, oy, oz, c,
+                                                                 _ffi.ptr(scale), int(have), st))
                 elif layer.ksize == 2:
                     have = key in grads
                     if not have:
@@ -428,7 +437,10 @@ class TrainUNet:
                         grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
                         _ffi.check(_ffi.lib.sk_train_sumpool2_f16(_ffi.ptr(dx16), _ffi.ptr(scale), _ffi.ptr(grads[key]), B,
                                                                   ox // 2, oy // 2, oz // 2, c, st))
-                    elif n_readers.get(key, 0) == 1 and key in fast_out and os.environ.get("SK_TRAIN_F32_GRADS") is None:
+                    elif (key in fast_out and key not in grads and os.environ.get("SK_TRAIN_F32_GRADS") is None and
+                          (n_readers.get(key, 0) == 1 or (n_readers.get(key, 0) == 2 and key in k2_read))):
+                        # single reader: handed to the GroupNorm backward as it is; a skip tensor whose other reader is a
+                        # fast stride-2 conv (processed later): summed inside that conv's interleave pass
                         grads[key] = (dx16, scale)
                     else:
                         have = key in grads
