@@ -240,6 +240,33 @@ int sk_heads(const void* x, const float* affine, const float* weight, const floa
              int B, int X, int Y, int Z, int C, const int* box_lo_host, const int* box_hi_host,
              void* stream);
 
+/* "split" precision mode: every activation is a pair of fp16 tensors hi + lo interleaved per voxel,
+ * (B, x, y, z, 2C) = [hi (C) | lo (C)], value = hi + lo (~22 significant bits); weights are split the same way.
+ * A product runs as three fp16 MFMAs with fp32 accumulation: w_lo*x_hi + w_hi*x_hi + w_hi*x_lo (the dropped
+ * lo*lo term is ~2^-22 relative).  Meets the max-abs 1e-3 tolerance BASELINE.json's north_star states against
+ * the fp32 oracle (the plain fp16-operand path sits at 4-7e-3, the reference's own fp16 autocast at eval.py:142
+ * likewise) at ~3x the matrix-core work of the fp16 path instead of the 11x of the exact-fp32 instruction.
+ * Same semantics as the entry points without the suffix; `c` of a source is its LOGICAL channel count,
+ * sources must be activated (affine == NULL). */
+int sk_conv3d_split(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias,
+                    void* out, int B, int ox, int oy, int oz, int cout, int ksize,
+                    float* gn_partial, void* zero_page, void* stream);
+/* HOST: torch-layout fp32 weight -> fragments for sk_conv3d_split (ksize 3: [lo, hi, hi] chunk triples of an
+ * expanded 3*cin contraction; ksize 1 / 2: hi fragments then lo fragments).  Bytes needed / written. */
+int64_t sk_conv3d_pack_weight_split_host(const float* w_host, int cout, int cin, int ksize,
+                                         void* dst_host);
+/* sk_conv3d_stem_apply storing the activation as a split pair: out (B, Xt, Yt, Zt, 64). */
+int sk_conv3d_stem_apply_split(int B, int Xt, int Yt, int Zt, const float* weight, const float* bias,
+                               const float* affine, void* out, int cout, const void* workspace,
+                               void* stream);
+/* Fused GroupNorm affine + SiLU in place on a split tensor (B, voxels, 2C), fp32 arithmetic. */
+int sk_groupnorm_silu_split(void* x, const float* affine, int B, int64_t voxels, int C, void* stream);
+/* sk_heads on a split tensor x (B, X, Y, Z, 2C); out5 stays (B, 5, X, Y, Z) fp16 (the reference's
+ * autocast output dtype, eval.py:142-147). */
+int sk_heads_split(const void* x, const float* affine, const float* weight, const float* bias,
+                   void* out5, int B, int X, int Y, int Z, int C, const int* box_lo_host,
+                   const int* box_hi_host, void* stream);
+
 /* fp32 precision mode (parity reference of the fast path): the same layers with fp32 activations
  * (B, x, y, z, C) and torch-layout fp32 weights (cout, cin, k, k, k) on the exact-fp32 matrix
  * instruction.  Same source / upsample / concat semantics and GroupNorm partial layout as

@@ -74,6 +74,11 @@ _SIGS = {
     "sk_groupnorm_finalize": (i32, [vp, i32, i32, i32, i32, i64, vp, vp, f32, vp, vp]),
     "sk_groupnorm_silu": (i32, [vp, vp, i32, i64, i32, vp]),
     "sk_heads": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, ip, ip, vp]),
+    "sk_conv3d_split": (i32, [C.POINTER(ConvSrc), i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "sk_conv3d_pack_weight_split_host": (i64, [fp, i32, i32, i32, vp]),
+    "sk_conv3d_stem_apply_split": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
+    "sk_groupnorm_silu_split": (i32, [vp, vp, i32, i64, i32, vp]),
+    "sk_heads_split": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, ip, ip, vp]),
     "sk_conv3d_f32": (i32, [C.POINTER(ConvSrc), i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "sk_conv3d_f32_num_blocks": (i32, [i32, i32, i32]),
     "sk_groupnorm_silu_f32": (i32, [vp, vp, i32, i64, i32, vp]),

@@ -49,6 +49,7 @@ constexpr int kPatch = 128;      // voxels per (y,z) patch = 4 waves x 32 column
 constexpr int kMaxDma = 4;       // DMA wave-instructions per plane per wave (nposp <= 256)
 constexpr int kPadStride = 64;   // bytes per voxel in the epilogue transpose pad (16-B chunks XOR-swizzled)
 constexpr int kPadBytes = 32 * kPadStride;
+constexpr int kMaxChunks = 16;   // phase chunks per step: 4 plain (128 channels) or 12 split (3 per 32 channels)
 
 struct SrcDev {
     const char* data;
@@ -72,8 +73,19 @@ struct Conv3Args {
     int mode;           // 0: linear (y,z) ranges (small Zt), 1: TY x TZ rectangles
     int TZ, nzc;
     int pitch, nposp;
-    int ablate;         // timing experiments only (SK_CONV_ABLATE): 1 skip DMA, 2 reuse first weights, 4 skip stores
+    int ablate;         // timing experiments only (-DSK_TUNING builds, SK_CONV_ABLATE): 1 skip DMA, 2 reuse first weights, 4 skip stores
+    // per phase chunk: bit 0 = source, bit 1 = "same LDS image as the previous chunk: no DMA", bits 8.. = byte offset of
+    // the chunk inside the source's voxel line
+    unsigned chinfo[kMaxChunks];
 };
+
+// Timing experiments (wrong results by design) exist only in the -DSK_TUNING build that tools/ use: in the release
+// library no environment variable can change what a kernel computes.
+#ifdef SK_TUNING
+#define SK_ABL(a, bits) ((a).ablate & (bits))
+#else
+#define SK_ABL(a, bits) 0
+#endif
 
 __device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -91,7 +103,7 @@ __device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
 // (Keeping chunk 0's rows resident in a two-chunk layer, selected at run time per phase, spills: 1.8x slower;
 // requesting a whole row of streamed fragments two bodies ahead instead of one measured 4 % slower.)
 // Measured A/B on one device: -4..5 % time on enc0.1 / dec0.1.
-template <int COUT, int XS, int RES = 0>
+template <int COUT, int XS, int RES = 0, bool SPLIT = false>
 __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     constexpr int NT = COUT / 32;
     constexpr int P = NT;            // column tiles per wave
@@ -110,7 +122,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     // share their y/z halo and consecutive x-chunks share two planes: give each XCD a contiguous
     // run of the (batch, x-chunk, patch) order so those re-reads hit its own L2 (bijective remap).
     int blk = blockIdx.x;
-    if (!(a.ablate & 16)) {
+    if (!SK_ABL(a, 16)) {
         const int nwg = gridDim.x, xcd = blk & 7, qn = nwg >> 3, rn = nwg & 7;
         blk = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blk >> 3);
     }
@@ -200,7 +212,9 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     const int plane_bytes = (a.nposp + 1) * kPosBytes;  // + the zero position (never written by the DMA)
     const int zero_addr = a.nposp * kPosBytes;
     const bool ring = (a.nchunks == 1);
-    const long long out_plane = (long long)a.Yt * a.Zt * COUT * 2;
+    // SPLIT: the output voxel line is [hi (COUT fp16) | lo (COUT fp16)], value = hi + lo (~22 significant bits)
+    constexpr int kOvs = COUT * 2 * (SPLIT ? 2 : 1);   // bytes per output voxel
+    const long long out_plane = (long long)a.Yt * a.Zt * kOvs;
     char* outb = a.out + (long long)b * a.Xt * out_plane;
 
     // bias as the initial accumulator: row (cout) = 32*wn + (r&3) + 8(r>>2) + 4h
@@ -227,11 +241,12 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
 
     auto issue_dma = [&](int step, int ch) {
         const int x0 = xa + step * XS;
-        const int si = ch < a.c0chunks ? 0 : 1;
+        const unsigned ci = a.chinfo[ch];
+        const int si = ci & 1;
         const SrcDev s = a.src[si];
-        const int choff = (ch - (si ? a.c0chunks : 0)) * kChunk * 2;  // byte offset of the chunk
+        const int choff = ci >> 8;  // byte offset of the chunk in the voxel line
         const int first_new = (ring && step > 0) ? 2 : 0;  // planes 0,1 survive in the ring
-        for (int i = (a.ablate & 1) ? R : first_new; i < R; ++i) {
+        for (int i = SK_ABL(a, 1) ? R : first_new; i < R; ++i) {
             const int x = x0 - 1 + i;
             const int slotp = ring ? (step * XS + i) % R : i;
             const bool xok = x >= 0 && x < a.Xt;
@@ -315,7 +330,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             constexpr int kTapUnroll = (NT <= 2) ? 9 : 1;
 #pragma unroll kTapUnroll
             for (int dydz = 0; dydz < 9; ++dydz) {
-                const char* wrow = wch + (long long)(((a.ablate & 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
+                const char* wrow = wch + (long long)((SK_ABL(a, 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
                 if constexpr (RES > 0) {
                     if (dydz < RES) {
                         compute(dydz, 0, wres[2 * dydz]);
@@ -328,13 +343,13 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                         continue;
                     }
                 }
-                if (!(a.ablate & 32) || dydz == 0) {
+                if (!SK_ABL(a, 32) || dydz == 0) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
                         a1[d] = *reinterpret_cast<const half8*>(wrow + ((3 + d) * NT) * 1024);
                 }
                 compute(dydz, 0, a0);
-                if (dydz < 8 && !(a.ablate & 32)) {
+                if (dydz < 8 && !SK_ABL(a, 32)) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
                         a0[d] = *reinterpret_cast<const half8*>(wrow + ((6 + d) * NT) * 1024);
@@ -353,7 +368,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
         const bool have_next = ph + 1 < nphases;
         __syncthreads();  // every wave is done reading the planes about to be overwritten
         if (have_next) {
-            issue_dma(nstep, nch);
+            if (!(a.chinfo[nch] & 2)) issue_dma(nstep, nch);   // bit 1: the next chunk multiplies the SAME staged planes
             if constexpr (RES == 0) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(nch) + (d * NT) * 1024);
@@ -365,7 +380,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             // epilogue's transposes and the stores still drain under the next phase's MFMAs.
             // Measured per layer (same device, A/B): -4 % time for COUT 32, +4 % for COUT 64 (two column tiles per
             // wave: a longer epilogue), neutral for COUT 128 -> late wait for NT != 2 only.
-            if (!kLateWait || !step_done || a.ablate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!kLateWait || !step_done || SK_ABL(a, ~0)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 
         // ---------------- epilogue (overlaps the DMA): raw fp16 store + GroupNorm partials ------
@@ -382,30 +397,36 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                     const int x = x0 + o;
                     const bool ok = vvalid[p] && x < xb;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float v0 = acc[p][o][4 * q], v1 = acc[p][o][4 * q + 1];
-                        float v2 = acc[p][o][4 * q + 2], v3 = acc[p][o][4 * q + 3];
-                        half4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-                        *reinterpret_cast<half4*>(pad + col * kPadStride + ((q ^ ((col >> 1) & 3)) * 16) + 8 * h) = hv;
-                        if (ok) {
-                            gsum[q] += (v0 + v1) + (v2 + v3);
-                            gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-                        }
-                    }
-                    if (!(a.ablate & 4)) {
-                        char* op = outb + (long long)x * out_plane + tile_vox0 * (COUT * 2) + wn * 64;
+                    for (int part = 0; part < (SPLIT ? 2 : 1); ++part) {   // SPLIT: the hi halves, then the lo halves
 #pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
-                            const int vv = rv + 16 * hh;
-                            const half8 line = *reinterpret_cast<const half8*>(
-                                pad + vv * kPadStride + ((rc ^ ((vv >> 1) & 3)) * 16));
-                            const bool sok = x < xb && tile_vox0 + vv < tile_nvox[p];
-                            if constexpr (kLateWait) {
-                                // always issued (the counted wait below relies on it); masked lanes hit the scratch line
-                                char* dst = sok ? op + (long long)vv * (COUT * 2) + rc * 16 : trash;
-                                *reinterpret_cast<half8*>(dst) = line;
-                            } else if (sok) {
-                                *reinterpret_cast<half8*>(op + (long long)vv * (COUT * 2) + rc * 16) = line;
+                        for (int q = 0; q < 4; ++q) {
+                            float v0 = acc[p][o][4 * q], v1 = acc[p][o][4 * q + 1];
+                            float v2 = acc[p][o][4 * q + 2], v3 = acc[p][o][4 * q + 3];
+                            half4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+                            if (part == 1)   // lo = fp16(v - hi): exact difference, rounded once
+                                hv = half4{(_Float16)(v0 - (float)hv[0]), (_Float16)(v1 - (float)hv[1]),
+                                           (_Float16)(v2 - (float)hv[2]), (_Float16)(v3 - (float)hv[3])};
+                            *reinterpret_cast<half4*>(pad + col * kPadStride + ((q ^ ((col >> 1) & 3)) * 16) + 8 * h) = hv;
+                            if (ok && part == 0) {
+                                gsum[q] += (v0 + v1) + (v2 + v3);
+                                gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                            }
+                        }
+                        if (!SK_ABL(a, 4)) {
+                            char* op = outb + (long long)x * out_plane + tile_vox0 * kOvs + wn * 64 + part * (COUT * 2);
+#pragma unroll
+                            for (int hh = 0; hh < 2; ++hh) {
+                                const int vv = rv + 16 * hh;
+                                const half8 line = *reinterpret_cast<const half8*>(
+                                    pad + vv * kPadStride + ((rc ^ ((vv >> 1) & 3)) * 16));
+                                const bool sok = x < xb && tile_vox0 + vv < tile_nvox[p];
+                                if constexpr (kLateWait) {
+                                    // always issued (the counted wait below relies on it); masked lanes hit the scratch line
+                                    char* dst = sok ? op + (long long)vv * kOvs + rc * 16 : trash;
+                                    *reinterpret_cast<half8*>(dst) = line;
+                                } else if (sok) {
+                                    *reinterpret_cast<half8*>(op + (long long)vv * kOvs + rc * 16) = line;
+                                }
                             }
                         }
                     }
@@ -413,8 +434,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             }
         }
         if (have_next) {
-            if (kLateWait && step_done && !a.ablate) {
-                constexpr int kStores = P * XS * 2;  // global stores the epilogue just issued
+            if (kLateWait && step_done && !SK_ABL(a, ~0)) {
+                constexpr int kStores = P * XS * 2 * (SPLIT ? 2 : 1);  // global stores the epilogue just issued
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -467,7 +488,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
 // (Keeping chunk 0's rows resident in a two-chunk layer, selected at run time per phase, spills: 1.8x slower;
 // requesting a whole row of streamed fragments two bodies ahead instead of one measured 4 % slower.)
 // Measured A/B on one device: -4..5 % time on enc0.1 / dec0.1.
-template <int COUT, int XS, int RES = 0>
+template <int COUT, int XS, int RES = 0, bool SPLIT = false>
 __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     constexpr int NT = COUT / 32;
     constexpr int P = NT;            // column tiles per wave
@@ -488,7 +509,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     // share their y/z halo and consecutive x-chunks share two planes: give each XCD a contiguous
     // run of the (batch, x-chunk, patch) order so those re-reads hit its own L2 (bijective remap).
     int blk = blockIdx.x;
-    if (!(a.ablate & 16)) {
+    if (!SK_ABL(a, 16)) {
         const int nwg = gridDim.x, xcd = blk & 7, qn = nwg >> 3, rn = nwg & 7;
         blk = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blk >> 3);
     }
@@ -592,7 +613,9 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     const int plane_bytes = (a.nposp + 1) * kPosBytes;  // + the zero position (never written by the DMA)
     const int zero_addr = a.nposp * kPosBytes;
     const bool ring = (a.nchunks == 1);
-    const long long out_plane = (long long)a.Yt * a.Zt * COUT * 2;
+    // SPLIT: the output voxel line is [hi (COUT fp16) | lo (COUT fp16)], value = hi + lo (~22 significant bits)
+    constexpr int kOvs = COUT * 2 * (SPLIT ? 2 : 1);   // bytes per output voxel
+    const long long out_plane = (long long)a.Yt * a.Zt * kOvs;
     char* outb = a.out + (long long)b * a.Xt * out_plane;
 
     // bias is the initial accumulator: cout = 32 wn + 16 i + 4 g + r (re-read per step: 8 registers less in the loop)
@@ -611,11 +634,12 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
 
     auto issue_dma = [&](int step, int ch) {
         const int x0 = xa + step * XS;
-        const int si = ch < a.c0chunks ? 0 : 1;
+        const unsigned ci = a.chinfo[ch];
+        const int si = ci & 1;
         const SrcDev s = a.src[si];
-        const int choff = (ch - (si ? a.c0chunks : 0)) * kChunk * 2;  // byte offset of the chunk
+        const int choff = ci >> 8;  // byte offset of the chunk in the voxel line
         const int first_new = (ring && step > 0) ? 2 : 0;  // planes 0,1 survive in the ring
-        for (int i = (a.ablate & 1) ? R : first_new; i < R; ++i) {
+        for (int i = SK_ABL(a, 1) ? R : first_new; i < R; ++i) {
             const int x = x0 - 1 + i;
             const int slotp = ring ? (step * XS + i) % R : i;
             const bool xok = x >= 0 && x < a.Xt;
@@ -710,7 +734,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
             constexpr int kTapUnroll = (NT <= 1) ? 9 : 1;
 #pragma unroll kTapUnroll
             for (int dydz = 0; dydz < 9; ++dydz) {
-                const char* wrow = wch + (long long)(((a.ablate & 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
+                const char* wrow = wch + (long long)((SK_ABL(a, 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
                 if constexpr (RES > 0) {
                     if (dydz < RES) {
                         compute(dydz, 0, wres[2 * dydz]);
@@ -723,13 +747,13 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                         continue;
                     }
                 }
-                if (!(a.ablate & 32) || dydz == 0) {
+                if (!SK_ABL(a, 32) || dydz == 0) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
                         a1[d] = *reinterpret_cast<const half8*>(wrow + ((3 + d) * NT) * 1024);
                 }
                 compute(dydz, 0, a0);
-                if (dydz < 8 && !(a.ablate & 32)) {
+                if (dydz < 8 && !SK_ABL(a, 32)) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
                         a0[d] = *reinterpret_cast<const half8*>(wrow + ((6 + d) * NT) * 1024);
@@ -748,7 +772,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
         const bool have_next = ph + 1 < nphases;
         __syncthreads();  // every wave is done reading the planes about to be overwritten
         if (have_next) {
-            issue_dma(nstep, nch);
+            if (!(a.chinfo[nch] & 2)) issue_dma(nstep, nch);   // bit 1: the next chunk multiplies the SAME staged planes
             if constexpr (RES == 0) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(nch) + (d * NT) * 1024);
@@ -760,7 +784,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
             // epilogue's transposes and the stores still drain under the next phase's MFMAs.
             // Measured per layer (same device, A/B): -4 % time for COUT 32, +4 % for COUT 64 (two column tiles per
             // wave: a longer epilogue), neutral for COUT 128 -> late wait for NT != 2 only.
-            if (!kLateWait || !step_done || a.ablate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!kLateWait || !step_done || SK_ABL(a, ~0)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 
         // ---------------- epilogue (overlaps the DMA): raw fp16 store + GroupNorm partials ------
@@ -776,34 +800,40 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                 for (int o = 0; o < XS; ++o) {
                     const int x = x0 + o;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int part = 0; part < (SPLIT ? 2 : 1); ++part) {   // SPLIT: the hi halves, then the lo halves
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const f32x4 r = acc[p][o][i][j];
-                            half4 hv = {(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
-                            // voxel 16 j + c16, channels 16 i + 4 g .. +3 of the tile: 16-byte chunk 2 i + (g >> 1), half g & 1
-                            const int vx = 16 * j + c16;
-                            *reinterpret_cast<half4*>(pad + vx * kPadStride + (((2 * i + (g >> 1)) ^ ((vx >> 1) & 3)) * 16) +
-                                                      8 * (g & 1)) = hv;
-                            if (vvalid(p, j) && x < xb) {
-                                gsum[i] += (r[0] + r[1]) + (r[2] + r[3]);
-                                gsq[i] += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const f32x4 r = acc[p][o][i][j];
+                                half4 hv = {(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
+                                if (part == 1)   // lo = fp16(v - hi): exact difference, rounded once
+                                    hv = half4{(_Float16)(r[0] - (float)hv[0]), (_Float16)(r[1] - (float)hv[1]),
+                                               (_Float16)(r[2] - (float)hv[2]), (_Float16)(r[3] - (float)hv[3])};
+                                // voxel 16 j + c16, channels 16 i + 4 g .. +3 of the tile: 16-byte chunk 2 i + (g >> 1), half g & 1
+                                const int vx = 16 * j + c16;
+                                *reinterpret_cast<half4*>(pad + vx * kPadStride + (((2 * i + (g >> 1)) ^ ((vx >> 1) & 3)) * 16) +
+                                                          8 * (g & 1)) = hv;
+                                if (part == 0 && vvalid(p, j) && x < xb) {
+                                    gsum[i] += (r[0] + r[1]) + (r[2] + r[3]);
+                                    gsq[i] += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+                                }
                             }
-                        }
-                    if (!(a.ablate & 4)) {
-                        char* op = outb + (long long)x * out_plane + (long long)tile_vox0 * (COUT * 2) + wn * 64;
+                        if (!SK_ABL(a, 4)) {
+                            char* op = outb + (long long)x * out_plane + (long long)tile_vox0 * kOvs + wn * 64 + part * (COUT * 2);
 #pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
-                            const int vv = rv + 16 * hh;
-                            const half8 line = *reinterpret_cast<const half8*>(
-                                pad + vv * kPadStride + ((rc ^ ((vv >> 1) & 3)) * 16));
-                            const bool sok = x < xb && tile_vox0 + vv < tile_nvox[p];
-                            if constexpr (kLateWait) {
-                                // always issued (the counted wait below relies on it); masked lanes hit the scratch line
-                                char* dst = sok ? op + (long long)vv * (COUT * 2) + rc * 16 : trash;
-                                *reinterpret_cast<half8*>(dst) = line;
-                            } else if (sok) {
-                                *reinterpret_cast<half8*>(op + (long long)vv * (COUT * 2) + rc * 16) = line;
+                            for (int hh = 0; hh < 2; ++hh) {
+                                const int vv = rv + 16 * hh;
+                                const half8 line = *reinterpret_cast<const half8*>(
+                                    pad + vv * kPadStride + ((rc ^ ((vv >> 1) & 3)) * 16));
+                                const bool sok = x < xb && tile_vox0 + vv < tile_nvox[p];
+                                if constexpr (kLateWait) {
+                                    // always issued (the counted wait below relies on it); masked lanes hit the scratch line
+                                    char* dst = sok ? op + (long long)vv * kOvs + rc * 16 : trash;
+                                    *reinterpret_cast<half8*>(dst) = line;
+                                } else if (sok) {
+                                    *reinterpret_cast<half8*>(op + (long long)vv * kOvs + rc * 16) = line;
+                                }
                             }
                         }
                     }
@@ -811,8 +841,8 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
             }
         }
         if (have_next) {
-            if (kLateWait && step_done && !a.ablate) {
-                constexpr int kStores = P * XS * 2;  // global stores the epilogue just issued
+            if (kLateWait && step_done && !SK_ABL(a, ~0)) {
+                constexpr int kStores = P * XS * 2 * (SPLIT ? 2 : 1);  // global stores the epilogue just issued
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -869,9 +899,13 @@ struct GatherArgs {
     int nblk;
 };
 
-template <int COUT, int PV, int D>
+// SPLIT: input and output voxel lines are [hi | lo] fp16 pairs (value = hi + lo), the weights come as hi fragments
+// followed by lo fragments; per K step w_lo*x_hi + w_hi*x_lo + w_hi*x_hi (the dropped lo*lo term is ~2^-22 relative).
+template <int COUT, int PV, int D, bool SPLIT = false>
 __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
     constexpr int NT = COUT / 32;
+    constexpr int kOvs = COUT * 2 * (SPLIT ? 2 : 1);   // bytes per output voxel
+    const long long lstride = (long long)a.Cin * 2 * (SPLIT ? 2 : 1);   // bytes per input voxel
     __shared__ float red[4 * NT * 16];
     __shared__ float aff[2 * 128];   // silu(a*x + b) coefficients of this batch item (RAW input only)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -914,21 +948,29 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
         for (int i = tid; i < 2 * a.Cin; i += 256) aff[i] = a.affine[(long long)b * 2 * a.Cin + i];
         __syncthreads();
     }
-    const char* inb = a.in + (long long)b * a.Xi * a.Yi * a.Zi * a.Cin * 2;
+    const char* inb = a.in + (long long)b * a.Xi * a.Yi * a.Zi * lstride;
+    const char* wlo = a.wpk + (long long)nsteps * NT * 1024;   // SPLIT: the lo fragments follow the hi fragments
     // Software pipeline, D steps deep: the B fragments (16 B per lane straight from HBM, no reuse) and the weight
     // fragments of step s + D are requested before step s is multiplied -- a wave keeps D*(PV + NT) KiB in flight
     // instead of one load -> wait -> MFMA round trip per step.
     half8 afr[D][NT], bfr[D][PV];
+    half8 alo[SPLIT ? D : 1][NT], blo[SPLIT ? D : 1][PV];
 #define SK_GATHER_ISSUE(S, SLOT)                                                                              \
     {                                                                                                         \
         const int s_ = (S);                                                                                   \
         const int tap_ = s_ / nks, ks_ = s_ - tap_ * nks;                                                     \
         const int dx_ = tap_ / (a.ksize * a.ksize), dy_ = (tap_ / a.ksize) % a.ksize, dz_ = tap_ % a.ksize;   \
         const long long toff_ = ((long long)dx_ * a.Yi + dy_) * a.Zi + dz_;                                   \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) afr[SLOT][nt] =                                     \
-            *reinterpret_cast<const half8*>(a.wpk + ((long long)s_ * NT + nt) * 1024 + lane * 16);            \
-        _Pragma("unroll") for (int p = 0; p < PV; ++p) bfr[SLOT][p] = *reinterpret_cast<const half8*>(        \
-            inb + ((vin[p] + toff_) * a.Cin + ks_ * 16 + 8 * h) * 2);                                         \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                   \
+            afr[SLOT][nt] = *reinterpret_cast<const half8*>(a.wpk + ((long long)s_ * NT + nt) * 1024 + lane * 16); \
+            if constexpr (SPLIT)                                                                              \
+                alo[SLOT][nt] = *reinterpret_cast<const half8*>(wlo + ((long long)s_ * NT + nt) * 1024 + lane * 16); \
+        }                                                                                                     \
+        _Pragma("unroll") for (int p = 0; p < PV; ++p) {                                                      \
+            const char* src_ = inb + (vin[p] + toff_) * lstride + (ks_ * 16 + 8 * h) * 2;                     \
+            bfr[SLOT][p] = *reinterpret_cast<const half8*>(src_);                                             \
+            if constexpr (SPLIT) blo[SLOT][p] = *reinterpret_cast<const half8*>(src_ + a.Cin * 2);            \
+        }                                                                                                     \
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) SK_GATHER_ISSUE(d, d)
@@ -937,9 +979,13 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
 #define SK_GATHER_STEP(S, SLOT, PREFETCH)                                                                     \
     {                                                                                                         \
         const int s = (S);                                                                                    \
-        half8 av[NT], bv[PV];                                                                                 \
+        half8 av[NT], bv[PV], avl[NT], bvl[PV];                                                               \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) av[nt] = afr[SLOT][nt];                             \
         _Pragma("unroll") for (int p = 0; p < PV; ++p) bv[p] = bfr[SLOT][p];                                  \
+        if constexpr (SPLIT) {                                                                                \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) avl[nt] = alo[SLOT][nt];                        \
+            _Pragma("unroll") for (int p = 0; p < PV; ++p) bvl[p] = blo[SLOT][p];                             \
+        }                                                                                                     \
         if (PREFETCH) SK_GATHER_ISSUE(s + D, SLOT)                                                            \
         if (raw) { /* this lane's 8 input channels of the K step */                                           \
             const int c0 = (s % nks) * 16 + 8 * h;                                                            \
@@ -954,8 +1000,13 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
                 bv[p][j] = (_Float16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));                         \
             }                                                                                                 \
         }                                                                                                     \
-        _Pragma("unroll") for (int p = 0; p < PV; ++p) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)      \
+        _Pragma("unroll") for (int p = 0; p < PV; ++p) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {    \
+            if constexpr (SPLIT) {                                                                            \
+                acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[nt], bv[p], acc[p][nt], 0, 0, 0);     \
+                acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[nt], bvl[p], acc[p][nt], 0, 0, 0);     \
+            }                                                                                                 \
             acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[nt], bv[p], acc[p][nt], 0, 0, 0);          \
+        }                                                                                                     \
     }
     int s0 = 0;
     for (; s0 + D < nsteps; s0 += D) {
@@ -971,7 +1022,7 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) gsum[nt][q] = gsq[nt][q] = 0.0f;
-    char* outb = a.out + (long long)b * nvox * COUT * 2;
+    char* outb = a.out + (long long)b * nvox * kOvs;
 #pragma unroll
     for (int p = 0; p < PV; ++p) {
 #pragma unroll
@@ -982,7 +1033,13 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
                 float v2 = acc[p][nt][4 * q + 2], v3 = acc[p][nt][4 * q + 3];
                 if (ok[p]) {
                     half4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-                    *reinterpret_cast<half4*>(outb + (vout[p] * COUT + 32 * nt + 8 * q + 4 * h) * 2) = hv;
+                    char* dst = outb + vout[p] * kOvs + (32 * nt + 8 * q + 4 * h) * 2;
+                    *reinterpret_cast<half4*>(dst) = hv;
+                    if constexpr (SPLIT) {
+                        half4 lv = {(_Float16)(v0 - (float)hv[0]), (_Float16)(v1 - (float)hv[1]),
+                                    (_Float16)(v2 - (float)hv[2]), (_Float16)(v3 - (float)hv[3])};
+                        *reinterpret_cast<half4*>(dst + COUT * 2) = lv;
+                    }
                     gsum[nt][q] += (v0 + v1) + (v2 + v3);
                     gsq[nt][q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
                 }
@@ -1046,7 +1103,11 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
     p.lds = (size_t)(p.xs + 2) * (p.nposp + 1) * kPosBytes + 4 * kPadBytes;
     // Two workgroups per CU need <= 80 KiB each.  The rectangle patches (208 positions a plane) miss that with a
     // 6-plane ring: run them with XS = 3 (5 planes); measured on the 512x512x128 tile (SK_CONV_RECT_XS4=1 to compare).
-    if (p.xs == 4 && p.lds > 80 * 1024 && !getenv("SK_CONV_RECT_XS4")) {
+    bool keep_xs4 = false;
+#ifdef SK_TUNING
+    keep_xs4 = getenv("SK_CONV_RECT_XS4") != nullptr;
+#endif
+    if (p.xs == 4 && p.lds > 80 * 1024 && !keep_xs4) {
         p.xs = 3;
         p.lds = (size_t)(p.xs + 2) * (p.nposp + 1) * kPosBytes + 4 * kPadBytes;
     }
@@ -1057,16 +1118,21 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
     if (nxc > max_nxc) nxc = max_nxc;
     if (nxc < 1) nxc = 1;
     int XC = (Xt + nxc - 1) / nxc;
-    if (const char* e = getenv("SK_CONV_XC")) XC = atoi(e);  // tuning experiments
+#ifdef SK_TUNING
+    if (const char* e = getenv("SK_CONV_XC")) {  // tuning experiments
+        const int v = atoi(e);
+        if (v >= p.xs && v <= Xt + p.xs) XC = v;
+    }
+#endif
     XC = (XC + p.xs - 1) / p.xs * p.xs;
     p.XC = XC;
     p.nxc = (Xt + XC - 1) / XC;
     return 0;
 }
 
-template <int XS, int RES = 0>
+template <int XS, int RES = 0, bool SPLIT = false>
 int launch_conv3_m16(const Conv3Args& a, const Plan& p, hipStream_t stream) {
-    auto kern = conv3_m16_kernel<32, XS, RES>;
+    auto kern = conv3_m16_kernel<32, XS, RES, SPLIT>;
     if (p.lds > 48 * 1024)
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)p.lds));
@@ -1076,9 +1142,9 @@ int launch_conv3_m16(const Conv3Args& a, const Plan& p, hipStream_t stream) {
     return SK_OK;
 }
 
-template <int COUT, int XS, int RES = 0>
+template <int COUT, int XS, int RES = 0, bool SPLIT = false>
 int launch_conv3(const Conv3Args& a, const Plan& p, hipStream_t stream) {
-    auto kern = conv3_kernel<COUT, XS, RES>;
+    auto kern = conv3_kernel<COUT, XS, RES, SPLIT>;
     if (p.lds > 48 * 1024)
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)p.lds));
@@ -1154,10 +1220,11 @@ int64_t sk_conv3d_pack_weight_host(const float* w, int cout, int cin, int ksize,
     return nfrag * 1024;
 }
 
-int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,
-              int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial,
-              void* zeros, void* stream_) {
+static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,
+                       int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial,
+                       void* zeros, void* stream_, const bool split) {
     hipStream_t stream = (hipStream_t)stream_;
+    const int lanes = split ? 2 : 1;   // fp16 values per logical channel in a voxel line: [hi | lo]
     SK_CHECK_ARG(srcs && weight && bias && out, "sk_conv3d: NULL pointer");
     SK_CHECK_ARG(n_src == 1 || n_src == 2, "sk_conv3d: n_src must be 1 or 2");
     SK_CHECK_ARG(B > 0 && ox > 0 && oy > 0 && oz > 0, "sk_conv3d: bad output extents");
@@ -1178,17 +1245,33 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
                          "sk_conv3d: upsampled source needs even output extents");
             int xs = up ? ox / 2 : ox, ys = up ? oy / 2 : oy, zs = up ? oz / 2 : oz;
             a.src[i].data = (const char*)srcs[i].data;
-            a.src[i].C = srcs[i].c;
+            a.src[i].C = srcs[i].c * lanes;     // halves per voxel line
             a.src[i].up = up;
             a.src[i].Ys = ys;
             a.src[i].Zs = zs;
-            a.src[i].plane = (long long)ys * zs * srcs[i].c * 2;
+            a.src[i].plane = (long long)ys * zs * srcs[i].c * lanes * 2;
             a.src[i].batch = a.src[i].plane * xs;
             cin += srcs[i].c;
         }
         if (n_src == 1) a.src[1] = a.src[0];
-        a.nchunks = cin / kChunk;
         a.c0chunks = srcs[0].c / kChunk;
+        // phase chunks of a step.  Plain: the 32-channel chunks of the concatenated sources in order.  Split: per
+        // logical chunk three phases -- (x_hi, w_lo), (x_hi again: no DMA, w_hi), (x_lo, w_hi); the packed weight
+        // (sk_conv3d_pack_weight_split_host) holds the matching [lo, hi, hi] fragment sets in this order.
+        a.nchunks = 0;
+        for (int k = 0; k < cin / kChunk; ++k) {
+            const int si = k < a.c0chunks ? 0 : 1;
+            const unsigned off = (unsigned)(k - (si ? a.c0chunks : 0)) * kChunk * 2;
+            const unsigned lo_off = off + (unsigned)srcs[si].c * 2;
+            SK_CHECK_ARG(a.nchunks + (split ? 3 : 1) <= kMaxChunks, "sk_conv3d: too many input channels (%d)", cin);
+            if (!split) {
+                a.chinfo[a.nchunks++] = (unsigned)si | (off << 8);
+            } else {
+                a.chinfo[a.nchunks++] = (unsigned)si | (off << 8);
+                a.chinfo[a.nchunks++] = (unsigned)si | 2u | (off << 8);
+                a.chinfo[a.nchunks++] = (unsigned)si | (lo_off << 8);
+            }
+        }
         a.wpk = (const char*)weight;
         a.bias = bias;
         a.out = (char*)out;
@@ -1208,9 +1291,14 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
         a.nzc = p.nzc;
         a.pitch = p.pitch;
         a.nposp = p.nposp;
-        {
-            const char* e = getenv("SK_CONV_ABLATE");
-            a.ablate = e ? atoi(e) : 0;
+        a.ablate = 0;
+#ifdef SK_TUNING
+        if (const char* e = getenv("SK_CONV_ABLATE")) a.ablate = atoi(e);
+#endif
+        if (split) {
+            if (cout == 32) return p.xs == 3 ? launch_conv3_m16<3, 0, true>(a, p, stream) : launch_conv3_m16<4, 0, true>(a, p, stream);
+            if (cout == 64) return p.xs == 3 ? launch_conv3<64, 3, 0, true>(a, p, stream) : launch_conv3<64, 4, 0, true>(a, p, stream);
+            return launch_conv3<128, 2, 0, true>(a, p, stream);
         }
         if (cout == 32) {   // 16x16x32 kernel
             if (p.xs == 3) return launch_conv3_m16<3>(a, p, stream);
@@ -1223,6 +1311,7 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
     SK_CHECK_ARG(ksize == 1 || ksize == 2, "sk_conv3d: ksize must be 1, 2 or 3");
     SK_CHECK_ARG(n_src == 1 && !srcs[0].upsample, "sk_conv3d: ksize %d takes one plain source", ksize);
     SK_CHECK_ARG(srcs[0].c % 16 == 0, "sk_conv3d: cin must be a multiple of 16");
+    SK_CHECK_ARG(!split || srcs[0].affine == nullptr, "sk_conv3d_split: sources must be activated (affine NULL)");
     GatherArgs g{};
     g.in = (const char*)srcs[0].data;
     g.affine = srcs[0].affine;
@@ -1244,6 +1333,16 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
     const int nsteps = ksize * ksize * ksize * (g.Cin / 16);
     SK_CHECK_ARG(g.Cin <= 128 && nsteps % 2 == 0, "sk_conv3d: ksize %d needs 32 <= cin <= 128 (got %d)", ksize, g.Cin);
     const bool deep = nsteps % 4 == 0;  // pipeline depth 4 (2 only for the 32-channel pointwise case)
+    if (split) {   // depth 2: twice the fragments in flight per step
+        if (cout == 32)
+            gather_gemm_kernel<32, 2, 2, true><<<grid, 256, 0, stream>>>(g);
+        else if (cout == 64)
+            gather_gemm_kernel<64, 2, 2, true><<<grid, 256, 0, stream>>>(g);
+        else
+            gather_gemm_kernel<128, 1, 2, true><<<grid, 256, 0, stream>>>(g);
+        SK_CHECK_LAUNCH();
+        return SK_OK;
+    }
     if (cout == 32)
         deep ? gather_gemm_kernel<32, 2, 4><<<grid, 256, 0, stream>>>(g) : gather_gemm_kernel<32, 2, 2><<<grid, 256, 0, stream>>>(g);
     else if (cout == 64)
@@ -1252,6 +1351,55 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
         deep ? gather_gemm_kernel<128, 1, 4><<<grid, 256, 0, stream>>>(g) : gather_gemm_kernel<128, 1, 2><<<grid, 256, 0, stream>>>(g);
     SK_CHECK_LAUNCH();
     return SK_OK;
+}
+
+int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,
+              int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial,
+              void* zeros, void* stream) {
+    return conv3d_impl(srcs, n_src, weight, bias, out, B, ox, oy, oz, cout, ksize, gn_partial, zeros, stream, false);
+}
+
+int sk_conv3d_split(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,
+                    int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial,
+                    void* zeros, void* stream) {
+    return conv3d_impl(srcs, n_src, weight, bias, out, B, ox, oy, oz, cout, ksize, gn_partial, zeros, stream, true);
+}
+
+int64_t sk_conv3d_pack_weight_split_host(const float* w, int cout, int cin, int ksize, void* dst) {
+    // w = hi + lo with hi = fp16(w), lo = fp16(w - hi): ~22 significant bits.
+    // ksize 3: the fragments of an expanded (cout, 3*cin) weight whose 32-channel chunks are [lo_k, hi_k, hi_k] per
+    // logical chunk k -- the phase order of the split conv kernel.  ksize 1 / 2: all hi fragments, then all lo fragments.
+    if (!(ksize == 1 || ksize == 2 || ksize == 3) || cout % 32 || cin % (ksize == 3 ? 32 : 16)) {
+        sk::set_error("sk_conv3d_pack_weight_split_host: unsupported shape cout=%d cin=%d k=%d", cout, cin, ksize);
+        return SK_ERR_ARG;
+    }
+    const int k3 = ksize * ksize * ksize;
+    const int64_t n = (int64_t)cout * cin * k3;
+    std::vector<float> hi(n), lo(n);
+    for (int64_t i = 0; i < n; ++i) {
+        const float h = __half2float(__float2half(w[i]));
+        hi[i] = h;
+        lo[i] = __half2float(__float2half(w[i] - h));
+    }
+    if (ksize != 3) {
+        const int64_t half_bytes = sk_conv3d_pack_weight_host(hi.data(), cout, cin, ksize, nullptr);
+        if (!dst || half_bytes < 0) return half_bytes < 0 ? half_bytes : 2 * half_bytes;
+        sk_conv3d_pack_weight_host(hi.data(), cout, cin, ksize, dst);
+        sk_conv3d_pack_weight_host(lo.data(), cout, cin, ksize, (char*)dst + half_bytes);
+        return 2 * half_bytes;
+    }
+    const int cin3 = 3 * cin;
+    if (!dst) return sk_conv3d_pack_weight_host(hi.data(), cout, cin3, 3, nullptr);
+    std::vector<float> we((size_t)cout * cin3 * 27);
+    for (int co = 0; co < cout; ++co)
+        for (int k = 0; k < cin / 32; ++k)
+            for (int part = 0; part < 3; ++part) {
+                const std::vector<float>& src = part == 0 ? lo : hi;
+                for (int c = 0; c < 32; ++c)
+                    for (int t = 0; t < 27; ++t)
+                        we[((size_t)co * cin3 + (3 * k + part) * 32 + c) * 27 + t] = src[((size_t)co * cin + 32 * k + c) * 27 + t];
+            }
+    return sk_conv3d_pack_weight_host(we.data(), cout, cin3, 3, dst);
 }
 
 }  // extern "C"

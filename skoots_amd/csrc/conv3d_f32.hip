@@ -182,10 +182,22 @@ __global__ void __launch_bounds__(256) conv_f32_lds_kernel(ConvF32Args a) {
     for (int s = 0; s < a.nsrc; ++s) {
         const SrcF32 S = a.src[s];
         const long long svox = (long long)S.Xs * S.Ys * S.Zs;
-        // block-uniform descriptor of this batch item's source (host checks < 4 GiB): masked lanes pass an
-        // out-of-range offset and read 0, so no load sits behind a branch
-        const __amdgpu_buffer_rsrc_t rs = sk::make_rsrc(S.data + (long long)b * svox * S.C, (unsigned)(svox * S.C * 4));
         const int Xf = S.up ? S.Xs * 2 : S.Xs, Yf = S.up ? S.Ys * 2 : S.Ys, Zf = S.up ? S.Zs * 2 : S.Zs;
+        // block-uniform descriptor of the source x-planes this block's 256 consecutive voxels (+ taps) can touch --
+        // a window, so that a tensor above 4 GiB (one 512x512x128 tile at 32 channels) stays addressable with 32-bit
+        // offsets; masked lanes pass an out-of-range offset and read 0, so no load sits behind a branch
+        const long long vfirst = (long long)vb * 256, vlast = min(nvox - 1, vfirst + 255);
+        const long long oyz = (long long)a.oy * a.oz;
+        int xlo = (int)(vfirst / oyz) * stride - padw, xhi = (int)(vlast / oyz) * stride + (k - 1) - padw;
+        xlo = max(xlo, 0);
+        xhi = min(xhi, Xf - 1);
+        if (S.up) {
+            xlo >>= 1;
+            xhi >>= 1;
+        }
+        const long long splane = (long long)S.Ys * S.Zs * S.C;   // floats per source x-plane
+        const __amdgpu_buffer_rsrc_t rs = sk::make_rsrc(S.data + (long long)b * svox * S.C + xlo * splane,
+                                                        (unsigned)((xhi - xlo + 1) * splane * 4));
         for (int ch = 0; ch < S.C; ch += 32) {
             for (int tg = 0; tg < ntg; ++tg) {
                 __syncthreads();
@@ -217,7 +229,7 @@ __global__ void __launch_bounds__(256) conv_f32_lds_kernel(ConvF32Args a) {
                             yi >>= 1;
                             zi >>= 1;
                         }
-                        const unsigned off = inb ? ((unsigned)((xi * S.Ys + yi) * S.Zs + zi) * (unsigned)S.C + (unsigned)(ch + 4 * h)) * 4u
+                        const unsigned off = inb ? ((unsigned)(((xi - xlo) * S.Ys + yi) * S.Zs + zi) * (unsigned)S.C + (unsigned)(ch + 4 * h)) * 4u
                                                  : sk::kOob;
                         f32x4 bq[4];
 #pragma unroll
@@ -534,8 +546,9 @@ static int launch_conv_f32(const ConvF32Args& a, hipStream_t st) {
     bool lds = true;
     for (int i = 0; i < a.nsrc; ++i) lds = lds && (a.src[i].C % 32 == 0);
     for (int i = 0; i < a.nsrc && lds; ++i)
-        SK_CHECK_ARG((long long)a.src[i].Xs * a.src[i].Ys * a.src[i].Zs * a.src[i].C * 4 < (1LL << 32),
-                     "fp32 conv: source %d of one batch item must be < 4 GiB", i);
+        // the kernel addresses a window of x-planes per block with 32-bit offsets: 256 voxels + the taps
+        SK_CHECK_ARG((long long)a.src[i].Ys * a.src[i].Zs * a.src[i].C * 4 * (256 / ((long long)a.oy * a.oz) + 6) < (1LL << 32),
+                     "fp32 conv: source %d: x-planes too large for 32-bit window offsets", i);
     const int nct = (a.cout + 31) / 32;
     if (lds) {
         unsigned grid = (unsigned)(((a.nblk + 1) / 2) * a.B * nct);

@@ -2016,7 +2016,11 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
     const unsigned grid = (unsigned)((long long)a.nchunk * a.ncot * a.ncit * a.ngroup);
     bool lines = zero_page != nullptr && cout % 32 == 0;  // whole 64-byte channel lines: LDS-DMA + transposed reads
     for (int i = 0; i < n_src; ++i) lines = lines && srcs[i].c % 32 == 0;
-    if (lines && ksize == 3 && oz % 16 == 0 && oy % 4 == 0 && !getenv("SK_WGRAD_NOSTRIP")) {
+    bool strips = true;   // -DSK_TUNING builds (tools/) can switch the strip kernel off for A/B timing
+#ifdef SK_TUNING
+    strips = getenv("SK_WGRAD_NOSTRIP") == nullptr;
+#endif
+    if (lines && ksize == 3 && oz % 16 == 0 && oy % 4 == 0 && strips) {
         a.ngroup = 3;
         const unsigned g3 = (unsigned)((long long)a.nchunk * a.ncot * a.ncit * 3);
         const int ncol = ox * (oz / 16);
@@ -2026,7 +2030,9 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
             // three taps per wave (nine tap groups): 8 KiB of LDS tiles per wave instead of 20, so ~2.5x the waves
             // and DMA steps in flight per CU -- the kernel is bound by the latency of its tile loads
             int tpw = 9;  // 3 measured 1.5 % slower: the kernel is bound by L2 bandwidth (every input line is read once per tap), not by latency
-            if (const char* e = getenv("SK_WGRAD_TPW")) tpw = atoi(e);
+#ifdef SK_TUNING
+            if (const char* e = getenv("SK_WGRAD_TPW")) tpw = atoi(e) == 3 ? 3 : 9;
+#endif
             a.ngroup = 27 / tpw;
             const unsigned g = (unsigned)((long long)a.nchunk * a.ncot * a.ncit * a.ngroup);
             if (tpw == 3)

@@ -75,7 +75,12 @@ __global__ void __launch_bounds__(256) stem_norm_kernel(StemArgs a) {
 static int stem_rows(int Yt, int Zt) {
     int r = (40 * 1024) / (3 * (Zt + 2) * (int)sizeof(__half)) - 2;
     if (r > 150) r = 150;
-    if (const char* e = getenv("SK_STEM_ROWS")) r = atoi(e);
+#ifdef SK_TUNING
+    if (const char* e = getenv("SK_STEM_ROWS")) {
+        const int v = atoi(e);
+        if (v >= 1 && (size_t)3 * (v + 2) * (Zt + 2) * sizeof(__half) <= 60 * 1024) r = v;
+    }
+#endif
     if (r > Yt) r = Yt;
     // even split of Yt
     int n = (Yt + r - 1) / r;
@@ -84,10 +89,12 @@ static int stem_rows(int Yt, int Zt) {
 }
 
 // MODE 0: statistics only; 1: recompute + affine + SiLU, store the activation; 2 (training, mixed precision):
-// statistics AND the raw fp16 result in one pass (the backward needs the raw tensor anyway)
+// statistics AND the raw fp16 result in one pass (the backward needs the raw tensor anyway); 3: as 1, but the
+// activation is stored as a split pair [hi (32) | lo (32)] per voxel (value = hi + lo, precision "split")
 template <int MODE>
 __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
-    constexpr bool STATS = MODE != 1;
+    constexpr bool STATS = MODE == 0 || MODE == 2;
+    constexpr int kOutC = MODE == 3 ? 64 : 32;   // halves per output voxel line
     __shared__ float red[4 * 16];
     extern __shared__ __attribute__((aligned(16))) unsigned int stem_lds[];  // [3][rows+2][Zt+2] halves
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -177,16 +184,19 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
                 }
             } else {
                 const long long v = ((long long)x * a.Yt + (y0 + yl)) * a.Zt + z;
-                __half* op = a.out + ((long long)b * nvox + v) * 32;
+                __half* op = a.out + ((long long)b * nvox + v) * kOutC;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    half4v hv;
+                    half4v hv, lv;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float yv = fmaf(ga[4 * q + j], acc[4 * q + j], gb[4 * q + j]);
-                        hv[j] = (_Float16)(yv * __builtin_amdgcn_rcpf(1.0f + __expf(-yv)));
+                        const float sv = yv * __builtin_amdgcn_rcpf(1.0f + __expf(-yv));
+                        hv[j] = (_Float16)sv;
+                        lv[j] = (_Float16)(sv - (float)hv[j]);
                     }
                     *reinterpret_cast<half4v*>(op + 8 * q + 4 * h) = hv;
+                    if (MODE == 3) *reinterpret_cast<half4v*>(op + 32 + 8 * q + 4 * h) = lv;
                 }
             }
         }
@@ -316,6 +326,39 @@ __global__ void __launch_bounds__(256) gn_silu_kernel(__half* __restrict__ x,
     }
 }
 
+// split tensors: x (B, vox, 2C) = [hi (C) | lo (C)] fp16 per voxel, value = hi + lo; in place, fp32 arithmetic
+__global__ void __launch_bounds__(256) gn_silu_split_kernel(__half* __restrict__ x, const float* __restrict__ affine,
+                                                            int C, long long nvec_per_batch) {
+    const int b = blockIdx.y;
+    const int vpc = C / 8;  // 16-byte vectors per voxel and half
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;  // multiple of vpc
+    const int c0 = (int)(i % vpc) * 8;
+    float ga[8], gb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ga[j] = affine[((long long)b * 2) * C + c0 + j];
+        gb[j] = affine[((long long)b * 2 + 1) * C + c0 + j];
+    }
+    half8* p = reinterpret_cast<half8*>(x) + (long long)b * nvec_per_batch * 2;
+    for (; i < nvec_per_batch; i += stride) {
+        const long long vox = i / vpc;
+        half8* ph = p + vox * (2 * vpc) + (i - vox * vpc);
+        half8 vh = ph[0], vl = ph[vpc];
+        half8 rh, rl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xv = (float)vh[j] + (float)vl[j];
+            const float y = fmaf(ga[j], xv, gb[j]);
+            const float sv = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+            rh[j] = (_Float16)sv;
+            rl[j] = (_Float16)(sv - (float)rh[j]);
+        }
+        ph[0] = rh;
+        ph[vpc] = rl;
+    }
+}
+
 // ------------------------------------------------------------------------------ heads
 struct HeadArgs {
     const __half* x;     // (B, n, C) fp16 (activated, or raw when affine != NULL)
@@ -333,9 +376,11 @@ struct HeadArgs {
 // out5[k][voxel] = act_k( W[k][:] . silu(affine(x[voxel][:])) + bias[k] ) as a 32x32x16 MFMA with
 // 5 useful rows: per 32 voxels a wave loads 2 x 16 B per lane, activates 16 values per lane and
 // issues 4 MFMAs (weights split hi + lo: exact products, the logits keep fp32 precision).
-template <int C>
+// SPLIT: x is (B, n, 2C) = [hi | lo] pairs; the (activated) fp32 value is split again into hi + lo MFMA operands
+template <int C, bool SPLIT = false>
 __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
     static_assert(C == 32, "two K steps of 16");
+    constexpr int kLine = C * (SPLIT ? 2 : 1);   // halves per input voxel line
     const int tid = threadIdx.x, lane = tid & 63;
     const int col = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
@@ -365,7 +410,7 @@ __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
     } else {
         binit[0] = a.bias[4];  // row 4 = register 0 of the upper half-wave
     }
-    const __half* xb = a.x + (long long)b * a.n * C;
+    const __half* xb = a.x + (long long)b * a.n * kLine;
     __half* ob = a.out5 + (long long)b * 5 * a.n;
     const long long nbox = (long long)a.bx * a.by * a.bz;
     const long long ntiles = (nbox + 31) / 32;
@@ -376,12 +421,24 @@ __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
         const int z = (int)(ii % a.bz);
         const long long r2 = ii / a.bz;
         const long long v = ((long long)(a.lx + (int)(r2 / a.by)) * a.Y + (a.ly + (int)(r2 % a.by))) * a.Z + (a.lz + z);
-        const half8* p = reinterpret_cast<const half8*>(xb + (ok ? v : 0) * C);
-        half8 bf[2];
+        const half8* p = reinterpret_cast<const half8*>(xb + (ok ? v : 0) * kLine);
+        half8 bf[2], bl[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             half8 raw = p[2 * ks + h];
-            if (a.affine) {
+            if constexpr (SPLIT) {
+                const half8 rlo = p[C / 8 + 2 * ks + h];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float y = (float)raw[j] + (float)rlo[j];
+                    if (a.affine) {
+                        y = fmaf(ga[ks][j], y, gb[ks][j]);
+                        y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+                    }
+                    raw[j] = (_Float16)y;
+                    bl[ks][j] = (_Float16)(y - (float)raw[j]);
+                }
+            } else if (a.affine) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float y = fmaf(ga[ks][j], (float)raw[j], gb[ks][j]);
@@ -391,6 +448,10 @@ __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
             bf[ks] = raw;
         }
         f32x16 acc = binit;
+        if constexpr (SPLIT) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], bl[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], bl[1], acc, 0, 0, 0);
+        }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[0], bf[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[1], bf[1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], bf[0], acc, 0, 0, 0);
@@ -480,8 +541,8 @@ int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origin
     return SK_OK;
 }
 
-int sk_conv3d_stem_apply(int B, int Xt, int Yt, int Zt, const float* weight, const float* bias,
-                         const float* affine, void* out, int cout, const void* workspace, void* stream) {
+static int stem_apply_impl(int B, int Xt, int Yt, int Zt, const float* weight, const float* bias,
+                           const float* affine, void* out, int cout, const void* workspace, void* stream, bool split) {
     SK_CHECK_ARG(weight && bias && affine && out && workspace, "sk_conv3d_stem_apply: NULL pointer");
     SK_CHECK_ARG(cout == 32 && B >= 1 && B <= 16, "sk_conv3d_stem_apply: bad cout / batch");
     StemArgs a{};
@@ -496,12 +557,23 @@ int sk_conv3d_stem_apply(int B, int Xt, int Yt, int Zt, const float* weight, con
     a.out = (__half*)out;
     a.nblk = sk_conv3d_stem_num_blocks(Xt, Yt, Zt);
     a.rows = stem_rows(Yt, Zt);
+    auto kern = split ? stem_kernel<3> : stem_kernel<1>;
     if (stem_lds_bytes(Yt, Zt) > 40 * 1024)
-        SK_CHECK_HIP(hipFuncSetAttribute((const void*)stem_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)stem_lds_bytes(Yt, Zt)));
-    stem_kernel<1><<<(unsigned)(a.nblk * B), 256, stem_lds_bytes(Yt, Zt), (hipStream_t)stream>>>(a);
+    kern<<<(unsigned)(a.nblk * B), 256, stem_lds_bytes(Yt, Zt), (hipStream_t)stream>>>(a);
     SK_CHECK_LAUNCH();
     return SK_OK;
+}
+
+int sk_conv3d_stem_apply(int B, int Xt, int Yt, int Zt, const float* weight, const float* bias,
+                         const float* affine, void* out, int cout, const void* workspace, void* stream) {
+    return stem_apply_impl(B, Xt, Yt, Zt, weight, bias, affine, out, cout, workspace, stream, false);
+}
+
+int sk_conv3d_stem_apply_split(int B, int Xt, int Yt, int Zt, const float* weight, const float* bias,
+                               const float* affine, void* out, int cout, const void* workspace, void* stream) {
+    return stem_apply_impl(B, Xt, Yt, Zt, weight, bias, affine, out, cout, workspace, stream, true);
 }
 
 // ---- training, mixed precision: the stem as a fast block -------------------------------------------------------
@@ -595,8 +667,18 @@ int sk_groupnorm_silu(void* x, const float* affine, int B, int64_t voxels, int C
     return SK_OK;
 }
 
-int sk_heads(const void* x, const float* affine, const float* weight, const float* bias, void* out5, int B,
-             int X, int Y, int Z, int C, const int* box_lo_host, const int* box_hi_host, void* stream) {
+int sk_groupnorm_silu_split(void* x, const float* affine, int B, int64_t voxels, int C, void* stream) {
+    SK_CHECK_ARG(x && affine, "sk_groupnorm_silu_split: NULL pointer");
+    SK_CHECK_ARG(C % 8 == 0 && 256 % (C / 8) == 0, "sk_groupnorm_silu_split: C=%d unsupported", C);
+    long long nvec = voxels * (C / 8);
+    dim3 grid(sk::stream_grid(nvec, 256, 4), B);
+    gn_silu_split_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((__half*)x, affine, C, nvec);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+static int heads_impl(const void* x, const float* affine, const float* weight, const float* bias, void* out5, int B,
+                      int X, int Y, int Z, int C, const int* box_lo_host, const int* box_hi_host, void* stream, bool split) {
     SK_CHECK_ARG(x && weight && bias && out5, "sk_heads: NULL pointer");
     SK_CHECK_ARG(C == 32, "sk_heads: C must be 32");
     SK_CHECK_ARG(X > 0 && Y > 0 && Z > 0, "sk_heads: bad extents");
@@ -627,9 +709,22 @@ int sk_heads(const void* x, const float* affine, const float* weight, const floa
     }
     const long long voxels = (long long)a.bx * a.by * a.bz;
     dim3 grid(sk::stream_grid((voxels + 31) / 32, 4, 4), B);
-    heads_kernel<32><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    if (split)
+        heads_kernel<32, true><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    else
+        heads_kernel<32><<<grid, 256, 0, (hipStream_t)stream>>>(a);
     SK_CHECK_LAUNCH();
     return SK_OK;
+}
+
+int sk_heads(const void* x, const float* affine, const float* weight, const float* bias, void* out5, int B,
+             int X, int Y, int Z, int C, const int* box_lo_host, const int* box_hi_host, void* stream) {
+    return heads_impl(x, affine, weight, bias, out5, B, X, Y, Z, C, box_lo_host, box_hi_host, stream, false);
+}
+
+int sk_heads_split(const void* x, const float* affine, const float* weight, const float* bias, void* out5, int B,
+                   int X, int Y, int Z, int C, const int* box_lo_host, const int* box_hi_host, void* stream) {
+    return heads_impl(x, affine, weight, bias, out5, B, X, Y, Z, C, box_lo_host, box_hi_host, stream, true);
 }
 
 }  // extern "C"

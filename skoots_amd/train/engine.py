@@ -60,6 +60,10 @@ class TrainUNet:
         self.precision = precision
         self.device = torch.device(device)
         self.dims, self.depths = tuple(dims), tuple(depths)
+        # A/B switches of the mixed step (tools/bench_train.py sets them; defaults = the fast choices)
+        self.fast_stem = True          # stem as an fp16-operand fast block
+        self.fast_heads = True         # heads straight on the fp16 activation
+        self.f16_grad_handoff = True   # single-reader fp16 data gradients handed on without an fp32 copy
 
         def stack(name, n):
             return [_Layer(f"{name}.{i}", 3, True) for i in range(n)]
@@ -203,7 +207,7 @@ class TrainUNet:
         """The stem (Cin = 1, 27 taps, Cout 32) as a fast block: fp16 image operand, exact weights (hi + lo split)."""
         B = srcs[0][0].shape[0]
         return (self.precision == "mixed" and layer.norm and layer.cin == 1 and layer.cout == 32 and layer.ksize == 3 and
-                len(srcs) == 1 and B <= 16 and out_shape[2] % 2 == 0 and os.environ.get("SK_TRAIN_STEM_F32") is None)
+                len(srcs) == 1 and B <= 16 and out_shape[2] % 2 == 0 and self.fast_stem)
 
     def _block_stem_mixed(self, layer: _Layer, srcs, out_shape) -> Tensor:
         image = srcs[0][0]                       # (B, X, Y, Z, 1) fp32
@@ -231,8 +235,7 @@ class TrainUNet:
         return z16
 
     def _heads_fast(self, layer: _Layer) -> bool:
-        return (self.precision == "mixed" and not layer.norm and layer.ksize == 1 and layer.cout == 5 and layer.cin == 32 and
-                os.environ.get("SK_TRAIN_HEADS_F32") is None)
+        return (self.precision == "mixed" and not layer.norm and layer.ksize == 1 and layer.cout == 5 and layer.cin == 32 and self.fast_heads)
 
     def _block_heads_mixed(self, layer: _Layer, srcs, out_shape) -> Tensor:
         """1x1x1 heads straight on the fp16 activation (an HBM stream: no fp32 copy of the last feature map)."""
@@ -437,7 +440,7 @@ class TrainUNet:
                         grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
                         _ffi.check(_ffi.lib.sk_train_sumpool2_f16(_ffi.ptr(dx16), _ffi.ptr(scale), _ffi.ptr(grads[key]), B,
                                                                   ox // 2, oy // 2, oz // 2, c, st))
-                    elif (key in fast_out and key not in grads and os.environ.get("SK_TRAIN_F32_GRADS") is None and
+                    elif (key in fast_out and key not in grads and self.f16_grad_handoff and
                           (n_readers.get(key, 0) == 1 or (n_readers.get(key, 0) == 2 and key in k2_read))):
                         # single reader: handed to the GroupNorm backward as it is; a skip tensor whose other reader is a
                         # fast stride-2 conv (processed later): summed inside that conv's interleave pass

@@ -24,6 +24,7 @@ from . import _ffi
 
 GN_GROUPS = 8
 GN_EPS = 1e-5
+PRECISIONS = ("fp16", "split", "fp32")
 
 
 class _ConvLayer:
@@ -39,20 +40,30 @@ class _ConvLayer:
         self.bias = sd[prefix + ".conv.bias"].detach().float().to(device).contiguous()
         self.gamma = sd[prefix + ".norm.weight"].detach().float().to(device).contiguous()
         self.beta = sd[prefix + ".norm.bias"].detach().float().to(device).contiguous()
-        if self.cin == 1:  # stem: (27, cout) fp32, tap-major
+        self._w_cpu, self._device, self._packed = w, device, {}
+        if self.cin == 1:  # stem: (27, cout) fp32, tap-major (the kernel splits it into hi + lo itself)
             assert ksize == 3
-            self.weight = w.reshape(self.cout, 27).t().contiguous().to(device)
-        else:
-            wp = w.numpy()
-            fpt = wp.ctypes.data_as(C.POINTER(C.c_float))
-            nbytes = _ffi.lib.sk_conv3d_pack_weight_host(fpt, self.cout, self.cin, ksize, None)
+            self._packed[False] = self._packed[True] = w.reshape(self.cout, 27).t().contiguous().to(device)
+        self.flops_per_out_voxel = 2.0 * self.cin * self.cout * ksize ** 3
+
+    def packed(self, split: bool = False) -> Tensor:
+        """MFMA A-fragment image of the weight on the device: fp16 (``sk_conv3d``) or hi + lo split
+        (``sk_conv3d_split``); packed on first use."""
+        t = self._packed.get(split)
+        if t is None:
+            fn = _ffi.lib.sk_conv3d_pack_weight_split_host if split else _ffi.lib.sk_conv3d_pack_weight_host
+            fpt = self._w_cpu.numpy().ctypes.data_as(C.POINTER(C.c_float))
+            nbytes = fn(fpt, self.cout, self.cin, self.ksize, None)
             if nbytes < 0:
                 _ffi.check(int(nbytes))
             buf = np.empty(nbytes, dtype=np.uint8)
-            _ffi.lib.sk_conv3d_pack_weight_host(fpt, self.cout, self.cin, ksize,
-                                                buf.ctypes.data_as(C.c_void_p))
-            self.weight = torch.from_numpy(buf).to(device)
-        self.flops_per_out_voxel = 2.0 * self.cin * self.cout * ksize ** 3
+            fn(fpt, self.cout, self.cin, self.ksize, buf.ctypes.data_as(C.c_void_p))
+            t = self._packed[split] = torch.from_numpy(buf).to(self._device)
+        return t
+
+    @property
+    def weight(self) -> Tensor:
+        return self.packed(False)
 
 
 class ConvProfile:
@@ -81,10 +92,13 @@ class HipUNet:
     def __init__(self, state_dict: Dict[str, Tensor], device="cuda:0",
                  dims: Sequence[int] = (32, 64, 128, 64, 32),
                  depths: Sequence[int] = (2, 2, 2, 2, 2), precision: str = "fp16"):
-        """``precision``: "fp16" (fast path: fp16 MFMA operands, fp32 accumulation) or "fp32" (every
-        layer on the exact-fp32 matrix instruction; the parity reference of the fast path)."""
-        if precision not in ("fp16", "fp32"):
-            raise ValueError("precision must be 'fp16' or 'fp32'")
+        """``precision``: "fp16" (fast path: fp16 MFMA operands, fp32 accumulation -- what the reference's fp16
+        autocast does, eval.py:142; max-abs ~5e-3 against an fp32 forward), "split" (activations and weights as
+        fp16 hi + lo pairs, three fp16 MFMAs per product: max-abs <= 1e-3 against fp32, BASELINE.json's tolerance,
+        at ~1/3 of the fast path's speed) or "fp32" (every layer on the exact-fp32 matrix instruction; the parity
+        reference of the other two, ~1/11 of the fast path's speed)."""
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}")
         self.precision = precision
         self.device = torch.device(device)
         self.dims, self.depths = tuple(dims), tuple(depths)
@@ -115,8 +129,11 @@ class HipUNet:
         self._bufs: Dict[Tuple, Tensor] = {}
         self.last_features: Dict[str, Tensor] = {}
         self.profile: Optional[ConvProfile] = None
-        import os
-        self.defer_activation = os.environ.get("SK_DEFER_ACT", "1") != "0"  # A/B switch
+        self.defer_activation = True  # single-consumer tensors stay RAW and are activated on load (tools/ A/B switch)
+
+    @property
+    def split(self) -> bool:
+        return self.precision == "split"
 
     def clone_context(self) -> "HipUNet":
         """Same weights, separate activation buffers: lets two tile batches be in flight on two
@@ -158,7 +175,8 @@ class HipUNet:
                                                   _ffi.ptr(layer.gamma), _ffi.ptr(layer.beta), GN_EPS,
                                                   _ffi.ptr(aff), st))
         if apply:
-            _ffi.check(_ffi.lib.sk_groupnorm_silu(_ffi.ptr(x), _ffi.ptr(aff), B, vox, layer.cout, st))
+            fn = _ffi.lib.sk_groupnorm_silu_split if self.split else _ffi.lib.sk_groupnorm_silu
+            _ffi.check(fn(_ffi.ptr(x), _ffi.ptr(aff), B, vox, layer.cout, st))
         return aff
 
     def _conv(self, layer: _ConvLayer, srcs: List[Tuple], out_shape: Tuple[int, int, int],
@@ -167,7 +185,9 @@ class HipUNet:
         (raw output, affine) when ``activate`` is False."""
         B = srcs[0][0].shape[0]
         ox, oy, oz = out_shape
-        out = self._buf(tag, (B, ox, oy, oz, layer.cout))
+        split = self.split
+        lanes = 2 if split else 1   # split tensors hold [hi | lo] per voxel: twice the channels
+        out = self._buf(tag, (B, ox, oy, oz, layer.cout * lanes))
         nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, layer.cout, layer.ksize)
         if nblk <= 0:
             raise ValueError(f"{layer.name}: unsupported output shape {out_shape}")
@@ -178,17 +198,18 @@ class HipUNet:
             t, up = src[0], src[1]
             arr[i].data = t.data_ptr()
             arr[i].affine = src[2].data_ptr() if len(src) > 2 and src[2] is not None else None
-            arr[i].c = t.shape[-1]
+            arr[i].c = t.shape[-1] // lanes
             arr[i].upsample = up
-            cin += t.shape[-1]
+            cin += t.shape[-1] // lanes
         assert cin == layer.cin, (layer.name, cin, layer.cin)
         timed = self.profile is not None and layer.ksize == 3
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
-        _ffi.check(_ffi.lib.sk_conv3d(arr, len(srcs), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
-                                      _ffi.ptr(out), B, ox, oy, oz, layer.cout, layer.ksize,
-                                      _ffi.ptr(partial), _ffi.ptr(self.zeros), _ffi.stream_ptr(self.device)))
+        fn = _ffi.lib.sk_conv3d_split if split else _ffi.lib.sk_conv3d
+        _ffi.check(fn(arr, len(srcs), _ffi.ptr(layer.packed(split)), _ffi.ptr(layer.bias),
+                      _ffi.ptr(out), B, ox, oy, oz, layer.cout, layer.ksize,
+                      _ffi.ptr(partial), _ffi.ptr(self.zeros), _ffi.stream_ptr(self.device)))
         if timed:
             e1.record(torch.cuda.current_stream(self.device))
             self.profile.events.append((e0, e1, layer.flops_per_out_voxel * B * ox * oy * oz, layer.name))
@@ -202,7 +223,7 @@ class HipUNet:
         B = len(origins)
         X, Y, Z = image.shape
         xt, yt, zt = tile
-        out = self._buf(tag, (B, xt, yt, zt, layer.cout))
+        out = self._buf(tag, (B, xt, yt, zt, layer.cout * (2 if self.split else 1)))
         nblk = _ffi.lib.sk_conv3d_stem_num_blocks(xt, yt, zt)
         partial = self._buf("partial", (B * nblk * (layer.cout // 4) * 2,), torch.float32)
         org = (C.c_int32 * (3 * B))(*[int(v) for o in origins for v in o])
@@ -213,8 +234,9 @@ class HipUNet:
                                            _ffi.ptr(layer.weight), _ffi.ptr(layer.bias), layer.cout,
                                            _ffi.ptr(partial), _ffi.ptr(ws), ws_bytes, st))
         aff = self._norm_act(layer, out, partial, nblk, apply=False)
-        _ffi.check(_ffi.lib.sk_conv3d_stem_apply(B, xt, yt, zt, _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
-                                                 _ffi.ptr(aff), _ffi.ptr(out), layer.cout, _ffi.ptr(ws), st))
+        fn = _ffi.lib.sk_conv3d_stem_apply_split if self.split else _ffi.lib.sk_conv3d_stem_apply
+        _ffi.check(fn(B, xt, yt, zt, _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
+                      _ffi.ptr(aff), _ffi.ptr(out), layer.cout, _ffi.ptr(ws), st))
         return out
 
     # -- forward -----------------------------------------------------------------------
@@ -267,7 +289,8 @@ class HipUNet:
         tags = ["L2b", "L2a"]
         aff = None
         for i, layer in enumerate(self.mid):
-            last = self.defer_activation and i == len(self.mid) - 1  # only red1 (1x1x1, gather GEMM) reads it: activate on load
+            # only red1 (1x1x1, gather GEMM) reads it: activate on load (the split gather GEMM takes activated input)
+            last = self.defer_activation and not self.split and i == len(self.mid) - 1
             a = self._conv(layer, [(a, 0)], L2, tags[i % 2], activate=not last)
             if last:
                 a, aff = a
@@ -277,7 +300,7 @@ class HipUNet:
         tags = ["L1a", "L1b"]
         aff = None
         for i, layer in enumerate(self.dec1):
-            last = self.defer_activation and i == len(self.dec1) - 1  # consumed only by red0
+            last = self.defer_activation and not self.split and i == len(self.dec1) - 1  # consumed only by red0
             src = [(s1, 0), (r1, 1)] if i == 0 else [(a, 0)]
             a = self._conv(layer, src, L1, tags[i % 2], activate=not last)
             if last:
@@ -298,9 +321,9 @@ class HipUNet:
         i3 = C.c_int32 * 3
         blo = i3(*[int(v) for v in out_box[0]]) if out_box is not None else None
         bhi = i3(*[int(v) for v in out_box[1]]) if out_box is not None else None
-        _ffi.check(_ffi.lib.sk_heads(_ffi.ptr(a), _ffi.ptr(aff), _ffi.ptr(self.head_w), _ffi.ptr(self.head_b),
-                                     _ffi.ptr(out5), B, xt, yt, zt, a.shape[-1], blo, bhi,
-                                     _ffi.stream_ptr(self.device)))
+        fn = _ffi.lib.sk_heads_split if self.split else _ffi.lib.sk_heads
+        _ffi.check(fn(_ffi.ptr(a), _ffi.ptr(aff), _ffi.ptr(self.head_w), _ffi.ptr(self.head_b),
+                      _ffi.ptr(out5), B, xt, yt, zt, self.dims[4], blo, bhi, _ffi.stream_ptr(self.device)))
         return out5
 
     # -- fp32 precision mode ------------------------------------------------------------
@@ -370,17 +393,33 @@ class HipUNet:
         return f + 2.0 * self.dims[4] * 5
 
 
-def cfg_to_model(cfg, device="cuda:0", state_dict: Optional[Dict[str, Tensor]] = None) -> HipUNet:
+# what this build's network implements of the reference's MODEL config (skoots/config.py:20-34)
+SUPPORTED_ARCHITECTURE = "skoots_amd_unet"   # oracle/unet_spec.py; NOT bism's "bism_unext" / "bism_unet" (absent package)
+
+
+def cfg_to_model(cfg, device="cuda:0", state_dict: Optional[Dict[str, Tensor]] = None,
+                 precision: str = "fp16") -> HipUNet:
     """Counterpart of ``cfg_to_bism_model`` (skoots/lib/utils.py:17-107): reads the same
-    ``cfg.MODEL`` keys (DIMS, DEPTHS, IN_CHANNELS) from an attribute/dict config."""
+    ``cfg.MODEL`` keys from an attribute/dict config.  The network body is the build's own U-Net
+    (oracle/unet_spec.py: Conv3d k=3 -> GroupNorm(8) -> SiLU blocks): a config that asks for anything else --
+    the reference's default ``bism_unext`` with LayerNorm / GELU / 7^3 depthwise kernels, whose code lives in
+    the absent ``bism`` package -- raises instead of silently running a different network.  Checkpoints written
+    by the reference's trainer (pickled yacs ``CfgNode`` + bism ``UNeXT_3D`` keys) are therefore NOT loadable;
+    checkpoints written by ``skoots_amd.train`` are."""
     model = cfg["MODEL"] if isinstance(cfg, dict) else cfg.MODEL
     get = (lambda k, d: model.get(k, d)) if isinstance(model, dict) else (lambda k, d: getattr(model, k, d))
     dims, depths = get("DIMS", [32, 64, 128, 64, 32]), get("DEPTHS", [2, 2, 2, 2, 2])
     if get("IN_CHANNELS", 1) != 1:
         raise RuntimeError("IN_CHANNELS must be 1")
+    for key, ok in (("ARCHITECTURE", (SUPPORTED_ARCHITECTURE,)), ("NORMALIZATION", ("groupnorm",)),
+                    ("ACTIVATION", ("silu",)), ("KERNEL_SIZE", (3,))):
+        v = get(key, ok[0])
+        if v not in ok:
+            raise RuntimeError(f"MODEL.{key}={v!r} is not implemented by skoots_amd (supported: {ok}); "
+                               "bism architectures need the bism package, which this build does not reimplement")
     if state_dict is None:
         raise RuntimeError("a model_state_dict is required (random init lives in oracle/unet_spec.py)")
-    return HipUNet(state_dict, device, dims, depths)
+    return HipUNet(state_dict, device, dims, depths, precision)
 
 
 def random_state_dict(dims=(32, 64, 128, 64, 32), depths=(2, 2, 2, 2, 2), seed: int = 101196) -> Dict[str, Tensor]:
@@ -425,27 +464,43 @@ def smoke_model(device="cuda:0") -> Optional[HipUNet]:
 # ----------------------------------------------------------------------------------------
 # Operator-level entry points (used by the parity tests and by bench.py's conv-only leg)
 # ----------------------------------------------------------------------------------------
-def pack_conv_weight(weight: Tensor, device) -> Tensor:
-    """(cout, cin, k, k, k) fp32 -> MFMA A-fragment order (fp16 bytes) on the device."""
+def pack_conv_weight(weight: Tensor, device, split: bool = False) -> Tensor:
+    """(cout, cin, k, k, k) fp32 -> MFMA A-fragment order (fp16 bytes) on the device; ``split``: the hi + lo
+    fragment sets of ``sk_conv3d_split``."""
     w = weight.detach().float().cpu().contiguous().numpy()
     cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
     fpt = w.ctypes.data_as(C.POINTER(C.c_float))
-    nbytes = _ffi.lib.sk_conv3d_pack_weight_host(fpt, cout, cin, k, None)
+    fn = _ffi.lib.sk_conv3d_pack_weight_split_host if split else _ffi.lib.sk_conv3d_pack_weight_host
+    nbytes = fn(fpt, cout, cin, k, None)
     if nbytes < 0:
         _ffi.check(int(nbytes))
     buf = np.empty(nbytes, dtype=np.uint8)
-    _ffi.lib.sk_conv3d_pack_weight_host(fpt, cout, cin, k, buf.ctypes.data_as(C.c_void_p))
+    fn(fpt, cout, cin, k, buf.ctypes.data_as(C.c_void_p))
     return torch.from_numpy(buf).to(device)
 
 
+def split_pair(x: Tensor) -> Tensor:
+    """fp32 (..., C) -> the split layout (..., 2C) fp16 = [hi | lo], hi = fp16(x), lo = fp16(x - hi)."""
+    hi = x.half()
+    return torch.cat([hi, (x - hi.float()).half()], dim=-1).contiguous()
+
+
+def join_pair(x: Tensor) -> Tensor:
+    """Split layout (..., 2C) fp16 -> fp32 (..., C) = hi + lo."""
+    c = x.shape[-1] // 2
+    return x[..., :c].float() + x[..., c:].float()
+
+
 def conv3d(srcs: List[Tuple[Tensor, int]], packed_weight: Tensor, bias: Tensor, cout: int, ksize: int,
-           out_shape: Sequence[int], zeros: Tensor, want_stats: bool = True):
+           out_shape: Sequence[int], zeros: Tensor, want_stats: bool = True, split: bool = False):
     """Raw conv (no normalisation): srcs [(B,x,y,z,c) fp16 tensor, upsample flag] ->
-    ((B, ox, oy, oz, cout) fp16, gn_partial (B, nblk, cout/4, 2) fp32 or None)."""
+    ((B, ox, oy, oz, cout) fp16, gn_partial (B, nblk, cout/4, 2) fp32 or None).  ``split``: sources and
+    output are split pairs (..., 2c) (see :func:`split_pair`), weight packed with ``split=True``."""
     B = srcs[0][0].shape[0]
     dev = srcs[0][0].device
     ox, oy, oz = (int(v) for v in out_shape)
-    out = torch.empty((B, ox, oy, oz, cout), dtype=torch.float16, device=dev)
+    lanes = 2 if split else 1
+    out = torch.empty((B, ox, oy, oz, cout * lanes), dtype=torch.float16, device=dev)
     nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, cout, ksize)
     if nblk <= 0:
         raise ValueError(f"unsupported conv output shape {tuple(out_shape)}")
@@ -455,11 +510,11 @@ def conv3d(srcs: List[Tuple[Tensor, int]], packed_weight: Tensor, bias: Tensor, 
         _ffi.require_gpu(t, "src")
         arr[i].data = t.data_ptr()
         arr[i].affine = None
-        arr[i].c = t.shape[-1]
+        arr[i].c = t.shape[-1] // lanes
         arr[i].upsample = up
-    _ffi.check(_ffi.lib.sk_conv3d(arr, len(srcs), _ffi.ptr(packed_weight), _ffi.ptr(bias), _ffi.ptr(out), B,
-                                  ox, oy, oz, cout, ksize, _ffi.ptr(partial), _ffi.ptr(zeros),
-                                  _ffi.stream_ptr(dev)))
+    fn = _ffi.lib.sk_conv3d_split if split else _ffi.lib.sk_conv3d
+    _ffi.check(fn(arr, len(srcs), _ffi.ptr(packed_weight), _ffi.ptr(bias), _ffi.ptr(out), B,
+                  ox, oy, oz, cout, ksize, _ffi.ptr(partial), _ffi.ptr(zeros), _ffi.stream_ptr(dev)))
     return out, partial
 
 

@@ -83,6 +83,41 @@ def test_conv_vs_torch(U, B, osp, srcdef, cout, ksize):
     assert torch.allclose(p[..., 1], (wq ** 2).sum(dim=(2, 3)), rtol=2e-3)
 
 
+@pytest.mark.parametrize("B,osp,srcdef,cout,ksize", CONV_CASES)
+def test_conv_split_vs_torch(U, B, osp, srcdef, cout, ksize):
+    """precision "split": fp32 operands carried as fp16 hi + lo pairs, three MFMAs per product.  Against a float64
+    conv of the SAME fp32 operands: the only approximations left are the dropped lo*lo term and the 22-bit
+    representation, ~1e-6 relative (the plain fp16 kernel sits at 1e-3 on the same data)."""
+    gen = torch.Generator().manual_seed(cout * 5 + ksize + osp[1])
+    srcs_cpu, srcs_dev = [], []
+    for c, up in srcdef:
+        if ksize == 3:
+            sp = tuple(s // 2 for s in osp) if up else osp
+        else:
+            sp = tuple(s * ksize for s in osp)
+        t = torch.randn((B, c) + sp, generator=gen)
+        t = U.join_pair(U.split_pair(t))   # what the pair can hold exactly
+        srcs_cpu.append((t, up))
+        srcs_dev.append((U.split_pair(_cl(t)).to(DEV), up))
+    cin = sum(c for c, _ in srcdef)
+    w = torch.randn((cout, cin, ksize, ksize, ksize), generator=gen) / (cin * ksize ** 3) ** 0.5
+    w = U.join_pair(U.split_pair(w.unsqueeze(-1))).squeeze(-1)
+    b = torch.randn(cout, generator=gen) * 0.1
+    xs = [F.interpolate(t.double(), scale_factor=2, mode="nearest") if up else t.double() for t, up in srcs_cpu]
+    x = torch.cat(xs, dim=1)
+    want = F.conv3d(x, w.double(), b.double(), padding=1) if ksize == 3 else F.conv3d(x, w.double(), b.double(), stride=ksize)
+    zeros = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    got, partial = U.conv3d(srcs_dev, U.pack_conv_weight(w, DEV, split=True), b.to(DEV), cout, ksize, osp, zeros,
+                            split=True)
+    got = _cf(U.join_pair(got.cpu())).double()
+    err = (got - want).abs().max().item()
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), err
+    p = partial.sum(dim=1).cpu().double()
+    wq = want.reshape(B, cout // 4, 4, -1)
+    assert torch.allclose(p[..., 0], wq.sum(dim=(2, 3)), rtol=1e-4, atol=1e-3 * wq.shape[-1] ** 0.5)
+    assert torch.allclose(p[..., 1], (wq ** 2).sum(dim=(2, 3)), rtol=1e-4)
+
+
 def test_conv_exact_integer_layout(U):
     """Asymmetric small-integer operands: checks the MFMA operand / accumulator maps exactly."""
     gen = torch.Generator().manual_seed(1)
@@ -205,6 +240,28 @@ def test_network_vs_oracle(U, tile, origins):
               f"fp16-storage emulation vs fp32 rms {rms(emu):.2e} max {emu.max():.2e}")
         assert rms(e32) <= 1e-3 and e32.max().item() <= 1e-2
         assert rms(e32) <= 1.25 * rms(emu) + 1e-5
+
+
+@pytest.mark.parametrize("tile,origins", [((64, 64, 20), [(0, 0, 0)]), ((32, 48, 20), [(3, 1, 2), (10, 0, 0)]),
+                                           ((30, 45, 18), [(0, 0, 0)]), ((13, 22, 7), [(0, 0, 0)])])
+def test_network_split_mode_vs_oracle(U, tile, origins):
+    """precision="split": matrix-core path (fp16 hi + lo operand pairs) that meets BASELINE.json's north_star
+    tolerance -- max-abs <= 1e-3 against the fp32 oracle on every output channel."""
+    from oracle import unet_spec
+    ref = unet_spec.build(101196)
+    hip = U.HipUNet.from_module(ref, DEV, precision="split")
+    gen = torch.Generator().manual_seed(tile[0])
+    shape = tuple(max(o[k] for o in origins) + tile[k] for k in range(3))
+    vol = torch.randint(0, 256, shape, generator=gen).to(torch.float16)
+    mean, std = float(vol.mean()), float(vol.std())
+    out5 = hip.forward_tiles(vol.to(DEV), origins, tile, mean, std).cpu().float()
+    for b, (x, y, z) in enumerate(origins):
+        crop = vol[x:x + tile[0], y:y + tile[1], z:z + tile[2]][None, None].sub(mean).div(std).float()
+        with torch.no_grad():
+            want = ref(crop)[0]
+        e = (out5[b] - want).abs()
+        print(f"split mode tile {b}: max abs err {e.max().item():.2e} rms {e.pow(2).mean().sqrt().item():.2e}")
+        assert e.max().item() <= 1e-3
 
 
 @pytest.mark.parametrize("tile,origins", [((64, 64, 20), [(0, 0, 0)]), ((32, 48, 20), [(3, 1, 2), (10, 0, 0)]),
