@@ -10,6 +10,17 @@ already resident in HBM when the timed region starts.
   N > 1 : weak scaling, 2^28 voxels per GPU, Z-sharded: 2048x1024x256 (N=2),
           2048x2048x256 (N=4), 2048x2048x512 (N=8 = configs[3])
 
+``--gpus N`` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself, one
+process per device, and relays rank 0's JSON line; it exits non-zero when the node has fewer than N
+devices -- a multi-GPU request never silently turns into a 1-GPU line.
+
+``--precision``: "fp16" (default; the dtype BASELINE's configs name, fp16 MFMA operands -- what the
+reference's autocast does), "split" (fp16 hi + lo operand pairs: max-abs <= 1e-3 vs fp32, the
+north_star tolerance) or "fp32" (exact-fp32 MFMA).  Every line states its own measured tolerance
+(``parity_vs_fp32_mode``: the benched precision against the exact-fp32 mode on one production batch).
+
+``--config train``: BASELINE configs[4], one training step on a synthetic 256^3 crop (see train_main).
+
 Synthetic data: uint8-range random image, random-init network of the named shape
 (DIMS [32,64,128,64,32], DEPTHS [2,2,2,2,2]).  A random-init net never crosses the 0.8
 gates, so the post-network stages would see an empty skeleton; as SURVEY.md 8(d)
@@ -24,6 +35,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,6 +47,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 SCALE = (60, 60, 12)  # cfg.SKOOTS.VECTOR_SCALING default, skoots/config.py:144
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 matrix peak
 
 
 def workload_shape(n_gpus: int):
@@ -92,88 +107,181 @@ def cpu_threads() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(budget_s: float = 20.0):
-    """The CPU restatement (oracle/) timed on this host on a bounded sample of BASELINE
-    configs[0]: the 128x128x32 volume with the same network shape -- the reference's own
-    CPU-runnable case, where it evaluates 100 tiles (every clamped duplicate included).
-    Stage 1 runs for at most ``budget_s`` seconds and is scaled to the 100 tiles; stages
-    2-3 + renumber run in full."""
+def cpu_baseline(budget_s: float = 8.0):
+    """The CPU restatement (oracle/) timed on this host on a bounded sample (~20 s) and reported for
+    the SAME workload as the GPU line, BASELINE configs[2] (1024x1024x256), in the units the reference
+    does the work in:
+
+      stage 1   seconds per 300x300x20 tile (network + gate/dilate/scatter, eval.py:126-176), measured on
+                a few tiles, x 936 tiles -- the reference's generator emits every clamped duplicate
+                (cropper.py:97-144)
+      stage 2   labelling of one 500x500x50 volume with a blob-field skeleton, x voxels / 12.5 M
+      stage 3   one 500x500x50 crop: vector_to_embedding(N=10) + index_skeleton_by_embed
+                (eval.py:271-279), x 63 crops
+      renumber  one 500x500x50 int volume, x voxels / 12.5 M
+
+    ``config0_value``: the reference's own CPU-runnable case (configs[0], 128x128x32: 100 tiles for 3
+    distinct origins -- 62x overcompute, so not comparable with the GPU line) measured the same way."""
+    import numpy as np
     from oracle import pipeline as O
     from oracle import unet_spec
     threads = cpu_threads()
     torch.set_num_threads(threads)
     model = unet_spec.build()
     g = torch.Generator().manual_seed(0)
-    image = torch.randint(0, 256, (1, 128, 128, 32), generator=g).to(torch.float16)
-    prog = {}
     with torch.no_grad():
-        model(torch.zeros(1, 1, 128, 128, 20))  # warm the allocator / thread pool, untimed
-        vectors, skeleton = O.stage1(image, model, image.mean(), image.std(), budget_s=budget_s, progress=prog)
-        t1 = prog["seconds"] * prog["total"] / prog["done"]
+        # ---- stage 1: per-tile cost at the production tile size -----------------------------------
+        model(torch.zeros(1, 1, 64, 64, 20))  # warm the allocator / thread pool, untimed
+        img = torch.randint(0, 256, (1, 300, 300, 20), generator=g).to(torch.float16)
+        prog = {}
+        O.stage1(img, model, img.mean(), img.std(), budget_s=budget_s, progress=prog)
+        t_tile, n_tiles = prog["seconds"] / prog["done"], prog["done"]
+        # ---- configs[0]: 128x128x32, per-tile cost x 100 tiles + stages 2-3 in full ------------
+        img0 = torch.randint(0, 256, (1, 128, 128, 32), generator=g).to(torch.float16)
+        prog0 = {}
+        v0, s0 = O.stage1(img0, model, img0.mean(), img0.std(), budget_s=budget_s / 2, progress=prog0)
         t0 = time.perf_counter()
-        O.post_model(vectors, skeleton, SCALE)
-        t23 = time.perf_counter() - t0
-    dt = t1 + t23
-    return {"value": round(128 * 128 * 32 / dt / 1e6, 5), "unit": "Mvoxels/s", "cores": threads,
-            "kind": "port",
-            "sample": f"configs[0] 128x128x32 fp32, torch CPU {threads} threads: stage 1 timed on {prog['done']} of "
-                      f"{prog['total']} tiles (128x128x20) in {prog['seconds']:.1f} s and scaled to {t1:.1f} s; stages 2-3 + "
-                      f"renumber in full {t23:.1f} s"}
+        O.post_model(v0, s0, SCALE)
+        t_c0 = prog0["seconds"] * prog0["total"] / prog0["done"] + time.perf_counter() - t0
+        # ---- stages 2-3 + renumber on one 500x500x50 crop of a blob field ------------------------
+        from tests.workload import blob_field
+        field, _ = blob_field((500, 500, 50), seed=1, n_blobs=60, rmax=(18, 18, 5), noise=0.0)
+        skel = (field[3] > 0.8).numpy().astype(np.uint8)[None]
+        t0 = time.perf_counter()
+        labels = O.stage2(skel)
+        t_ccl = time.perf_counter() - t0
+        vec = field[0:3].to(torch.float16).unsqueeze(0)
+        t0 = time.perf_counter()
+        emb = O.vector_to_embedding(torch.as_tensor(SCALE), vec, N=O.FOLLOW_N)      # eval.py:271-273
+        inst = O.index_skeleton_by_embed(labels.unsqueeze(0).unsqueeze(0), emb)      # eval.py:277-279
+        t_crop = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.renumber(inst[0, 0].numpy())
+        t_ren = time.perf_counter() - t0
+    vox2 = 1024 * 1024 * 256
+    crop_vox = 500 * 500 * 50
+    t2 = 936 * t_tile + (vox2 / crop_vox) * (t_ccl + t_ren) + 63 * t_crop
+    return {"value": round(vox2 / t2 / 1e6, 4), "unit": "Mvoxels/s", "cores": threads, "kind": "port",
+            "config0_value": round(128 * 128 * 32 / t_c0 / 1e6, 5),
+            "sample": f"torch CPU {threads} threads, configs[2] 1024x1024x256 extrapolated from measured units: "
+                      f"{t_tile:.2f} s per 300x300x20 tile (network + gate/dilate, {n_tiles} tiles timed) x 936 reference "
+                      f"tiles + {t_crop:.2f} s per 500x500x50 follow+assign crop x 63 + labelling {t_ccl:.2f} s and "
+                      f"renumber {t_ren:.2f} s per 12.5 Mvoxel x {vox2 / crop_vox:.1f} = {t2:.0f} s; config0_value = "
+                      f"configs[0] 128x128x32 (100 tiles, 62x overcompute) measured the same way"}
 
 
 def conv_hbm_traffic():
     """HBM bytes per conv3 launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     in separate runs of the same launch shapes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).
-    bench.py cannot collect PMC counters itself; returns None when the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic_pmc.json")
-    try:
-        prof = json.load(open(path))
-    except OSError:
-        return None
-    tot, n = 0.0, 0
-    for k in prof["kernels"]:
-        if "conv3_kernel" in k["kernel"] or "conv3_m16_kernel" in k["kernel"]:
-            tot += (k["fetch_MB_per_launch_x2_gfx950_correction"] + k["write_MB_per_launch"]) * k["launches"]
-            n += k["launches"]
-    return round(tot / n * 1024 * 1024) if n else None
+    bench.py cannot collect PMC counters itself; returns (None, None) when no profile is committed."""
+    for name in ("r02_conv_hbm_traffic_pmc.json", "r01_conv_hbm_traffic_pmc.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            prof = json.load(open(path))
+        except OSError:
+            continue
+        tot, n = 0.0, 0
+        for k in prof["kernels"]:
+            if "conv3_kernel" in k["kernel"] or "conv3_m16_kernel" in k["kernel"]:
+                tot += (k["fetch_MB_per_launch_x2_gfx950_correction"] + k["write_MB_per_launch"]) * k["launches"]
+                n += k["launches"]
+        if n:
+            return round(tot / n * 1024 * 1024), name
+    return None, None
 
 
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--tile-batch", type=int, default=8)
-    ap.add_argument("--shape", type=str, default="", help="override X,Y,Z (debug)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-inject", action="store_true")
-    ap.add_argument("--streams", type=int, default=1, help="tile batches in flight (HIP streams)")
-    ap.add_argument("--precision", choices=["fp16", "fp32"], default="fp16",
-                    help="fp32: every layer on the exact-fp32 matrix instruction (strict 1e-3 parity mode; not the headline)")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------
+# launcher: --gpus N without torchrun
+# ---------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+def spawn_ranks(args, argv) -> int:
+    """One fresh child process per device (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torchrun would);
+    rank 0's stdout (the JSON line) is relayed, every rank's stderr passes through.  Nothing here touches
+    the GPU: ``device_count()`` does not initialise it."""
+    n = args.gpus
+    rehearsal = os.environ.get("SKOOTS_DIST_BACKEND") == "gloo"   # ranks share a device, host-staged collectives
+    if not args.launcher_dry_run:
+        have = torch.cuda.device_count()
+        if have < (1 if rehearsal else n):
+            print(f"bench.py: --gpus {n} requested but this node exposes {have} device(s); refusing to print a "
+                  f"{have}-GPU line for a {n}-GPU request", file=sys.stderr)
+            return 2
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for ln in out0.decode().splitlines():   # stdout carries the JSON line only; library chatter goes to stderr
+        print(ln, file=sys.stdout if ln.lstrip().startswith("{") else sys.stderr, flush=True)
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def launcher_dry_run(rank: int, world: int) -> None:
+    """CPU rehearsal of the launch path (tests/test_parallel_cpu.py): the spawned ranks rendezvous over gloo,
+    all-reduce their ranks and rank 0 prints one JSON line."""
+    dist.init_process_group("gloo")
+    t = torch.tensor([rank], dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launcher": "ok", "n_gpus": world, "rank_sum": int(t.item()),
+                          "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}), flush=True)
+    dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------
+def parity_vs_fp32_mode(model, image, origins, eff, mean, std, out_box, precision):
+    """The benched precision against the exact-fp32 MFMA mode (pinned to the fp32 oracle at 1e-5 by
+    tests/test_hip_unet.py and tests/test_hip_geometry.py) on one production tile batch, over the box
+    of every tile that the pipeline consumes.  Measured live, outside the timed region."""
+    model.precision = precision
+    got = model.forward_tiles(image, origins, eff, mean, std, out_box=out_box).float()
+    model.precision = "fp32"
+    want = model.forward_tiles(image, origins, eff, mean, std)
+    model.precision = precision
+    (x0, y0, z0), (x1, y1, z1) = out_box
+    e = (got[:, :, x0:x1, y0:y1, z0:z1] - want[:, :, x0:x1, y0:y1, z0:z1]).abs()
+    return {"max_abs": float(f"{e.max().item():.3e}"), "rms": float(f"{e.pow(2).mean().sqrt().item():.3e}"),
+            "tiles": len(origins), "reference": "precision='fp32' (exact-fp32 MFMA; 1e-5 from the fp32 CPU oracle)",
+            "north_star_tolerance": 1e-3}
+
+
+def eval_main(args, rank, world, local):
     ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path")
     torch.cuda.set_device(local % ndev)
     dev = torch.device("cuda", local % ndev)
+    backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("SKOOTS_DIST_BACKEND", "nccl")  # "gloo": single-GPU rehearsal of the N>1 path
         if backend == "nccl":
+            if ndev < world:
+                raise SystemExit(f"WORLD_SIZE={world} but only {ndev} device(s) visible: RCCL needs one device per rank")
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
     from skoots_amd import unet
     from skoots_amd.parallel import ShardedVolume
+    from skoots_amd.profile import KernelProfile
 
     shape = tuple(int(v) for v in args.shape.split(",")) if args.shape else workload_shape(world)
     X, Y, Z = shape
@@ -198,9 +306,9 @@ def main():
         x, y, z = origin
         return inject_vol[:, x:x + eff[0], y:y + eff[1], z:z + eff[2]]  # strided view: no copy
 
-    def step(prof=None):
+    def step(prof=None, sprof=None):
         return sv.run(image, model, SCALE, mean, std, tile_batch=args.tile_batch, inject=inject,
-                      conv_profile=prof, streams=args.streams)
+                      conv_profile=prof, streams=args.streams, stage_profile=sprof)
 
     def barrier():
         if world > 1:
@@ -211,52 +319,137 @@ def main():
     for _ in range(args.warmup):
         res = step()
         log(f"warm-up step done: {sv.timings}")
+    sv.timings.clear()
+    sv.comm._acct.clear()
     barrier()
-    prof = unet.ConvProfile()
+    prof, sprof = unet.ConvProfile(), KernelProfile()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step(prof)
+        res = step(prof, sprof)
     barrier()
     dt = time.perf_counter() - t0
     log(f"timed {args.steps} steps in {dt:.3f} s")
+    comm_stats = sv.comm.stats()
+    tiles = sv.tiles_this_rank
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # per-rank tile counts and communication time (max over ranks: the slowest rank sets the step time)
+        tl = torch.tensor([tiles], dtype=torch.int64, device=dev)
+        gathered = [torch.zeros_like(tl) for _ in range(world)]
+        dist.all_gather(gathered, tl)
+        tiles = [int(v.item()) for v in gathered]
+        keys = sorted(comm_stats)
+        ms = torch.tensor([comm_stats[k]["ms"] for k in keys], dtype=torch.float64, device=dev)
+        dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+        for k, v in zip(keys, ms.tolist()):
+            comm_stats[k]["ms_max_over_ranks"] = round(v, 3)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         voxels = X * Y * Z
         conv_ms, conv_flops, conv_launches = prof.totals()
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        traffic, traffic_src = conv_hbm_traffic()
         line = {
             "metric": "Mvoxels/s end-to-end (3D U-Net fwd + instance assign)",
             "value": round(voxels / (dt / args.steps) / 1e6, 3), "unit": "Mvoxels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if args.precision == "fp16" else "f32",
+            "dtype": {"fp16": "f16", "split": "f16 hi+lo pairs (3 MFMA products, f32 accumulate)", "fp32": "f32"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{X}x{Y}x{Z} fp16 volume, 300x300x20 tiles (margin 50,50,5), "
                                    f"U-Net dims [32,64,128,64,32] depths [2,2,2,2,2], N=10 follow, "
-                                   f"Z-sharded x{world}", "tile_batch": args.tile_batch, "streams": args.streams,
+                                   f"Z-sharded x{world}", "precision": args.precision,
+                       "tile_batch": args.tile_batch, "streams": args.streams,
                        "instances": int(res.get("n_instances", -1)), "blobs_injected": n_blobs,
-                       "stage_ms": {k: round(v / (args.steps + args.warmup) * 1e3, 2)
-                                    for k, v in sv.timings.items()}},
+                       "stage_ms": {k: round(v / args.steps * 1e3, 2) for k, v in sv.timings.items()}},
             "roofline": {"bound": "mfma", "kernel": "conv3_m16_kernel / conv3_kernel (all 3x3x3 MFMA conv launches)",
-                         "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(achieved / 2500.0, 4), "traffic": conv_hbm_traffic(),
-                         "traffic_unit": "bytes per launch (PMC, profiles/r01_conv_hbm_traffic_pmc.json)",
-                         "launches": conv_launches, "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4)},
+                         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic if args.precision == "fp16" else None,
+                         "traffic_unit": f"bytes per launch (PMC, profiles/{traffic_src})",
+                         "launches": conv_launches, "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
+                         "flops_counted": "algorithmic 2*Cin*Cout*27 per output voxel (split mode issues 3x that on the MFMA pipe)"},
         }
-        if args.precision != "fp16":  # the MFMA conv profile only instruments the fp16 kernel
+        if args.precision == "fp32":  # the MFMA conv profile only instruments the fp16 / split kernels
             line["roofline"] = None
-            line["config"]["precision"] = args.precision
+        # HBM-bound stages: algorithmic bytes / HIP-event kernel time vs the 8 TB/s peak
+        names = {"gate_dilate_scatter": "roofline_gate", "ccl": "roofline_ccl", "follow_assign": "roofline_assign"}
+        for kname, (kms, kbytes, kn) in sprof.totals().items():
+            gbs = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+            line[names[kname]] = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                  "launches": kn, "avg_launch_ms": round(kms / max(kn, 1), 4),
+                                  "algorithmic_bytes_per_voxel": {"gate_dilate_scatter": 17, "ccl": 9, "follow_assign": 64}[kname]}
+        if world > 1:
+            line["multi_gpu"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                                 "tiles_per_rank": tiles, "slab_planes": [b - a for a, b in sv.slabs],
+                                 "comm_rank0_per_step": {k: {"bytes": v["bytes"] // args.steps,
+                                                             "ms": round(v["ms"] / args.steps, 3),
+                                                             "ms_max_over_ranks": round(v.get("ms_max_over_ranks", v["ms"]) / args.steps, 3),
+                                                             "calls": v["calls"] // args.steps}
+                                                         for k, v in comm_stats.items()}}
+    if not args.no_parity:
+        # every rank runs it (same launches everywhere keeps the ranks in step); rank 0 reports
+        from skoots_amd.parallel import tile_plan
+        plan, eff = tile_plan(shape, (300, 300, 20), (50, 50, 5), world)
+        mine = plan[rank][:8]
+        reach, ov = (3, 3, 1), (50, 50, 5)
+        box = ([max(0, o - r) for o, r in zip(ov, reach)], [min(s, s - o + r) for s, o, r in zip(eff, ov, reach)])
+        par = parity_vs_fp32_mode(model, image, [(x, y, z - zlo) for (x, y, z) in mine], eff, mean, std, box,
+                                  args.precision)
+        if rank == 0:
+            line["parity_vs_fp32_mode"] = par
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             log("timing the CPU restatement (bounded sample)")
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=["eval", "train"], default="eval",
+                    help="eval: BASELINE configs[2]/[3] (the headline metric); train: configs[4], one training step")
+    ap.add_argument("--tile-batch", type=int, default=8)
+    ap.add_argument("--shape", type=str, default="", help="override X,Y,Z (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inject", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the live parity_vs_fp32_mode measurement")
+    ap.add_argument("--streams", type=int, default=1, help="tile batches in flight (HIP streams)")
+    ap.add_argument("--precision", choices=["fp16", "split", "fp32", "bf16", "mixed"], default=None,
+                    help="eval: fp16 (default) | split (<= 1e-3 vs fp32) | fp32; train: bf16 (default) | mixed (fp16) | fp32")
+    ap.add_argument("--launcher-dry-run", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.precision is None:
+        args.precision = "fp16" if args.config == "eval" else "bf16"
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # launched bare (python bench.py --gpus N): start the N ranks ourselves, before any GPU call
+        raise SystemExit(spawn_ranks(args, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(env_world or "1")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a line for a different GPU count")
+    if args.launcher_dry_run:
+        return launcher_dry_run(rank, world)
+    if args.config == "train":
+        from tools.bench_train import train_main
+        return train_main(args, rank, world, local)
+    if args.precision not in ("fp16", "split", "fp32"):
+        raise SystemExit(f"--precision {args.precision} is a training precision; eval takes fp16 | split | fp32")
+    eval_main(args, rank, world, local)
 
 
 if __name__ == "__main__":

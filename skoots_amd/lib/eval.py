@@ -25,6 +25,7 @@ import torch
 from torch import Tensor
 
 from .. import _ffi
+from ..profile import ASSIGN_BYTES_PER_VOXEL, GATE_BYTES_PER_VOXEL, maybe_span
 from . import cropper
 from .flood_fill import label_skeleton
 from .vector_to_embedding import step_scales
@@ -68,6 +69,7 @@ class VolumeState:
                            if keep_planar_vectors else None)
         self.labels: Optional[Tensor] = None
         self.instance: Optional[Tensor] = None
+        self.profile = None   # optional skoots_amd.profile.KernelProfile (bench.py: per-stage HBM rooflines)
 
     # -- stage 1 tail ------------------------------------------------------------------
     def scatter_tile(self, out5: Tensor, origin: Sequence[int], overlap=TILE_OVERLAP,
@@ -119,12 +121,15 @@ class VolumeState:
         pthr, sthr = thresholds_for(t0.dtype)
         for k in range(0, n, 16):
             m = min(16, n - k)
-            _ffi.check(_ffi.lib.sk_gate_dilate_scatter(
-                C.c_void_p(base), _ffi.dtype_code(t0), m, (C.c_int64 * m)(*offs[k:k + m]),
-                t0.stride(0), t0.stride(1), t0.stride(2), w, h, d, (C.c_int32 * (3 * m))(*orgs[3 * k:3 * (k + m)]),
-                (C.c_int32 * (3 * m))(*los[3 * k:3 * (k + m)]), (C.c_int32 * (3 * m))(*his[3 * k:3 * (k + m)]),
-                _ffi.ptr(self.vec4), _ffi.ptr(self.vec_planar), _ffi.ptr(self.skeleton), X, Y, zl, pthr, sthr,
-                _ffi.stream_ptr(self.device)))
+            written = sum((his[3 * j] - los[3 * j]) * (his[3 * j + 1] - los[3 * j + 1]) * (his[3 * j + 2] - los[3 * j + 2])
+                          for j in range(k, k + m))
+            with maybe_span(self.profile, "gate_dilate_scatter", self.device, GATE_BYTES_PER_VOXEL * written):
+                _ffi.check(_ffi.lib.sk_gate_dilate_scatter(
+                    C.c_void_p(base), _ffi.dtype_code(t0), m, (C.c_int64 * m)(*offs[k:k + m]),
+                    t0.stride(0), t0.stride(1), t0.stride(2), w, h, d,
+                    (C.c_int32 * (3 * m))(*orgs[3 * k:3 * (k + m)]), (C.c_int32 * (3 * m))(*los[3 * k:3 * (k + m)]),
+                    (C.c_int32 * (3 * m))(*his[3 * k:3 * (k + m)]), _ffi.ptr(self.vec4), _ffi.ptr(self.vec_planar),
+                    _ffi.ptr(self.skeleton), X, Y, zl, pthr, sthr, _ffi.stream_ptr(self.device)))
         self._keep = tiles  # the views must outlive the launch
 
     # -- stage 2 -----------------------------------------------------------------------
@@ -154,10 +159,11 @@ class VolumeState:
         own = [torch.from_numpy(t).to(self.device) for t in tables]
         self.instance = torch.zeros((X, Y, z_hi - z_lo), dtype=torch.int32, device=self.device)
         sc = step_scales(scale, n, decay)
-        _ffi.check(_ffi.lib.sk_follow_assign(
-            _ffi.ptr(self.vec4), _ffi.ptr(labels), _ffi.dtype_code(labels), _ffi.ptr(self.instance),
-            X, Y, Z, self.window[0], self.window[1], _ffi.ptr(own[0]), _ffi.ptr(own[1]), _ffi.ptr(own[2]),
-            eff[0], eff[1], eff[2], _ffi.float_array(sc), n, z_lo, z_hi, _ffi.stream_ptr(self.device)))
+        with maybe_span(self.profile, "follow_assign", self.device, ASSIGN_BYTES_PER_VOXEL * X * Y * (z_hi - z_lo)):
+            _ffi.check(_ffi.lib.sk_follow_assign(
+                _ffi.ptr(self.vec4), _ffi.ptr(labels), _ffi.dtype_code(labels), _ffi.ptr(self.instance),
+                X, Y, Z, self.window[0], self.window[1], _ffi.ptr(own[0]), _ffi.ptr(own[1]), _ffi.ptr(own[2]),
+                eff[0], eff[1], eff[2], _ffi.float_array(sc), n, z_lo, z_hi, _ffi.stream_ptr(self.device)))
         self._own = own  # keep the tables alive until the stream has consumed them
         return self.instance
 

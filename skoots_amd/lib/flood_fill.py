@@ -20,9 +20,11 @@ import torch
 from torch import Tensor
 
 from .. import _ffi
+from ..profile import CCL_BYTES_PER_VOXEL, maybe_span
 from . import cropper
 
 FLOOD_CROP = (1000, 1000, 200)  # flood_fill.py:28
+PAIR_CAP = 16384                # seam pairs per rank carried inside the fixed-size metadata all-gather (128 KiB)
 
 
 def _seam_planes(origins) -> Tuple[List[int], List[int], List[int]]:
@@ -34,7 +36,7 @@ def _seam_planes(origins) -> Tuple[List[int], List[int], List[int]]:
     return seams
 
 
-def label_skeleton(skeleton_u8: Tensor, crop=FLOOD_CROP, reference_ids: bool = True) -> Tensor:
+def label_skeleton(skeleton_u8: Tensor, crop=FLOOD_CROP, reference_ids: bool = True, profile=None) -> Tensor:
     """(X, Y, Z) uint8 binary skeleton on the GPU -> (X, Y, Z) int32 labels.
 
     ``reference_ids=True`` reproduces the reference's label VALUES (its 1000x1000x200 crop grid
@@ -56,8 +58,9 @@ def label_skeleton(skeleton_u8: Tensor, crop=FLOOD_CROP, reference_ids: bool = T
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     state = torch.tensor([1, 0, 0, 0], dtype=torch.int32, device=dev)  # running id starts at 1 (:33)
     for (x, y, z) in origins:
-        _ffi.check(_ffi.lib.sk_ccl_crop(_ffi.ptr(skeleton_u8), _ffi.ptr(labels), X, Y, Z, x, y, z,
-                                        w, h, d, _ffi.ptr(ws), ws_bytes, _ffi.ptr(state), st))
+        with maybe_span(profile, "ccl", dev, CCL_BYTES_PER_VOXEL * w * h * d):
+            _ffi.check(_ffi.lib.sk_ccl_crop(_ffi.ptr(skeleton_u8), _ffi.ptr(labels), X, Y, Z, x, y, z,
+                                            w, h, d, _ffi.ptr(ws), ws_bytes, _ffi.ptr(state), st))
     del ws
     seams = _seam_planes(origins)
     planes = [(axis, v) for axis in range(3) for v in seams[axis] if v > 0]
@@ -100,7 +103,7 @@ def label_skeleton(skeleton_u8: Tensor, crop=FLOOD_CROP, reference_ids: bool = T
     return labels
 
 
-def label_slab(skeleton_win: Tensor, shape, slab, window, slabs, rank: int, comm, sparse=None):
+def label_slab(skeleton_win: Tensor, shape, slab, window, slabs, rank: int, comm, sparse=None, profile=None):
     """Z-sharded labelling.  ``skeleton_win``: this rank's (X, Y, window) uint8 mask.
     Labels the rank's slab, merges components across slab boundaries (exchange of the
     boundary label planes + all-gather of the seam equivalences) and all-gathers the
@@ -117,45 +120,63 @@ def label_slab(skeleton_win: Tensor, shape, slab, window, slabs, rank: int, comm
     ws_bytes = _ffi.lib.sk_ccl_workspace_bytes(X * Y * zl)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     state = torch.tensor([-1, 0, 0, 0], dtype=torch.int32, device=dev)  # first id = state[0] + 2 = 1
-    _ffi.check(_ffi.lib.sk_ccl_crop(_ffi.ptr(skeleton_win), _ffi.ptr(local), X, Y, skeleton_win.shape[2],
-                                    0, 0, zlo - w0, X, Y, zl, _ffi.ptr(ws), ws_bytes, _ffi.ptr(state), st))
+    with maybe_span(profile, "ccl", dev, CCL_BYTES_PER_VOXEL * X * Y * zl):
+        _ffi.check(_ffi.lib.sk_ccl_crop(_ffi.ptr(skeleton_win), _ffi.ptr(local), X, Y, skeleton_win.shape[2],
+                                        0, 0, zlo - w0, X, Y, zl, _ffi.ptr(ws), ws_bytes, _ffi.ptr(state), st))
     del ws
     mine = local[:, :, zlo - w0:zhi - w0].contiguous()
-    k_local = int(state[1].item())
-    counts = [int(t.item()) for t in comm.all_gather(torch.tensor([k_local], dtype=torch.int64, device=dev))]
-    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    total = int(offsets[-1])
-    off = int(offsets[rank])
-    # boundary planes: the first plane of every slab goes to the rank below it
+    # boundary planes (LOCAL ids: no offsets needed yet): the first plane of every slab goes to the rank below it
     world = len(slabs)
     sends, like = [], []
     if rank > 0:
         sends.append((rank - 1, mine[:, :, 0].contiguous()))
     if rank < world - 1:
         like.append((rank + 1, torch.empty((X, Y), dtype=torch.int32, device=dev)))
-    got = comm.exchange(sends, like)
-    pairs_np = np.zeros((0, 2), dtype=np.int32)
+    got = comm.exchange(sends, like, what="label_seam_planes")
+    pairs_dev = torch.zeros((0, 2), dtype=torch.int32, device=dev)
     if rank < world - 1:
-        upper = got[0]
-        two = torch.stack([mine[:, :, zl - 1] + (mine[:, :, zl - 1] > 0) * off,
-                           upper + (upper > 0) * int(offsets[rank + 1])], dim=2).to(torch.int32).contiguous()
+        # face-adjacent (my last plane, upper rank's first plane) pairs, both in their rank's local ids
+        two = torch.stack([mine[:, :, zl - 1], got[0]], dim=2).contiguous()
         cap = X * Y
         pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
         count = torch.zeros(1, dtype=torch.int32, device=dev)
         _ffi.check(_ffi.lib.sk_seam_pairs(_ffi.ptr(two), X, Y, 2, 2, 1, _ffi.ptr(pairs), _ffi.ptr(count), cap, st))
-        n = int(count.item())
+        n = int(count.item())   # local sync only (no collective behind it)
         if n:
-            pairs_np = np.unique(pairs[:n].cpu().numpy(), axis=0)
-    # all-gather the (few) seam equivalences, padded to a common length (+ the slab's foreground count)
+            pairs_dev = torch.unique(pairs[:n], dim=0)   # sorted (a, b): the reference's nested unique() loops
     nz = torch.nonzero(mine.reshape(-1)).flatten()  # positions do not change under the relabelling below
-    meta = comm.all_gather(torch.tensor([len(pairs_np), nz.numel()], dtype=torch.int64, device=dev))
-    lens = [int(t[0].item()) for t in meta]
-    nnz = [int(t[1].item()) for t in meta]
-    mx = max(max(lens), 1)
-    pad = np.zeros((mx, 2), dtype=np.int32)
-    pad[:len(pairs_np)] = pairs_np
-    allp = [t.cpu().numpy()[:l] for t, l in zip(comm.all_gather(torch.from_numpy(pad).to(dev)), lens)]
-    allp = np.ascontiguousarray(np.concatenate(allp, axis=0).astype(np.int32))
+    # ONE fixed-size all-gather carries everything the ranks need from each other before the label volume itself:
+    # [components, seam pairs, foreground voxels | the seam pairs, padded].  A rank with more than PAIR_CAP pairs (never
+    # seen: a pair is one skeleton crossing a slab boundary) triggers a second, exactly sized gather of the pairs.
+    k_local = state[1:2].to(torch.int32)              # still on the device
+    msg = torch.zeros(4 + 2 * PAIR_CAP, dtype=torch.int32, device=dev)
+    msg[0:1] = k_local
+    msg[1] = pairs_dev.shape[0]
+    msg[2] = nz.numel() & 0x7FFFFFFF
+    msg[3] = nz.numel() >> 31
+    npair_fit = min(pairs_dev.shape[0], PAIR_CAP)
+    msg[4:4 + 2 * npair_fit] = pairs_dev[:npair_fit].reshape(-1)
+    meta = torch.stack(comm.all_gather(msg, what="label_meta")).cpu().numpy()
+    counts = [int(m[0]) for m in meta]
+    lens = [int(m[1]) for m in meta]
+    nnz = [int(m[2]) + (int(m[3]) << 31) for m in meta]
+    k_local = counts[rank]
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    total = int(offsets[-1])
+    off = int(offsets[rank])
+    if max(lens) > PAIR_CAP:
+        mx = max(lens)
+        pad = torch.zeros((mx, 2), dtype=torch.int32, device=dev)
+        pad[:pairs_dev.shape[0]] = pairs_dev
+        per_rank = [t.cpu().numpy()[:l] for t, l in zip(comm.all_gather(pad, what="label_meta"), lens)]
+    else:
+        per_rank = [m[4:4 + 2 * l].reshape(l, 2) for m, l in zip(meta, lens)]
+    # local -> global ids.  sk_seam_pairs emits (label in plane 1, label in plane 0) = (upper rank's id, this rank's
+    # id): column 0 shifts by offsets[r + 1], column 1 by offsets[r]
+    allp = [p.astype(np.int64) + np.array([offsets[min(r + 1, world - 1)], offsets[r]], dtype=np.int64)
+            for r, p in enumerate(per_rank) if len(p)]
+    allp = (np.ascontiguousarray(np.concatenate(allp, axis=0).astype(np.int32)) if allp
+            else np.zeros((0, 2), dtype=np.int32))
     lut = np.arange(total + 1, dtype=np.int32)
     if len(allp):
         to_rep = np.empty(2 * len(allp), dtype=np.int32)
@@ -184,7 +205,7 @@ def label_slab(skeleton_win: Tensor, shape, slab, window, slabs, rank: int, comm
         if packed.numel() < cap:
             packed = torch.cat([packed, torch.zeros(cap - packed.numel(), dtype=torch.int64, device=dev)])
         full = torch.zeros(X * Y * Z, dtype=torch.int32, device=dev)
-        for part, n_r in zip(comm.all_gather(packed), nnz):
+        for part, n_r in zip(comm.all_gather(packed, what="label_gather"), nnz):
             part = part[:n_r]
             full[part >> 32] = (part & 0xFFFFFFFF).to(torch.int32)
         return full.view(X, Y, Z), total
@@ -193,7 +214,7 @@ def label_slab(skeleton_win: Tensor, shape, slab, window, slabs, rank: int, comm
         padded[:, :, :zl] = mine
     else:
         padded = mine
-    parts = comm.all_gather(padded)
+    parts = comm.all_gather(padded, what="label_gather")
     full = torch.cat([p[:, :, :b - a] for p, (a, b) in zip(parts, slabs)], dim=2).contiguous()
     return full, total
 

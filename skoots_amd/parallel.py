@@ -122,38 +122,90 @@ def halo_plan(slabs: List[Tuple[int, int]], windows: List[Tuple[int, int]], rank
 
 
 class Comm:
-    """Thin wrapper: RCCL moves device tensors directly; gloo stages through the host."""
+    """Thin wrapper: RCCL moves device tensors directly; gloo stages through the host.
+
+    Every call is accounted under a ``what`` tag (bytes this rank SENDS, time on the calling stream:
+    HIP events for RCCL, wall clock for the host-staged gloo rehearsal) -- ``stats()`` is what
+    bench.py prints for N > 1, so that a scaling curve can be read per exchange step."""
 
     def __init__(self, rank: int, world: int):
         self.rank, self.world = rank, world
         self.staged = world > 1 and dist.get_backend() == "gloo"
+        self._acct: Dict[str, Dict[str, object]] = {}
 
     def _out(self, t: Tensor) -> Tensor:
         return t.cpu() if (self.staged and t.is_cuda) else t
 
-    def all_gather(self, t: Tensor) -> List[Tensor]:
+    # -- accounting ----------------------------------------------------------------------
+    class _Span:
+        def __init__(self, comm: "Comm", what: str, nbytes: int, device):
+            self.c, self.what, self.nbytes, self.device = comm, what, int(nbytes), device
+
+        def __enter__(self):
+            self.ev = None
+            if (not self.c.staged) and self.device is not None and self.device.type == "cuda":
+                self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                self.ev[0].record(torch.cuda.current_stream(self.device))
+            self.t0 = time.perf_counter()
+            return self
+
+        def __exit__(self, *exc):
+            a = self.c._acct.setdefault(self.what, {"bytes": 0, "calls": 0, "wall_s": 0.0, "events": []})
+            a["bytes"] += self.nbytes
+            a["calls"] += 1
+            if self.ev is not None:
+                self.ev[1].record(torch.cuda.current_stream(self.device))
+                a["events"].append(self.ev)
+            else:
+                a["wall_s"] += time.perf_counter() - self.t0
+            return False
+
+    def span(self, what: str, nbytes: int, device=None) -> "_Span":
+        return Comm._Span(self, what, nbytes, device)
+
+    def stats(self) -> Dict[str, Dict[str, float]]:
+        """{tag: {"bytes": sent by this rank, "ms": time, "calls": n}} accumulated since construction."""
+        out = {}
+        for k, a in self._acct.items():
+            ms = a["wall_s"] * 1e3
+            for e0, e1 in a["events"]:
+                e1.synchronize()
+                ms += e0.elapsed_time(e1)
+            out[k] = {"bytes": int(a["bytes"]), "ms": round(ms, 3), "calls": int(a["calls"])}
+        return out
+
+    # -- collectives ---------------------------------------------------------------------
+    def all_gather(self, t: Tensor, what: str = "all_gather") -> List[Tensor]:
         if self.world == 1:
             return [t]
         src = self._out(t.contiguous())
-        if not self.staged:  # RCCL: one flat output buffer, no per-rank list copies
-            flat = torch.empty((self.world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
-            dist.all_gather_into_tensor(flat, src)
-            return list(flat.unbind(0))
-        outs = [torch.empty_like(src) for _ in range(self.world)]
-        dist.all_gather(outs, src)
-        return [o.to(t.device) for o in outs]
+        with self.span(what, src.numel() * src.element_size() * (self.world - 1), t.device):
+            if not self.staged:  # RCCL: one flat output buffer, no per-rank list copies
+                flat = torch.empty((self.world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+                dist.all_gather_into_tensor(flat, src)
+                return list(flat.unbind(0))
+            outs = [torch.empty_like(src) for _ in range(self.world)]
+            dist.all_gather(outs, src)
+            return [o.to(t.device) for o in outs]
 
-    def all_reduce_min(self, t: Tensor) -> Tensor:
+    def all_reduce_min(self, t: Tensor, what: str = "all_reduce") -> Tensor:
         if self.world == 1:
             return t
         src = self._out(t)
-        dist.all_reduce(src, op=dist.ReduceOp.MIN)
+        with self.span(what, 2 * src.numel() * src.element_size() * (self.world - 1) // self.world, t.device):
+            dist.all_reduce(src, op=dist.ReduceOp.MIN)
         return src.to(t.device)
 
-    def exchange(self, sends: List[Tuple[int, Tensor]], recv_like: List[Tuple[int, Tensor]]) -> List[Tensor]:
+    def exchange(self, sends: List[Tuple[int, Tensor]], recv_like: List[Tuple[int, Tensor]],
+                 what: str = "p2p") -> List[Tensor]:
         """Point-to-point batch: sends [(peer, tensor)], recv_like [(peer, empty tensor)]."""
         if self.world == 1:
             return []
+        dev = sends[0][1].device if sends else (recv_like[0][1].device if recv_like else None)
+        with self.span(what, sum(t.numel() * t.element_size() for _, t in sends), dev):
+            return self._exchange(sends, recv_like)
+
+    def _exchange(self, sends, recv_like) -> List[Tensor]:
         ops, staged_recv = [], []
         for peer, t in sends:
             ops.append(dist.P2POp(dist.isend, self._out(t.contiguous()), peer))
@@ -167,7 +219,7 @@ class Comm:
         return [b.to(t.device) for b, (_, t) in zip(staged_recv, recv_like)]
 
 
-def exchange_halo(arr: Tensor, slabs, windows, rank: int, comm: Comm, needs=None) -> None:
+def exchange_halo(arr: Tensor, slabs, windows, rank: int, comm: Comm, needs=None, what: str = "halo") -> None:
     """Fill the halo planes of a window-shaped array (X, Y, Zl, ...) from their owners.  ``needs``:
     per-rank plane ranges (inside the windows) that are actually read afterwards; default: the windows."""
     sends, recvs = halo_plan(slabs, windows if needs is None else needs, rank)
@@ -175,7 +227,7 @@ def exchange_halo(arr: Tensor, slabs, windows, rank: int, comm: Comm, needs=None
     out = [(q, arr[:, :, lo - w0:hi - w0]) for q, lo, hi in sends]
     like = [(q, torch.empty((arr.shape[0], arr.shape[1], hi - lo) + tuple(arr.shape[3:]), dtype=arr.dtype,
                             device=arr.device)) for q, lo, hi in recvs]
-    got = comm.exchange(out, like)
+    got = comm.exchange(out, like, what=what)
     for (q, lo, hi), t in zip(recvs, got):
         arr[:, :, lo - w0:hi - w0] = t
 
@@ -220,7 +272,7 @@ def exchange_blocks(arrays: Sequence[Tensor], blocks, windows, rank: int, comm: 
             n = sum((b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]) for b in in_by[peer]) * tail
             like.append((peer, torch.empty(n, dtype=arr.dtype, device=arr.device)))
             dst_views.append([view(arr, b) for b in in_by[peer]])
-    got = comm.exchange(sends, like)
+    got = comm.exchange(sends, like, what="block_exchange")
     for views, flat in zip(dst_views, got):
         at = 0
         for v in views:
@@ -241,6 +293,8 @@ class ShardedVolume:
         self.windows = [window_of(s, self.shape[2], world, halo) for s in self.slabs]
         self.slab, self.window = self.slabs[rank], self.windows[rank]
         self.timings: Dict[str, float] = {}
+        self.comm = Comm(rank, world)      # persistent: its per-exchange accounting accumulates over run() calls
+        self.tiles_this_rank = 0
 
     def _side_stream(self, i: int):
         if not hasattr(self, "_streams"):
@@ -256,7 +310,7 @@ class ShardedVolume:
     def run(self, image: Tensor, model, scale, mean: float, std: float, n: int = 10,
             decay: float = 1.0, tile=(300, 300, 20), tile_overlap=(50, 50, 5), tile_batch: int = 8,
             inject: Optional[Callable] = None, keep_planar_vectors: bool = False,
-            conv_profile=None, streams: int = 1) -> Dict[str, object]:
+            conv_profile=None, streams: int = 1, stage_profile=None) -> Dict[str, object]:
         """``image``: this rank's window of the fp16 volume, shape (X, Y, window planes)."""
         from . import _ffi
         from .lib.eval import ASSIGN_CROP, ASSIGN_OVERLAP, VolumeState
@@ -265,14 +319,16 @@ class ShardedVolume:
         X, Y, Z = self.shape
         (zlo, zhi), (wlo, whi) = self.slab, self.window
         dev = self.device
-        comm = Comm(self.rank, self.world)
+        comm = self.comm
         assert tuple(image.shape) == (X, Y, whi - wlo), (tuple(image.shape), (X, Y, whi - wlo))
         state = VolumeState(self.shape, dev, window=self.window, keep_planar_vectors=keep_planar_vectors)
+        state.profile = stage_profile
 
         # ---- stage 1 --------------------------------------------------------------------
         t0 = time.perf_counter()
         plan, eff = tile_plan(self.shape, tile, tile_overlap, self.world, halo=self.halo)
         origins = plan[self.rank]
+        self.tiles_this_rank = len(origins)
         for (_, _, oz) in origins:
             assert wlo <= oz and oz + eff[2] <= whi, "tile outside the rank's window: increase the halo"
         owners = [cropper.owner_table(dm, c, o) for dm, c, o in zip(self.shape, eff, tile_overlap)]
@@ -322,11 +378,12 @@ class ShardedVolume:
         # ---- stage 2 --------------------------------------------------------------------
         t0 = time.perf_counter()
         if self.world == 1:
-            labels = label_skeleton(state.skeleton, reference_ids=False)
+            labels = label_skeleton(state.skeleton, reference_ids=False, profile=stage_profile)
             n_labels_hint = None
         else:
             labels, n_labels_hint = label_slab(state.skeleton, self.shape, self.slab, self.window,
-                                               self.slabs, self.rank, comm, sparse=self.sparse_labels)
+                                               self.slabs, self.rank, comm, sparse=self.sparse_labels,
+                                               profile=stage_profile)
         state.labels = labels
         self._tick("stage2", t0)
 
@@ -334,7 +391,8 @@ class ShardedVolume:
         t0 = time.perf_counter()
         if self.world > 1:
             exchange_halo(state.vec4, self.slabs, self.windows, self.rank, comm,
-                          needs=assign_reach(self.shape, ASSIGN_CROP, ASSIGN_OVERLAP, self.slabs, self.windows))
+                          needs=assign_reach(self.shape, ASSIGN_CROP, ASSIGN_OVERLAP, self.slabs, self.windows),
+                          what="vector_halo")
         inst = state.assign(scale, n=n, decay=decay, crop=ASSIGN_CROP, overlap=ASSIGN_OVERLAP,
                             labels=labels, z_range=self.slab)
         self._tick("stage3", t0)
@@ -361,7 +419,7 @@ def distributed_renumber(inst: Tensor, shape, slab, max_label: int, comm: Comm) 
     _ffi.check(_ffi.lib.sk_first_seen(_ffi.ptr(inst), X, Y, slab[1] - slab[0], slab[0], Z, max_label,
                                       _ffi.ptr(first), _ffi.stream_ptr(dev)))
     f64 = first.to(torch.int64) & 0xFFFFFFFF
-    f64 = comm.all_reduce_min(f64)
+    f64 = comm.all_reduce_min(f64, what="renumber_allreduce")
     seen = torch.nonzero(f64 != 0xFFFFFFFF).flatten()
     order = torch.argsort(f64[seen])
     lut = torch.zeros(max_label + 1, dtype=torch.int32, device=dev)

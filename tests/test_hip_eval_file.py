@@ -88,3 +88,61 @@ def test_eval_used_cached_data(tmp_path):
     first = read(str(tmp_path / "v_instance_mask.tif"))
     sk_eval(ipath, cpath, used_cached_data=True)
     assert np.array_equal(read(str(tmp_path / "v_instance_mask.tif")), first)
+
+
+def _write_tif(path, arr):
+    """Multi-page TIFF as the reference's users hold them: arr [Z, X, Y] uint8 / uint16 or [Z, X, Y, 4] uint8."""
+    from PIL import Image
+    pages = [Image.fromarray(p) for p in arr]
+    pages[0].save(path, save_all=True, append_images=pages[1:])
+
+
+@pytest.mark.parametrize("kind", ["u8", "u16", "rgba"])
+def test_eval_reads_multipage_tif(tmp_path, kind):
+    """eval.py:61-64: a multi-page tif [Z, X, Y(, C)] -> [C=1, X, Y, Z]; with more than 3 channels channel
+    index 2 is the image.  Same answer as the .npy of the same stack (the read branch the other tests skip)."""
+    from oracle import unet_spec
+    from skoots_amd.lib import zarr_store
+    from skoots_amd.lib.eval import _read_image, eval as sk_eval
+    ref = unet_spec.build()
+    with torch.no_grad():
+        ref.heads.weight[3:5].mul_(0.05)
+        ref.heads.weight[0:3].mul_(1e-5)
+        ref.heads.bias[0:3] = 1e-5
+        ref.heads.bias[3] = 2.2
+        ref.heads.bias[4] = 3.0
+    gen = torch.Generator().manual_seed(5)
+    Z, X, Y = 22, 124, 130
+    if kind == "u16":
+        stack = torch.randint(0, 4096, (Z, X, Y), generator=gen, dtype=torch.int32).numpy().astype(np.uint16)
+        tif_arr, plain = stack, stack
+    elif kind == "rgba":
+        tif_arr = torch.randint(0, 256, (Z, X, Y, 4), generator=gen, dtype=torch.uint8).numpy()
+        plain = np.ascontiguousarray(tif_arr[..., 2])   # eval.py:64: image[[2], ...]
+    else:
+        stack = torch.randint(0, 256, (Z, X, Y), generator=gen, dtype=torch.uint8).numpy()
+        tif_arr, plain = stack, stack
+    tpath, npath, cpath = str(tmp_path / "t.tif"), str(tmp_path / "n.npy"), str(tmp_path / "m.trch")
+    _write_tif(tpath, tif_arr)
+    np.save(npath, plain)
+    got = _read_image(tpath)
+    assert got.shape == tif_arr.shape and got.dtype == tif_arr.dtype and np.array_equal(got, tif_arr)
+    cfg = {"SKOOTS": {"VECTOR_SCALING": (60, 60, 12)}, "MODEL": {"DIMS": [32, 64, 128, 64, 32], "DEPTHS": [2] * 5}}
+    stats = {"dataset_mean": 2000.0, "dataset_std": 1100.0} if kind == "u16" else {}
+    torch.save({"cfg": cfg, "model_state_dict": ref.state_dict(), **stats}, cpath)
+    sk_eval(tpath, cpath)
+    sk_eval(npath, cpath)
+    for suffix in ("_skoots_skeleton.zarr", "_skoots_vectors.zarr"):
+        a, b = zarr_store.load(str(tmp_path / "t") + suffix), zarr_store.load(str(tmp_path / "n") + suffix)
+        assert a.shape[1:] == (X, Y, Z) and np.array_equal(a, b)
+    from PIL import Image
+
+    def read(p):
+        with Image.open(p) as im:
+            out = []
+            for i in range(im.n_frames):
+                im.seek(i)
+                out.append(np.array(im))
+        return np.stack(out)
+    ma, mb = read(str(tmp_path / "t_instance_mask.tif")), read(str(tmp_path / "n_instance_mask.tif"))
+    assert ma.shape == (Z, X, Y) and np.array_equal(ma, mb) and ma.max() >= 1

@@ -25,12 +25,15 @@ def _field():
     return blob_field(SHAPE, seed=11, n_blobs=120, rmax=(9, 9, 3))
 
 
-def _run_rank(rank, world, port, q, sparse=None):
+def _run_rank(rank, world, port, q, sparse=None, pair_cap=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from skoots_amd.parallel import ShardedVolume
+        if pair_cap is not None:   # force the overflow path of the seam-pair metadata gather
+            from skoots_amd.lib import flood_fill
+            flood_fill.PAIR_CAP = pair_cap
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
         out_vol, _ = _field()
@@ -45,13 +48,13 @@ def _run_rank(rank, world, port, q, sparse=None):
             return out_dev[:, x:x + eff[0], y:y + eff[1], z:z + eff[2]].contiguous()
 
         res = sv.run(image, None, (60, 60, 12), 0.0, 1.0, inject=inject)
-        q.put((rank, sv.slab, res["instance_mask"].cpu().numpy(), res["n_instances"]))
+        q.put((rank, sv.slab, res["instance_mask"].cpu().numpy(), res["n_instances"], sv.comm.stats()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,sparse", [(2, None), (3, None), (2, False)])
-def test_sharded_equals_single(world, sparse):
+@pytest.mark.parametrize("world,sparse,pair_cap", [(2, None, None), (3, None, None), (2, False, None), (2, None, 0)])
+def test_sharded_equals_single(world, sparse, pair_cap):
     from skoots_amd.lib import eval as E
     out_vol, k = _field()
     dev = "cuda:0"
@@ -69,7 +72,7 @@ def test_sharded_equals_single(world, sparse):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_rank, args=(r, world, port, q, sparse)) for r in range(world)]
+    procs = [ctx.Process(target=_run_rank, args=(r, world, port, q, sparse, pair_cap)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in range(world)]
@@ -77,7 +80,12 @@ def test_sharded_equals_single(world, sparse):
         p.join(timeout=120)
         assert p.exitcode == 0
     got = np.zeros(SHAPE, dtype=np.int32)
-    for rank, slab, inst, n in results:
+    for rank, slab, inst, n, comm_stats in results:
         got[:, :, slab[0]:slab[1]] = inst
         assert n == single["n_instances"]
+        # per-exchange accounting that bench.py prints for N > 1: one metadata gather per run (two on the overflow path)
+        for key in ("block_exchange", "label_seam_planes", "label_meta", "label_gather", "vector_halo", "renumber_allreduce"):
+            assert key in comm_stats and comm_stats[key]["calls"] >= 1, (key, comm_stats)
+        # seed 11 puts skeleton cores across the z = 90 slab boundary: with a zero pair capacity the second gather runs
+        assert comm_stats["label_meta"]["calls"] == (2 if pair_cap is not None else 1), comm_stats["label_meta"]
     assert np.array_equal(got, want)

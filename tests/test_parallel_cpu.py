@@ -244,3 +244,42 @@ def test_gradient_sync_gloo():
     want = (torch.arange(10, dtype=torch.float32) * 1.5).tolist()
     for _, got in results:
         assert got == want
+
+
+# ---- bench.py --gpus N launch path (no launcher in front of it) ------------------------------------
+def _bench(*argv, env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True,
+                          timeout=600, env=e)
+
+
+def test_bench_launcher_spawns_ranks_gloo():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts two ranks itself (here: the gloo dry run of the
+    launch path) and relays rank 0's single JSON line."""
+    import json
+    r = _bench("--gpus", "2", "--launcher-dry-run")
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["rank_sum"] == 1 and line["launcher"] == "ok"
+
+
+def test_bench_refuses_more_gpus_than_devices():
+    """A multi-GPU request on a node without that many devices fails loudly: non-zero exit, no JSON line
+    (the old behaviour printed n_gpus: 1 for `--gpus 8`)."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("node has 8 devices")
+    r = _bench("--gpus", "8", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert "refusing" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_refuses_world_size_mismatch():
+    r = _bench("--gpus", "4", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
