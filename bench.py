@@ -411,6 +411,124 @@ def eval_main(args, rank, world, local):
         dist.destroy_process_group()
 
 
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: one training step
+# ---------------------------------------------------------------------------------------------------
+def train_cpu_baseline(crop=(64, 64, 64)):
+    """oracle/train_step.py (torch autograd + torch.optim.AdamW on oracle/unet_spec.py, fp32) on a sub-crop."""
+    from oracle import train_step as O
+    from oracle import unet_spec
+    threads = cpu_threads()
+    torch.set_num_threads(threads)
+    model = unet_spec.build().train()
+    opt = O.make_optimizer(model)
+    g = torch.Generator().manual_seed(0)
+    X, Y, Z = crop
+    images = torch.randn((1, 1, X, Y, Z), generator=g)
+    masks = (torch.rand((1, 1, X, Y, Z), generator=g) > 0.5).float()
+    skele = (torch.rand((1, 1, X, Y, Z), generator=g) > 0.9).float()
+    baked = torch.rand((1, 3, X, Y, Z), generator=g) * 64
+    sigma, scale = torch.tensor([20.0, 20.0, 20.0]), torch.tensor(SCALE)
+    O.train_step(model, opt, images, masks, skele, baked, sigma, scale)   # warm-up, untimed
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or time.perf_counter() - t0 < 8.0:
+        O.train_step(model, opt, images, masks, skele, baked, sigma, scale)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(X * Y * Z / dt / 1e6, 4), "unit": "Mvoxels/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/train_step.py (torch CPU fp32 autograd + AdamW, {threads} threads) on a {X}x{Y}x{Z} crop, "
+                      f"batch 1: {dt:.2f} s per step over {n} steps"}
+
+
+def train_main(args, rank, world, local):
+    """One training step of BASELINE configs[4] (skoots/train/engine.py:456-499: forward, three Tversky terms incl.
+    the embedding loss, backward, AdamW) on a synthetic 256^3 crop, batch 1 per GPU, random-init U-Net; N > 1 =
+    data-parallel replicas with one all-reduce of the flat gradient buffer per step (engine.py:113-115)."""
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path")
+    torch.cuda.set_device(local % ndev)
+    dev = torch.device("cuda", local % ndev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if ndev < world:
+            raise SystemExit(f"WORLD_SIZE={world} but only {ndev} device(s) visible")
+        dist.init_process_group("nccl", device_id=dev)
+    from skoots_amd.profile import KernelProfile
+    from skoots_amd.train import TrainStep, TrainUNet
+    from skoots_amd.unet import random_state_dict
+    X, Y, Z = (int(v) for v in args.shape.split(",")) if args.shape else (256, 256, 256)
+    B = 1
+    model = TrainUNet(random_state_dict(), dev, precision=args.precision)
+    step = TrainStep(model, process_group=None if world > 1 else False)
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    images = torch.randn((B, 1, X, Y, Z), device=dev, generator=gen)
+    gx = torch.arange(X, device=dev).view(X, 1, 1)
+    gy = torch.arange(Y, device=dev).view(1, Y, 1)
+    gz = torch.arange(Z, device=dev).view(1, 1, Z)
+    cell = ((gx // 32) * 64 + (gy // 32) * 8 + gz // 32 + 1).float()
+    inside = ((gx % 32 - 16) ** 2 + (gy % 32 - 16) ** 2 + (gz % 32 - 16) ** 2) < 12 ** 2
+    masks = (cell * inside).expand(B, 1, X, Y, Z).contiguous()
+    skele = (((gx % 32 - 16).abs() < 2) & ((gy % 32 - 16).abs() < 2) & ((gz % 32 - 16).abs() < 6)).float() \
+        .expand(B, 1, X, Y, Z).contiguous()
+    baked = torch.stack([(gx // 32 * 32 + 16).expand(X, Y, Z), (gy // 32 * 32 + 16).expand(X, Y, Z),
+                         (gz // 32 * 32 + 16).expand(X, Y, Z)]).float().expand(B, 3, X, Y, Z).contiguous()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        losses = step(images, masks, skele, baked)
+    barrier()
+    prof = KernelProfile()
+    model._L.profile = prof if model.fast16 else None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step(images, masks, skele, baked)
+    barrier()
+    dt = time.perf_counter() - t0
+    model._L.profile = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        line = {"metric": "training Mvoxels/s (U-Net fwd + Tversky/embedding loss + bwd + AdamW)",
+                "value": round(world * B * X * Y * Z / (dt / args.steps) / 1e6, 3), "unit": "Mvoxels/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": {"bf16": "bf16", "mixed": "f16 operands (f32 master / accumulate)", "fp32": "f32"}[args.precision],
+                "data": "synthetic",
+                "config": {"workload": f"BASELINE configs[4]: {X}x{Y}x{Z} crop, batch {B} per GPU, random-init U-Net dims "
+                                       f"[32,64,128,64,32], 3 Tversky terms (embedding sigma 20), AdamW; data-parallel x{world}",
+                           "precision": args.precision, "steps_per_s": round(args.steps / dt * world, 4),
+                           "losses": [round(float(v), 6) for v in losses.cpu()],
+                           "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}}
+        tot = prof.totals()
+        if tot:
+            kms = sum(v[0] for v in tot.values())
+            kfl = sum(v[1] for v in tot.values())
+            ach = kfl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+            line["roofline"] = {"bound": "mfma", "kernel": "all MFMA conv launches of the step: forward + data-gradient "
+                                                           "(conv3_*/gather_gemm) and weight-gradient (wgrad16*) kernels",
+                                "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                "launches": sum(v[2] for v in tot.values()),
+                                "ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in tot.items()},
+                                "tflops": {k: round(v[1] / (v[0] * 1e-3) / 1e12, 1) for k, v in tot.items() if v[0] > 0}}
+        if not args.no_cpu_baseline and world == 1:
+            log("timing the CPU restatement of the training step (bounded sample)")
+            line["cpu_baseline"] = train_cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -445,7 +563,8 @@ def main():
     if args.launcher_dry_run:
         return launcher_dry_run(rank, world)
     if args.config == "train":
-        from tools.bench_train import train_main
+        if args.precision not in ("bf16", "mixed", "fp32"):
+            raise SystemExit(f"--precision {args.precision} is an eval precision; train takes bf16 | mixed | fp32")
         return train_main(args, rank, world, local)
     if args.precision not in ("fp16", "split", "fp32"):
         raise SystemExit(f"--precision {args.precision} is a training precision; eval takes fp16 | split | fp32")

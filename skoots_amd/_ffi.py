@@ -120,6 +120,25 @@ _SIGS = {
     "sk_train_adamw": (i32, [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, vp]),
 }
 
+# bf16 twins (include/skoots_hip_bf16.h): the training-path sources are compiled a second time on bf16 storage and
+# exported with the suffix _bf16, same signatures
+BF16_TWINS = (
+    "sk_conv3d", "sk_conv3d_num_blocks", "sk_conv3d_pack_weight_host", "sk_conv3d_pack_weight_split_host",
+    "sk_conv3d_split", "sk_conv3d_stem", "sk_conv3d_stem_apply", "sk_conv3d_stem_apply_split",
+    "sk_conv3d_stem_num_blocks", "sk_conv3d_stem_workspace_bytes", "sk_groupnorm_finalize",
+    "sk_groupnorm_finalize_stats", "sk_groupnorm_silu", "sk_groupnorm_silu_split", "sk_heads", "sk_heads_split",
+    "sk_baked_embed_to_prob", "sk_train_absmax_scale", "sk_train_adamw", "sk_train_cast_f16_f32",
+    "sk_train_cast_f32_f16", "sk_train_conv_wgrad", "sk_train_conv_wgrad_f16",
+    "sk_train_conv_wgrad_workspace_floats", "sk_train_gn_bwd_f16_workspace_floats", "sk_train_gn_bwd_num_blocks",
+    "sk_train_gn_bwd_workspace_floats", "sk_train_gn_silu", "sk_train_gn_silu_bwd", "sk_train_gn_silu_bwd_f16",
+    "sk_train_gn_silu_bwd_f16h", "sk_train_gn_silu_f16", "sk_train_heads_fwd_f16", "sk_train_heads_wgrad_f16",
+    "sk_train_heads_wgrad_workspace_floats", "sk_train_interleave2", "sk_train_interleave2_add16", "sk_train_loss",
+    "sk_train_loss_num_blocks", "sk_train_loss_workspace_floats", "sk_train_pack_weight", "sk_train_stem_fwd_f16",
+    "sk_train_stem_wgrad_f16", "sk_train_sumpool2", "sk_train_sumpool2_f16", "sk_train_tversky",
+)
+for _name in BF16_TWINS:
+    _SIGS[_name + "_bf16"] = _SIGS[_name]
+
 EXPORTS = tuple(_SIGS)
 _missing = []
 for _name, (_res, _args) in _SIGS.items():
@@ -131,7 +150,7 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.restype = _res
     _fn.argtypes = _args
 if _missing:
-    raise ImportError(f"{LIB_PATH} lacks symbols declared in include/skoots_hip.h: {_missing}")
+    raise ImportError(f"{LIB_PATH} lacks symbols declared in include/skoots_hip*.h: {_missing}")
 
 
 def last_error() -> str:

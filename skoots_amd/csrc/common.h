@@ -7,6 +7,25 @@
 
 #include "../../include/skoots_hip.h"
 
+// 16-bit floating type of the matrix-core operands and of every 16-bit activation / gradient tensor.  The library is
+// fp16 (the inference dtype BASELINE's configs name, fp16 autocast at skoots/lib/eval.py:142).  The sources on the
+// training step's path (conv3d.hip, unet_misc.hip, train.hip) are compiled a second time with -DSK_BF16 -- the same
+// kernels with bf16 storage and v_mfma_*_bf16, the dtype of the reference's training step (train/engine.py:68,107-109)
+// -- and the entry points of that build carry the suffix _bf16 (Makefile: llvm-objcopy --redefine-syms).
+#ifdef SK_BF16
+typedef __bf16 t16;
+#define SK_MFMA_32x32x16_T16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define SK_MFMA_16x16x32_T16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define SK_DS_READ_TR16_B64 __builtin_amdgcn_ds_read_tr16_b64_v4bf16
+#define SK_TR16_ELEM __bf16
+#else
+typedef _Float16 t16;
+#define SK_MFMA_32x32x16_T16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define SK_MFMA_16x16x32_T16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define SK_DS_READ_TR16_B64 __builtin_amdgcn_ds_read_tr16_b64_v4f16
+#define SK_TR16_ELEM __fp16
+#endif
+
 namespace sk {
 
 void set_error(const char* fmt, ...);

@@ -38,8 +38,8 @@
 
 namespace {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef t16 half8 __attribute__((ext_vector_type(8)));
+typedef t16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                         for (int d = 0; d < 3; ++d) {
                             const int o = i - d;  // x_in = x_out + (d - 1)
                             if (o >= 0 && o < XS)
-                                acc[p][o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[d], bfr, acc[p][o], 0, 0, 0);
+                                acc[p][o] = SK_MFMA_32x32x16_T16(afr[d], bfr, acc[p][o], 0, 0, 0);
                         }
                     }
                 }
@@ -402,10 +402,10 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                         for (int q = 0; q < 4; ++q) {
                             float v0 = acc[p][o][4 * q], v1 = acc[p][o][4 * q + 1];
                             float v2 = acc[p][o][4 * q + 2], v3 = acc[p][o][4 * q + 3];
-                            half4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+                            half4 hv = {(t16)v0, (t16)v1, (t16)v2, (t16)v3};
                             if (part == 1)   // lo = fp16(v - hi): exact difference, rounded once
-                                hv = half4{(_Float16)(v0 - (float)hv[0]), (_Float16)(v1 - (float)hv[1]),
-                                           (_Float16)(v2 - (float)hv[2]), (_Float16)(v3 - (float)hv[3])};
+                                hv = half4{(t16)(v0 - (float)hv[0]), (t16)(v1 - (float)hv[1]),
+                                           (t16)(v2 - (float)hv[2]), (t16)(v3 - (float)hv[3])};
                             *reinterpret_cast<half4*>(pad + col * kPadStride + ((q ^ ((col >> 1) & 3)) * 16) + 8 * h) = hv;
                             if (ok && part == 0) {
                                 gsum[q] += (v0 + v1) + (v2 + v3);
@@ -720,7 +720,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                                 const int o = i - d;  // x_in = x_out + (d - 1)
                                 if (o >= 0 && o < XS)
                                     acc[p][o][ks][j] =
-                                        __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[d], bfr, acc[p][o][ks][j], 0, 0, 0);
+                                        SK_MFMA_16x16x32_T16(afr[d], bfr, acc[p][o][ks][j], 0, 0, 0);
                             }
                         }
                     }
@@ -806,10 +806,10 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
                                 const f32x4 r = acc[p][o][i][j];
-                                half4 hv = {(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
+                                half4 hv = {(t16)r[0], (t16)r[1], (t16)r[2], (t16)r[3]};
                                 if (part == 1)   // lo = fp16(v - hi): exact difference, rounded once
-                                    hv = half4{(_Float16)(r[0] - (float)hv[0]), (_Float16)(r[1] - (float)hv[1]),
-                                               (_Float16)(r[2] - (float)hv[2]), (_Float16)(r[3] - (float)hv[3])};
+                                    hv = half4{(t16)(r[0] - (float)hv[0]), (t16)(r[1] - (float)hv[1]),
+                                               (t16)(r[2] - (float)hv[2]), (t16)(r[3] - (float)hv[3])};
                                 // voxel 16 j + c16, channels 16 i + 4 g .. +3 of the tile: 16-byte chunk 2 i + (g >> 1), half g & 1
                                 const int vx = 16 * j + c16;
                                 *reinterpret_cast<half4*>(pad + vx * kPadStride + (((2 * i + (g >> 1)) ^ ((vx >> 1) & 3)) * 16) +
@@ -997,15 +997,15 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
             const float gb[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};                     \
             _Pragma("unroll") for (int p = 0; p < PV; ++p) _Pragma("unroll") for (int j = 0; j < 8; ++j) {    \
                 float y = fmaf(ga[j], (float)bv[p][j], gb[j]);                                                \
-                bv[p][j] = (_Float16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));                         \
+                bv[p][j] = (t16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));                         \
             }                                                                                                 \
         }                                                                                                     \
         _Pragma("unroll") for (int p = 0; p < PV; ++p) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {    \
             if constexpr (SPLIT) {                                                                            \
-                acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[nt], bv[p], acc[p][nt], 0, 0, 0);     \
-                acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[nt], bvl[p], acc[p][nt], 0, 0, 0);     \
+                acc[p][nt] = SK_MFMA_32x32x16_T16(avl[nt], bv[p], acc[p][nt], 0, 0, 0);     \
+                acc[p][nt] = SK_MFMA_32x32x16_T16(av[nt], bvl[p], acc[p][nt], 0, 0, 0);     \
             }                                                                                                 \
-            acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[nt], bv[p], acc[p][nt], 0, 0, 0);          \
+            acc[p][nt] = SK_MFMA_32x32x16_T16(av[nt], bv[p], acc[p][nt], 0, 0, 0);          \
         }                                                                                                     \
     }
     int s0 = 0;
@@ -1032,12 +1032,12 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
                 float v0 = acc[p][nt][4 * q], v1 = acc[p][nt][4 * q + 1];
                 float v2 = acc[p][nt][4 * q + 2], v3 = acc[p][nt][4 * q + 3];
                 if (ok[p]) {
-                    half4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+                    half4 hv = {(t16)v0, (t16)v1, (t16)v2, (t16)v3};
                     char* dst = outb + vout[p] * kOvs + (32 * nt + 8 * q + 4 * h) * 2;
                     *reinterpret_cast<half4*>(dst) = hv;
                     if constexpr (SPLIT) {
-                        half4 lv = {(_Float16)(v0 - (float)hv[0]), (_Float16)(v1 - (float)hv[1]),
-                                    (_Float16)(v2 - (float)hv[2]), (_Float16)(v3 - (float)hv[3])};
+                        half4 lv = {(t16)(v0 - (float)hv[0]), (t16)(v1 - (float)hv[1]),
+                                    (t16)(v2 - (float)hv[2]), (t16)(v3 - (float)hv[3])};
                         *reinterpret_cast<half4*>(dst + COUT * 2) = lv;
                     }
                     gsum[nt][q] += (v0 + v1) + (v2 + v3);
@@ -1180,7 +1180,7 @@ int64_t sk_conv3d_pack_weight_host(const float* w, int cout, int cin, int ksize,
     const int NT = cout / 32, k3 = ksize * ksize * ksize;
     int64_t nfrag = (int64_t)k3 * (cin / 16) * NT;
     if (!dst) return nfrag * 1024;
-    __half* out = (__half*)dst;
+    t16* out = (t16*)dst;
     auto W = [&](int co, int ci, int kx, int ky, int kz) {
         return w[((((int64_t)co * cin + ci) * ksize + kx) * ksize + ky) * ksize + kz];
     };
@@ -1188,7 +1188,7 @@ int64_t sk_conv3d_pack_weight_host(const float* w, int cout, int cin, int ksize,
     auto emit = [&](int nt, int c0, int kx, int ky, int kz) {
         for (int l = 0; l < 64; ++l)
             for (int j = 0; j < 8; ++j)
-                out[f * 512 + l * 8 + j] = __float2half(W(32 * nt + (l & 31), c0 + 8 * (l >> 5) + j, kx, ky, kz));
+                out[f * 512 + l * 8 + j] = (t16)(W(32 * nt + (l & 31), c0 + 8 * (l >> 5) + j, kx, ky, kz));
         ++f;
     };
     // ksize 3 with cout 32 runs on v_mfma_f32_16x16x32_f16: fragment = [16 cout][32 channels of the chunk], lane l
@@ -1196,7 +1196,7 @@ int64_t sk_conv3d_pack_weight_host(const float* w, int cout, int cin, int ksize,
     auto emit16 = [&](int nt, int i, int c0, int kx, int ky, int kz) {
         for (int l = 0; l < 64; ++l)
             for (int j = 0; j < 8; ++j)
-                out[f * 512 + l * 8 + j] = __float2half(W(32 * nt + 16 * i + (l & 15), c0 + 8 * (l >> 4) + j, kx, ky, kz));
+                out[f * 512 + l * 8 + j] = (t16)(W(32 * nt + 16 * i + (l & 15), c0 + 8 * (l >> 4) + j, kx, ky, kz));
         ++f;
     };
     if (ksize == 3 && cout == 32) {   // the COUT-32 conv kernel is the 16x16x32 one
@@ -1377,9 +1377,9 @@ int64_t sk_conv3d_pack_weight_split_host(const float* w, int cout, int cin, int 
     const int64_t n = (int64_t)cout * cin * k3;
     std::vector<float> hi(n), lo(n);
     for (int64_t i = 0; i < n; ++i) {
-        const float h = __half2float(__float2half(w[i]));
+        const float h = (float)((t16)(w[i]));
         hi[i] = h;
-        lo[i] = __half2float(__float2half(w[i] - h));
+        lo[i] = (float)((t16)(w[i] - h));
     }
     if (ksize != 3) {
         const int64_t half_bytes = sk_conv3d_pack_weight_host(hi.data(), cout, cin, ksize, nullptr);

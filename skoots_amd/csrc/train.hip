@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) gn_silu_fwd_kernel(const float* __restric
 //   dgamma = sum_b S2, dbeta = sum_b S1
 //   dy = rstd * (gamma*du - m1 - xh*m2),  m1 = sum_{c in g} gamma*S1 / n,  m2 = sum_{c in g} gamma*S2 / n
 // ------------------------------------------------------------------------------------------
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef t16 half8_t __attribute__((ext_vector_type(8)));
 // voxels per reduction block: about 65536 / C blocks per sample (2048 for 32 channels; the one-block finalize reads
 // blocks x 4C floats, so wide layers get fewer), but never fewer than 512 voxels a block -- a quarter-resolution layer
 // (262 k voxels, 128 channels) still gets 512 blocks (with a fixed 8192 voxels it got 32)
@@ -549,8 +549,8 @@ __global__ void __launch_bounds__(64) wgrad_kernel(WgradArgs a) {
     }
 }
 
-__device__ inline _Float16 buf_load_f16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return __builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, 0));
+__device__ inline t16 buf_load_f16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(t16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, 0));
 }
 
 // Weight gradient of the stem (Cin = 1, k = 3): with one input channel the 27 taps take the place of the input
@@ -666,7 +666,7 @@ __global__ void scale_from_absmax_kernel(const unsigned* __restrict__ mx, float*
 }
 
 // 8 elements per lane where the length and the pointers allow (n % 8 == 0: every tensor of the network), else scalar
-__global__ void __launch_bounds__(256) cast_f32_f16_kernel(const float* __restrict__ x, __half* __restrict__ y, long long n,
+__global__ void __launch_bounds__(256) cast_f32_f16_kernel(const float* __restrict__ x, t16* __restrict__ y, long long n,
                                                            const float* __restrict__ scale, int vec) {
     const float s = scale ? scale[0] : 1.0f;
     const long long stride = (long long)gridDim.x * 256;
@@ -674,16 +674,16 @@ __global__ void __launch_bounds__(256) cast_f32_f16_kernel(const float* __restri
     if (vec) {
         for (; i < n / 8; i += stride) {
             const float4 a = *reinterpret_cast<const float4*>(x + 8 * i), c = *reinterpret_cast<const float4*>(x + 8 * i + 4);
-            half8_t o = {(_Float16)(a.x * s), (_Float16)(a.y * s), (_Float16)(a.z * s), (_Float16)(a.w * s),
-                         (_Float16)(c.x * s), (_Float16)(c.y * s), (_Float16)(c.z * s), (_Float16)(c.w * s)};
+            half8_t o = {(t16)(a.x * s), (t16)(a.y * s), (t16)(a.z * s), (t16)(a.w * s),
+                         (t16)(c.x * s), (t16)(c.y * s), (t16)(c.z * s), (t16)(c.w * s)};
             *reinterpret_cast<half8_t*>(y + 8 * i) = o;
         }
         return;
     }
-    for (; i < n; i += stride) y[i] = __float2half_rn(x[i] * s);
+    for (; i < n; i += stride) y[i] = (t16)(x[i] * s);
 }
 
-__global__ void __launch_bounds__(256) cast_f16_f32_kernel(const __half* __restrict__ x, float* __restrict__ y, long long n,
+__global__ void __launch_bounds__(256) cast_f16_f32_kernel(const t16* __restrict__ x, float* __restrict__ y, long long n,
                                                            const float* __restrict__ scale, int accumulate, int vec) {
     const float s = scale ? scale[1] : 1.0f;
     const long long stride = (long long)gridDim.x * 256;
@@ -705,7 +705,7 @@ __global__ void __launch_bounds__(256) cast_f16_f32_kernel(const __half* __restr
         return;
     }
     for (; i < n; i += stride) {
-        const float v = __half2float(x[i]) * s;
+        const float v = (float)(x[i]) * s;
         y[i] = accumulate ? y[i] + v : v;
     }
 }
@@ -717,8 +717,8 @@ __global__ void __launch_bounds__(256) cast_f16_f32_kernel(const __half* __restr
 //   |dy| <= |k0| max|du| + |k1| + max|xh| |k2|   per (sample, channel)
 // whose ingredients come out of the reduction pass -- no separate max pass, no fp32 dy, no cast pass.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gn_silu_f16_kernel(const __half* __restrict__ y16, const float* __restrict__ affine,
-                                                          __half* __restrict__ z16, float* __restrict__ z32, int C,
+__global__ void __launch_bounds__(256) gn_silu_f16_kernel(const t16* __restrict__ y16, const float* __restrict__ affine,
+                                                          t16* __restrict__ z16, float* __restrict__ z32, int C,
                                                           long long n_per_batch) {
     // 8 consecutive channels per lane; the grid stride is a multiple of C/8 vectors: coefficients stay in registers
     const int b = blockIdx.y;
@@ -741,7 +741,7 @@ __global__ void __launch_bounds__(256) gn_silu_f16_kernel(const __half* __restri
         for (int j = 0; j < 8; ++j) {
             const float u = fmaf(ga[j], (float)yv[j], gb[j]);
             z[j] = u * sigmoid_fast(u);
-            o[j] = (_Float16)z[j];
+            o[j] = (t16)z[j];
         }
         *reinterpret_cast<half8_t*>(z16 + i) = o;
         if (z32) {
@@ -756,7 +756,7 @@ __global__ void __launch_bounds__(256) gn_silu_f16_kernel(const __half* __restri
 template <bool DZH>
 __device__ inline void load_dz8(const void* __restrict__ dz, long long i, float s, float (&dv)[8]) {
     if constexpr (DZH) {
-        const half8_t h = *reinterpret_cast<const half8_t*>(reinterpret_cast<const __half*>(dz) + i);
+        const half8_t h = *reinterpret_cast<const half8_t*>(reinterpret_cast<const t16*>(dz) + i);
 #pragma unroll
         for (int j = 0; j < 8; ++j) dv[j] = (float)h[j] * s;
     } else {
@@ -769,7 +769,7 @@ __device__ inline void load_dz8(const void* __restrict__ dz, long long i, float 
 
 template <bool DZH>
 __global__ void __launch_bounds__(256) gn_bwd_reduce16_kernel(const void* __restrict__ dz, const float* __restrict__ dz_scale,
-                                                              const __half* __restrict__ y,
+                                                              const t16* __restrict__ y,
                                                               const float* __restrict__ affine,
                                                               const float* __restrict__ stats, int C, int groups,
                                                               long long voxels, int nblk, float* __restrict__ partial) {
@@ -917,10 +917,10 @@ __global__ void __launch_bounds__(1024) gn_bwd_finalize16_kernel(const float* __
 
 template <bool DZH>
 __global__ void __launch_bounds__(256) gn_bwd_apply16_kernel(const void* __restrict__ dz, const float* __restrict__ dz_scale,
-                                                             const __half* __restrict__ y,
+                                                             const t16* __restrict__ y,
                                                              const float* __restrict__ affine,
                                                              const float* __restrict__ stats, const float* __restrict__ coef,
-                                                             const float* __restrict__ scale, __half* __restrict__ dy16, int C,
+                                                             const float* __restrict__ scale, t16* __restrict__ dy16, int C,
                                                              int groups, long long n_per_batch) {
     // 8 consecutive channels per lane (16-byte y load / dy store, two 16-byte dz loads); the grid stride is a multiple
     // of C/8 vectors, so a lane keeps its channels and their coefficients in registers
@@ -954,7 +954,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply16_kernel(const void* __restr
         for (int j = 0; j < 8; ++j) {
             const float yv = (float)yv8[j];
             const float du = dv[j] * silu_grad_fast(fmaf(a[j], yv, bb[j]));
-            out[j] = (_Float16)((k0[j] * du - k1[j] - ((yv - mean[j]) * rstd[j]) * k2[j]) * sc);
+            out[j] = (t16)((k0[j] * du - k1[j] - ((yv - mean[j]) * rstd[j]) * k2[j]) * sc);
         }
         *reinterpret_cast<half8_t*>(dy16 + i) = out;
     }
@@ -965,14 +965,14 @@ __global__ void __launch_bounds__(256) gn_bwd_apply16_kernel(const void* __restr
 // as 16-bit buffer loads (masked lanes read 0 through the bounds check) and packed in registers.
 
 struct Wg16Src {
-    const __half* data;  // (B, xs, ys, zs, C) activated input, fp16
+    const t16* data;  // (B, xs, ys, zs, C) activated input, fp16
     int C, up, Xs, Ys, Zs;
 };
 
 struct Wgrad16Args {
     Wg16Src src[2];
     int nsrc;
-    const __half* dy;  // (B, ox, oy, oz, cout) fp16, scaled
+    const t16* dy;  // (B, ox, oy, oz, cout) fp16, scaled
     float* part;
     float* part_bias;
     int B, ox, oy, oz, cout, cin, ksize;
@@ -1067,7 +1067,7 @@ __global__ void __launch_bounds__(64) wgrad16_kernel(Wgrad16Args a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) bsum += (float)av[j];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t] = SK_MFMA_32x32x16_T16(av, bv[t], acc[t], 0, 0, 0);
     }
     float* part = a.part + (long long)chunk * a.cout * a.cin * k3;
     const int cig = ci0 + col;
@@ -1093,7 +1093,7 @@ __global__ void __launch_bounds__(64) wgrad16_kernel(Wgrad16Args a) {
 // in HBM), and the K-major fragment the MFMA wants (8 voxels of one channel per lane) comes out of LDS with two
 // ds_read_b64_tr_b16 (hardware transpose: per 16-lane group a block of 4 rows x 16 columns, column-major).
 // 10 loads per step instead of 80 16-bit loads; tiles double-buffered, next step's DMA in flight under the MFMAs.
-typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));  // the builtin's own vector type
+typedef SK_TR16_ELEM fp16x4_t __attribute__((__vector_size__(4 * sizeof(SK_TR16_ELEM))));  // the builtin's own vector type
 
 __device__ __forceinline__ void dma16_tile(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -1107,13 +1107,13 @@ __device__ __forceinline__ half8_t tr_read_frag(const char* tile, int lane) {
     const char* base = tile + (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * p) * 2;
     // (the _v4i16 form of the builtin miscompiles the element extraction on ROCm 7.2: all four lanes of the result
     // read element 0; the _v4f16 form is correct)
-    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)base);
-    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + 4 * 64));
+    const fp16x4_t lo = SK_DS_READ_TR16_B64((__attribute__((address_space(3))) fp16x4_t*)base);
+    const fp16x4_t hi = SK_DS_READ_TR16_B64((__attribute__((address_space(3))) fp16x4_t*)(base + 4 * 64));
     half8_t r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        r[j] = (_Float16)lo[j];
-        r[4 + j] = (_Float16)hi[j];
+        r[j] = (t16)lo[j];
+        r[4 + j] = (t16)hi[j];
     }
     return r;
 }
@@ -1215,7 +1215,7 @@ __global__ void __launch_bounds__(64) wgrad16t_kernel(Wgrad16Args a, const char*
 #pragma unroll
         for (int j = 0; j < 8; ++j) bsum += (float)av[j];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t] = SK_MFMA_32x32x16_T16(av, bv[t], acc[t], 0, 0, 0);
         // the tile buffer is reused by the DMA issued at the top of the next-but-one iteration; every read of it
         // has completed by then (the MFMAs above consumed them)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1244,25 +1244,25 @@ __device__ __forceinline__ half8_t tr_read_rows(const char* tile, int lane, int 
     // as tr_read_frag with this lane's two source rows given explicitly (rows of its voxels 8h + q and 8h + 4 + q)
     const int g = lane >> 4, p = lane & 3;
     const char* base = tile + (16 * (g & 1) + 4 * p) * 2;
-    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + row0 * 64));
-    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + row1 * 64));
+    const fp16x4_t lo = SK_DS_READ_TR16_B64((__attribute__((address_space(3))) fp16x4_t*)(base + row0 * 64));
+    const fp16x4_t hi = SK_DS_READ_TR16_B64((__attribute__((address_space(3))) fp16x4_t*)(base + row1 * 64));
     half8_t r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        r[j] = (_Float16)lo[j];
-        r[4 + j] = (_Float16)hi[j];
+        r[j] = (t16)lo[j];
+        r[4 + j] = (t16)hi[j];
     }
     return r;
 }
 
 __device__ __forceinline__ half8_t tr_read_at(const char* p0, const char* p1) {
-    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p0);
-    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p1);
+    const fp16x4_t lo = SK_DS_READ_TR16_B64((__attribute__((address_space(3))) fp16x4_t*)p0);
+    const fp16x4_t hi = SK_DS_READ_TR16_B64((__attribute__((address_space(3))) fp16x4_t*)p1);
     half8_t r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        r[j] = (_Float16)lo[j];
-        r[4 + j] = (_Float16)hi[j];
+        r[j] = (t16)lo[j];
+        r[4 + j] = (t16)hi[j];
     }
     return r;
 }
@@ -1365,7 +1365,7 @@ __global__ void __launch_bounds__(64, 2) wgrad16y_kernel(Wgrad16Args a, const ch
                 for (int j = 0; j < 8; ++j) bsum += (float)av[j];
             }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < 9; ++t) acc[t] = SK_MFMA_32x32x16_T16(av, bv[t], acc[t], 0, 0, 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         // the previous column's fragments were all read before its last MFMAs were issued: the ring can be refilled
@@ -1403,7 +1403,7 @@ __global__ void __launch_bounds__(64, 2) wgrad16y_kernel(Wgrad16Args a, const ch
 // eff_cin = the layer's output channels).  One thread per fp16 element.
 struct PackArgs {
     const float* w;  // (Co, Ci, k, k, k)
-    __half* dst;
+    t16* dst;
     int Co, Ci, ksize, eff_cout, eff_cin, transposed, c_lo;
     long long n;     // halves to write
 };
@@ -1466,16 +1466,16 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(PackArgs a) {
     } else {
         src = ((long long)co * a.Ci + ci) * k3 + tap;
     }
-    a.dst[i] = __float2half_rn(a.w[src]);
+    a.dst[i] = (t16)(a.w[src]);
 }
 
 // Data gradient of a k = 2, stride-2 conv from its eight per-parity pointwise products: t16 (8, B, cx, cy, cz, C)
 // holds T_p[c] = W_p^T dY[c]; dX[2c + p] (+)= T_p[c] * scale[1].
 // add16 (optional): another scaled fp16 gradient of the same fine tensor (the decoder's contribution to a skip tensor,
 // scale add_scale), summed in here instead of through an fp32 copy + accumulate pass
-__global__ void __launch_bounds__(256) interleave2_kernel(const __half* __restrict__ t16, float* __restrict__ dx, int B,
+__global__ void __launch_bounds__(256) interleave2_kernel(const t16* __restrict__ tens16, float* __restrict__ dx, int B,
                                                           int cx, int cy, int cz, int C, const float* __restrict__ scale,
-                                                          int accumulate, const __half* __restrict__ add16,
+                                                          int accumulate, const t16* __restrict__ add16,
                                                           const float* __restrict__ add_scale) {
     // 8 channels per lane: one 16-byte load of the parity tensor, two 16-byte stores (+ loads when accumulating)
     const float s = scale ? scale[1] : 1.0f;
@@ -1493,7 +1493,7 @@ __global__ void __launch_bounds__(256) interleave2_kernel(const __half* __restri
         const int b = (int)(t / (2 * cx));
         const int p = ((x & 1) << 2) | ((y & 1) << 1) | (z & 1);
         const long long ci = ((((long long)b * cx + (x >> 1)) * cy + (y >> 1)) * cz + (z >> 1)) * C + 8 * q;
-        const half8_t h = *reinterpret_cast<const half8_t*>(t16 + (long long)p * ncoarse + ci);
+        const half8_t h = *reinterpret_cast<const half8_t*>(tens16 + (long long)p * ncoarse + ci);
         float4 v0 = {(float)h[0] * s, (float)h[1] * s, (float)h[2] * s, (float)h[3] * s};
         float4 v1 = {(float)h[4] * s, (float)h[5] * s, (float)h[6] * s, (float)h[7] * s};
         float4* o = reinterpret_cast<float4*>(dx + i * 8);
@@ -1583,7 +1583,7 @@ __global__ void __launch_bounds__(256) sumpool2_kernel(const float* __restrict__
 
 // the same from a scaled fp16 fine tensor (the fast data-gradient conv's output), 8 channels per lane: no fp32 copy of
 // the fine gradient is ever written
-__global__ void __launch_bounds__(256) sumpool2_f16_kernel(const __half* __restrict__ fine, const float* __restrict__ scale,
+__global__ void __launch_bounds__(256) sumpool2_f16_kernel(const t16* __restrict__ fine, const float* __restrict__ scale,
                                                            float* __restrict__ coarse, int B, int cx, int cy, int cz, int C) {
     const float s = scale[1];
     const int nq = C / 8;
@@ -1617,7 +1617,7 @@ __global__ void __launch_bounds__(256) sumpool2_f16_kernel(const __half* __restr
 // HBM streams (64 B in, 20 B out per voxel), so no matrix instruction.  Four lanes share a voxel (8 channels = 16 bytes
 // each), partial dot products are combined with two xor-shuffles.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) heads_fwd_f16_kernel(const __half* __restrict__ z, const float* __restrict__ w,
+__global__ void __launch_bounds__(256) heads_fwd_f16_kernel(const t16* __restrict__ z, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ logits,
                                                             long long nvox) {
     const int q = threadIdx.x & 3;
@@ -1651,7 +1651,7 @@ __global__ void __launch_bounds__(256) heads_fwd_f16_kernel(const __half* __rest
 
 // dW[k][c] = sum_v dl[v][k] z[v][c], db[k] = sum_v dl[v][k]: per block partials (fixed order), reduced by wgrad_reduce_kernel
 constexpr int kHeadsVox = 8192;  // voxels per block
-__global__ void __launch_bounds__(256) heads_wgrad_f16_kernel(const __half* __restrict__ z, const float* __restrict__ dl,
+__global__ void __launch_bounds__(256) heads_wgrad_f16_kernel(const t16* __restrict__ z, const float* __restrict__ dl,
                                                               float* __restrict__ part, float* __restrict__ part_b,
                                                               long long nvox) {
     __shared__ float red[64][41];   // 41: odd pitch, conflict-free column sums
@@ -1986,7 +1986,7 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
         int up = srcs[i].upsample ? 1 : 0;
         SK_CHECK_ARG(!up || (ksize == 3 && ox % 2 == 0 && oy % 2 == 0 && oz % 2 == 0),
                      "sk_train_conv_wgrad_f16: upsampled source needs ksize 3 and even output extents");
-        a.src[i].data = (const __half*)srcs[i].data;
+        a.src[i].data = (const t16*)srcs[i].data;
         a.src[i].C = srcs[i].c;
         a.src[i].up = up;
         int s = (ksize == 3) ? 1 : ksize;
@@ -1998,7 +1998,7 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
                      "sk_train_conv_wgrad_f16: source %d of one batch item must be < 4 GiB", i);
     }
     SK_CHECK_ARG((long long)ox * oy * oz * cout * 2 < (1LL << 32), "sk_train_conv_wgrad_f16: dy of one batch item must be < 4 GiB");
-    a.dy = (const __half*)dy;
+    a.dy = (const t16*)dy;
     a.B = B;
     a.ox = ox;
     a.oy = oy;
@@ -2071,7 +2071,7 @@ int sk_train_pack_weight(const float* weight, int Co, int Ci, int ksize, int tra
                  "sk_train_pack_weight: unsupported shape cout=%d cin=%d k=%d", eff_cout, eff_cin, ksize);
     PackArgs a{};
     a.w = weight;
-    a.dst = (__half*)dst;
+    a.dst = (t16*)dst;
     a.Co = Co;
     a.Ci = Ci;
     a.ksize = ksize;
@@ -2085,28 +2085,28 @@ int sk_train_pack_weight(const float* weight, int Co, int Ci, int ksize, int tra
     return SK_OK;
 }
 
-static int interleave2_impl(const void* t16, const void* add16, const float* add_scale, float* dx, int B, int cx, int cy, int cz,
+static int interleave2_impl(const void* tens16, const void* add16, const float* add_scale, float* dx, int B, int cx, int cy, int cz,
                             int C, const float* scale, int accumulate, void* stream) {
-    SK_CHECK_ARG(t16 && dx && B >= 1 && cx >= 1 && cy >= 1 && cz >= 1 && C >= 8 && C % 8 == 0,
+    SK_CHECK_ARG(tens16 && dx && B >= 1 && cx >= 1 && cy >= 1 && cz >= 1 && C >= 8 && C % 8 == 0,
                  "sk_train_interleave2: bad arguments (C must be a multiple of 8)");
     SK_CHECK_ARG(!add16 || add_scale, "sk_train_interleave2_add16: add_scale is NULL");
     long long n = (long long)B * cx * cy * cz * C;   // fine voxels x channel octets = coarse voxels x C
-    interleave2_kernel<<<sk::stream_grid(n, 256, 2), 256, 0, (hipStream_t)stream>>>((const __half*)t16, dx, B, cx, cy, cz, C, scale,
-                                                                                    accumulate ? 1 : 0, (const __half*)add16,
+    interleave2_kernel<<<sk::stream_grid(n, 256, 2), 256, 0, (hipStream_t)stream>>>((const t16*)tens16, dx, B, cx, cy, cz, C, scale,
+                                                                                    accumulate ? 1 : 0, (const t16*)add16,
                                                                                     add_scale);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
 
-int sk_train_interleave2(const void* t16, float* dx, int B, int cx, int cy, int cz, int C, const float* scale, int accumulate,
+int sk_train_interleave2(const void* tens16, float* dx, int B, int cx, int cy, int cz, int C, const float* scale, int accumulate,
                          void* stream) {
-    return interleave2_impl(t16, nullptr, nullptr, dx, B, cx, cy, cz, C, scale, accumulate, stream);
+    return interleave2_impl(tens16, nullptr, nullptr, dx, B, cx, cy, cz, C, scale, accumulate, stream);
 }
 
-int sk_train_interleave2_add16(const void* t16, const void* add16, const float* add_scale, float* dx, int B, int cx, int cy,
+int sk_train_interleave2_add16(const void* tens16, const void* add16, const float* add_scale, float* dx, int B, int cx, int cy,
                                int cz, int C, const float* scale, void* stream) {
     SK_CHECK_ARG(add16, "sk_train_interleave2_add16: add16 is NULL");
-    return interleave2_impl(t16, add16, add_scale, dx, B, cx, cy, cz, C, scale, 0, stream);
+    return interleave2_impl(tens16, add16, add_scale, dx, B, cx, cy, cz, C, scale, 0, stream);
 }
 
 int sk_train_gn_silu_f16(const void* y16, const float* affine, void* z16, float* z32, int B, int64_t voxels, int C,
@@ -2114,8 +2114,8 @@ int sk_train_gn_silu_f16(const void* y16, const float* affine, void* z16, float*
     SK_CHECK_ARG(y16 && affine && z16 && C > 0, "sk_train_gn_silu_f16: bad arguments");
     long long n = voxels * C;
     SK_CHECK_ARG(C % 8 == 0 && 256 % (C / 8) == 0, "sk_train_gn_silu_f16: C=%d unsupported", C);
-    gn_silu_f16_kernel<<<dim3(sk::stream_grid(n / 8, 256, 4), B), 256, 0, (hipStream_t)stream>>>((const __half*)y16, affine,
-                                                                                             (__half*)z16, z32, C, n);
+    gn_silu_f16_kernel<<<dim3(sk::stream_grid(n / 8, 256, 4), B), 256, 0, (hipStream_t)stream>>>((const t16*)y16, affine,
+                                                                                             (t16*)z16, z32, C, n);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
@@ -2136,10 +2136,10 @@ static int gn_silu_bwd_f16_impl(const void* dz, const float* dz_scale, const voi
     float* coef = workspace + (long long)B * nblk * C * 4;   // (B, C, 3)
     hipStream_t st = (hipStream_t)stream;
     if (dz_scale)
-        gn_bwd_reduce16_kernel<true><<<dim3(nblk, B), 256, 0, st>>>(dz, dz_scale, (const __half*)y16, affine, stats, C, groups,
+        gn_bwd_reduce16_kernel<true><<<dim3(nblk, B), 256, 0, st>>>(dz, dz_scale, (const t16*)y16, affine, stats, C, groups,
                                                                     voxels, nblk, partial);
     else
-        gn_bwd_reduce16_kernel<false><<<dim3(nblk, B), 256, 0, st>>>(dz, nullptr, (const __half*)y16, affine, stats, C, groups,
+        gn_bwd_reduce16_kernel<false><<<dim3(nblk, B), 256, 0, st>>>(dz, nullptr, (const t16*)y16, affine, stats, C, groups,
                                                                      voxels, nblk, partial);
     SK_CHECK_LAUNCH();
     gn_bwd_finalize16_kernel<<<1, 1024, 0, st>>>(partial, B, nblk, C, groups, (double)voxels, gamma, stats, coef, dgamma, dbeta,
@@ -2148,11 +2148,11 @@ static int gn_silu_bwd_f16_impl(const void* dz, const float* dz_scale, const voi
     long long n = voxels * C;
     const dim3 grid(sk::stream_grid(n / 8, 256, 4), B);
     if (dz_scale)
-        gn_bwd_apply16_kernel<true><<<grid, 256, 0, st>>>(dz, dz_scale, (const __half*)y16, affine, stats, coef, scale,
-                                                          (__half*)dy16, C, groups, n);
+        gn_bwd_apply16_kernel<true><<<grid, 256, 0, st>>>(dz, dz_scale, (const t16*)y16, affine, stats, coef, scale,
+                                                          (t16*)dy16, C, groups, n);
     else
-        gn_bwd_apply16_kernel<false><<<grid, 256, 0, st>>>(dz, nullptr, (const __half*)y16, affine, stats, coef, scale,
-                                                           (__half*)dy16, C, groups, n);
+        gn_bwd_apply16_kernel<false><<<grid, 256, 0, st>>>(dz, nullptr, (const t16*)y16, affine, stats, coef, scale,
+                                                           (t16*)dy16, C, groups, n);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
@@ -2187,7 +2187,7 @@ int sk_train_absmax_scale(const float* x, int64_t n, float* scale, void* stream)
 int sk_train_cast_f32_f16(const float* x, void* y, int64_t n, const float* scale, void* stream) {
     SK_CHECK_ARG(x && y && n >= 1, "sk_train_cast_f32_f16: bad arguments");
     const int vec = n % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
-    cast_f32_f16_kernel<<<sk::stream_grid(vec ? n / 8 : n, 256, 4), 256, 0, (hipStream_t)stream>>>(x, (__half*)y, n, scale, vec);
+    cast_f32_f16_kernel<<<sk::stream_grid(vec ? n / 8 : n, 256, 4), 256, 0, (hipStream_t)stream>>>(x, (t16*)y, n, scale, vec);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
@@ -2195,7 +2195,7 @@ int sk_train_cast_f32_f16(const float* x, void* y, int64_t n, const float* scale
 int sk_train_cast_f16_f32(const void* x, float* y, int64_t n, const float* scale, int accumulate, void* stream) {
     SK_CHECK_ARG(x && y && n >= 1, "sk_train_cast_f16_f32: bad arguments");
     const int vec = n % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
-    cast_f16_f32_kernel<<<sk::stream_grid(vec ? n / 8 : n, 256, 4), 256, 0, (hipStream_t)stream>>>((const __half*)x, y, n, scale,
+    cast_f16_f32_kernel<<<sk::stream_grid(vec ? n / 8 : n, 256, 4), 256, 0, (hipStream_t)stream>>>((const t16*)x, y, n, scale,
                                                                                      accumulate ? 1 : 0, vec);
     SK_CHECK_LAUNCH();
     return SK_OK;
@@ -2214,7 +2214,7 @@ int sk_train_sumpool2_f16(const void* fine16, const float* scale, float* coarse,
     SK_CHECK_ARG(fine16 && scale && coarse && B >= 1 && cx >= 1 && cy >= 1 && cz >= 1 && C >= 8 && C % 8 == 0,
                  "sk_train_sumpool2_f16: bad arguments");
     long long n = (long long)B * cx * cy * cz * (C / 8);
-    sumpool2_f16_kernel<<<sk::stream_grid(n, 256, 2), 256, 0, (hipStream_t)stream>>>((const __half*)fine16, scale, coarse, B, cx, cy,
+    sumpool2_f16_kernel<<<sk::stream_grid(n, 256, 2), 256, 0, (hipStream_t)stream>>>((const t16*)fine16, scale, coarse, B, cx, cy,
                                                                                      cz, C);
     SK_CHECK_LAUNCH();
     return SK_OK;
@@ -2223,7 +2223,7 @@ int sk_train_sumpool2_f16(const void* fine16, const float* scale, float* coarse,
 int sk_train_heads_fwd_f16(const void* z16, const float* weight, const float* bias, float* logits, int64_t nvox,
                            void* stream) {
     SK_CHECK_ARG(z16 && weight && bias && logits && nvox >= 1, "sk_train_heads_fwd_f16: bad arguments");
-    heads_fwd_f16_kernel<<<sk::stream_grid(nvox, 64, 4), 256, 0, (hipStream_t)stream>>>((const __half*)z16, weight, bias, logits,
+    heads_fwd_f16_kernel<<<sk::stream_grid(nvox, 64, 4), 256, 0, (hipStream_t)stream>>>((const t16*)z16, weight, bias, logits,
                                                                                       nvox);
     SK_CHECK_LAUNCH();
     return SK_OK;
@@ -2238,7 +2238,7 @@ int sk_train_heads_wgrad_f16(const void* z16, const float* dlogits, float* dweig
     float* part = workspace;
     float* part_b = workspace + (long long)nb * 160;
     hipStream_t st = (hipStream_t)stream;
-    heads_wgrad_f16_kernel<<<nb, 256, 0, st>>>((const __half*)z16, dlogits, part, part_b, nvox);
+    heads_wgrad_f16_kernel<<<nb, 256, 0, st>>>((const t16*)z16, dlogits, part, part_b, nvox);
     SK_CHECK_LAUNCH();
     wgrad_reduce_kernel<<<sk::cdiv(160, 64), 64 * kWredSlices, 0, st>>>(part, nb, 160, dweight, nullptr, 0, 0, 0);
     SK_CHECK_LAUNCH();

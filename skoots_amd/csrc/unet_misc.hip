@@ -9,7 +9,7 @@
 
 namespace {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef t16 half8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------------------ stem
 // (1) normalise: the B tiles are cut out of the fp16 volume, normalised with the reference's
@@ -19,18 +19,18 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // run twice (statistics, then apply): see stem_kernel.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef t16 half4v __attribute__((ext_vector_type(4)));
 
 struct StemArgs {
-    const __half* image;   // (X, Y, Z) fp16 volume
+    const t16* image;   // (X, Y, Z) fp16 volume
     int X, Y, Z;           // volume extents
     int ox[16], oy[16], oz[16];  // tile origins (B <= 16)
     int B, Xt, Yt, Zt;     // tile extents
     float mean, stdv;
     const float* weight;   // (27, 32) fp32: [tap = (dx*3+dy)*3+dz][cout]
     const float* bias;     // (32)
-    __half* norm;          // workspace (B, Xt+2, Yt+2, Zt+2) fp16
-    __half* out;           // (B, Xt, Yt, Zt, 32) fp16 ACTIVATED (apply pass)
+    t16* norm;          // workspace (B, Xt+2, Yt+2, Zt+2) fp16
+    t16* out;           // (B, Xt, Yt, Zt, 32) fp16 ACTIVATED (apply pass)
     float* partial;        // (B, nblk, 8, 2)     (stats pass)
     const float* affine;   // (B, 2, 32)           (apply pass)
     int nblk;
@@ -43,10 +43,10 @@ __global__ void __launch_bounds__(256) stem_norm_kernel(StemArgs a) {
     // with three 64-bit divisions each took 50 us per 8 tiles)
     const int b = blockIdx.y, x = blockIdx.x;
     const int py = a.Yt + 2, pz = a.Zt + 2;
-    __half* out = a.norm + ((long long)b * (a.Xt + 2) + x) * py * pz;
+    t16* out = a.norm + ((long long)b * (a.Xt + 2) + x) * py * pz;
     const int gx = a.ox[b] + x - 1;
     const bool xin = x >= 1 && x <= a.Xt && gx < a.X;
-    const __half* img = a.image + (long long)gx * a.Y * a.Z;
+    const t16* img = a.image + (long long)gx * a.Y * a.Z;
     for (int i = threadIdx.x; i < py * pz; i += 256) {
         const int y = i / pz, z = i - y * pz;
         float v = 0.0f;
@@ -54,12 +54,12 @@ __global__ void __launch_bounds__(256) stem_norm_kernel(StemArgs a) {
         // AFTER normalisation, like the conv frame
         const int gy = a.oy[b] + y - 1, gz = a.oz[b] + z - 1;
         if (xin && y >= 1 && y <= a.Yt && z >= 1 && z <= a.Zt && gy < a.Y && gz < a.Z) {
-            const float raw = __half2float(img[(long long)gy * a.Z + gz]);
+            const float raw = (float)(img[(long long)gy * a.Z + gz]);
             // eval.py:139  crop.sub(mean).div(std) on an fp16 tensor: each op rounds to fp16
-            const float s = __half2float(__float2half_rn(raw - a.mean));
-            v = __half2float(__float2half_rn(s / a.stdv));
+            const float s = (float)((t16)(raw - a.mean));
+            v = (float)((t16)(s / a.stdv));
         }
-        out[i] = __float2half_rn(v);
+        out[i] = (t16)(v);
     }
 }
 
@@ -73,12 +73,12 @@ __global__ void __launch_bounds__(256) stem_norm_kernel(StemArgs a) {
 // prologue (weight split, tap offsets, staging latency) is amortised over rows*Zt/32 tiles; statistics pass per 8
 // tiles of 300x300x20, rocprofv3: 60 rows 189 us, 100: 165, 150: 151, 300: 149 (apply pass 332 / 327 / 324 / 338).
 static int stem_rows(int Yt, int Zt) {
-    int r = (40 * 1024) / (3 * (Zt + 2) * (int)sizeof(__half)) - 2;
+    int r = (40 * 1024) / (3 * (Zt + 2) * (int)sizeof(t16)) - 2;
     if (r > 150) r = 150;
 #ifdef SK_TUNING
     if (const char* e = getenv("SK_STEM_ROWS")) {
         const int v = atoi(e);
-        if (v >= 1 && (size_t)3 * (v + 2) * (Zt + 2) * sizeof(__half) <= 60 * 1024) r = v;
+        if (v >= 1 && (size_t)3 * (v + 2) * (Zt + 2) * sizeof(t16) <= 60 * 1024) r = v;
     }
 #endif
     if (r > Yt) r = Yt;
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
     const int rows = min(a.rows, a.Yt - y0);
     const long long nvox = (long long)a.Xt * a.Yt * a.Zt;
     const int py = a.Yt + 2, pz = a.Zt + 2;
-    const __half* nb = a.norm + (long long)b * (a.Xt + 2) * py * pz;
+    const t16* nb = a.norm + (long long)b * (a.Xt + 2) * py * pz;
 
     // stage the three padded x planes' rows [y0, y0 + rows + 2): contiguous (rows+2)*pz halves each
     const int seg_halves = (a.rows + 2) * pz;          // LDS pitch per plane (halves, even)
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
         for (int i = tid; i < seg_dw; i += 256) dst[i] = src[i];
     }
     __syncthreads();
-    const _Float16* ls = reinterpret_cast<const _Float16*>(stem_lds);
+    const t16* ls = reinterpret_cast<const t16*>(stem_lds);
 
     // A operands: lane holds W[cout = l&31][tap = 16m + 8h + j], j = 0..7, m = 0,1 (tap >= 27: 0)
     half8 whi[2], wlo[2];
@@ -129,9 +129,9 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
         for (int j = 0; j < 8; ++j) {
             int tap = 16 * m + 8 * h + j;
             float wv = tap < 27 ? a.weight[tap * 32 + col] : 0.0f;
-            _Float16 hi = (_Float16)wv;
+            t16 hi = (t16)wv;
             whi[m][j] = hi;
-            wlo[m][j] = (_Float16)(wv - (float)hi);
+            wlo[m][j] = (t16)(wv - (float)hi);
             int tt = tap < 27 ? tap : 0;  // any valid address: its weight is zero
             toff[m][j] = (tt / 9) * seg_halves + ((tt / 3) % 3) * pz + tt % 3;
         }
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
         const bool ok = i < nloc;
         const int ii = ok ? i : 0;
         const int yl = ii / a.Zt, z = ii - yl * a.Zt;
-        const _Float16* p = ls + yl * pz + z;       // tap (0,0,0) in the staged planes
+        const t16* p = ls + yl * pz + z;       // tap (0,0,0) in the staged planes
         half8 b0, b1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -165,10 +165,10 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
             b1[j] = p[toff[1][j]];
         }
         f32x16 acc = binit;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[0], b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[1], b1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], b1, acc, 0, 0, 0);
+        acc = SK_MFMA_32x32x16_T16(wlo[0], b0, acc, 0, 0, 0);
+        acc = SK_MFMA_32x32x16_T16(wlo[1], b1, acc, 0, 0, 0);
+        acc = SK_MFMA_32x32x16_T16(whi[0], b0, acc, 0, 0, 0);
+        acc = SK_MFMA_32x32x16_T16(whi[1], b1, acc, 0, 0, 0);
         if (ok) {
             if (STATS) {
 #pragma unroll
@@ -178,13 +178,13 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
                     gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
                     if (MODE == 2) {
                         const long long v = ((long long)x * a.Yt + (y0 + yl)) * a.Zt + z;
-                        half4v hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+                        half4v hv = {(t16)v0, (t16)v1, (t16)v2, (t16)v3};
                         *reinterpret_cast<half4v*>(a.out + ((long long)b * nvox + v) * 32 + 8 * q + 4 * h) = hv;
                     }
                 }
             } else {
                 const long long v = ((long long)x * a.Yt + (y0 + yl)) * a.Zt + z;
-                __half* op = a.out + ((long long)b * nvox + v) * kOutC;
+                t16* op = a.out + ((long long)b * nvox + v) * kOutC;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     half4v hv, lv;
@@ -192,8 +192,8 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
                     for (int j = 0; j < 4; ++j) {
                         float yv = fmaf(ga[4 * q + j], acc[4 * q + j], gb[4 * q + j]);
                         const float sv = yv * __builtin_amdgcn_rcpf(1.0f + __expf(-yv));
-                        hv[j] = (_Float16)sv;
-                        lv[j] = (_Float16)(sv - (float)hv[j]);
+                        hv[j] = (t16)sv;
+                        lv[j] = (t16)(sv - (float)hv[j]);
                     }
                     *reinterpret_cast<half4v*>(op + 8 * q + 4 * h) = hv;
                     if (MODE == 3) *reinterpret_cast<half4v*>(op + 32 + 8 * q + 4 * h) = lv;
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(kFinThreads) gn_finalize_kernel(const float* _
 }
 
 // in place: x = silu(a*x + b), 8 channels (16 B) per lane
-__global__ void __launch_bounds__(256) gn_silu_kernel(__half* __restrict__ x,
+__global__ void __launch_bounds__(256) gn_silu_kernel(t16* __restrict__ x,
                                                       const float* __restrict__ affine, int C,
                                                       long long nvec_per_batch) {
     const int b = blockIdx.y;
@@ -320,14 +320,14 @@ __global__ void __launch_bounds__(256) gn_silu_kernel(__half* __restrict__ x,
         for (int j = 0; j < 8; ++j) {
             float y = fmaf(ga[j], (float)v[j], gb[j]);
             float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
-            r[j] = (_Float16)(y * sg);
+            r[j] = (t16)(y * sg);
         }
         p[i] = r;
     }
 }
 
 // split tensors: x (B, vox, 2C) = [hi (C) | lo (C)] fp16 per voxel, value = hi + lo; in place, fp32 arithmetic
-__global__ void __launch_bounds__(256) gn_silu_split_kernel(__half* __restrict__ x, const float* __restrict__ affine,
+__global__ void __launch_bounds__(256) gn_silu_split_kernel(t16* __restrict__ x, const float* __restrict__ affine,
                                                             int C, long long nvec_per_batch) {
     const int b = blockIdx.y;
     const int vpc = C / 8;  // 16-byte vectors per voxel and half
@@ -351,8 +351,8 @@ __global__ void __launch_bounds__(256) gn_silu_split_kernel(__half* __restrict__
             const float xv = (float)vh[j] + (float)vl[j];
             const float y = fmaf(ga[j], xv, gb[j]);
             const float sv = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
-            rh[j] = (_Float16)sv;
-            rl[j] = (_Float16)(sv - (float)rh[j]);
+            rh[j] = (t16)sv;
+            rl[j] = (t16)(sv - (float)rh[j]);
         }
         ph[0] = rh;
         ph[vpc] = rl;
@@ -361,11 +361,11 @@ __global__ void __launch_bounds__(256) gn_silu_split_kernel(__half* __restrict__
 
 // ------------------------------------------------------------------------------ heads
 struct HeadArgs {
-    const __half* x;     // (B, n, C) fp16 (activated, or raw when affine != NULL)
+    const t16* x;     // (B, n, C) fp16 (activated, or raw when affine != NULL)
     const float* affine; // (B, 2, C) or NULL
     const float* weight; // (5, C)
     const float* bias;   // (5)
-    __half* out5;        // (B, 5, n)
+    t16* out5;        // (B, 5, n)
     long long n;         // voxels per tile = X*Y*Z
     int C;
     int Y, Z;            // tile extents (X = n / (Y*Z))
@@ -393,9 +393,9 @@ __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
         for (int j = 0; j < 8; ++j) {
             const int c = 16 * ks + 8 * h + j;
             float wv = col < 5 ? a.weight[col * C + c] : 0.0f;
-            _Float16 hi = (_Float16)wv;
+            t16 hi = (t16)wv;
             whi[ks][j] = hi;
-            wlo[ks][j] = (_Float16)(wv - (float)hi);
+            wlo[ks][j] = (t16)(wv - (float)hi);
             ga[ks][j] = a.affine ? a.affine[(long long)b * 2 * C + c] : 1.0f;
             gb[ks][j] = a.affine ? a.affine[(long long)b * 2 * C + C + c] : 0.0f;
         }
@@ -410,8 +410,8 @@ __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
     } else {
         binit[0] = a.bias[4];  // row 4 = register 0 of the upper half-wave
     }
-    const __half* xb = a.x + (long long)b * a.n * kLine;
-    __half* ob = a.out5 + (long long)b * 5 * a.n;
+    const t16* xb = a.x + (long long)b * a.n * kLine;
+    t16* ob = a.out5 + (long long)b * 5 * a.n;
     const long long nbox = (long long)a.bx * a.by * a.bz;
     const long long ntiles = (nbox + 31) / 32;
     for (long long t = (long long)blockIdx.x * 4 + (tid >> 6); t < ntiles; t += (long long)gridDim.x * 4) {
@@ -435,35 +435,35 @@ __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
                         y = fmaf(ga[ks][j], y, gb[ks][j]);
                         y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
                     }
-                    raw[j] = (_Float16)y;
-                    bl[ks][j] = (_Float16)(y - (float)raw[j]);
+                    raw[j] = (t16)y;
+                    bl[ks][j] = (t16)(y - (float)raw[j]);
                 }
             } else if (a.affine) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float y = fmaf(ga[ks][j], (float)raw[j], gb[ks][j]);
-                    raw[j] = (_Float16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));
+                    raw[j] = (t16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));
                 }
             }
             bf[ks] = raw;
         }
         f32x16 acc = binit;
         if constexpr (SPLIT) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], bl[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], bl[1], acc, 0, 0, 0);
+            acc = SK_MFMA_32x32x16_T16(whi[0], bl[0], acc, 0, 0, 0);
+            acc = SK_MFMA_32x32x16_T16(whi[1], bl[1], acc, 0, 0, 0);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[0], bf[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[1], bf[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], bf[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], bf[1], acc, 0, 0, 0);
+        acc = SK_MFMA_32x32x16_T16(wlo[0], bf[0], acc, 0, 0, 0);
+        acc = SK_MFMA_32x32x16_T16(wlo[1], bf[1], acc, 0, 0, 0);
+        acc = SK_MFMA_32x32x16_T16(whi[0], bf[0], acc, 0, 0, 0);
+        acc = SK_MFMA_32x32x16_T16(whi[1], bf[1], acc, 0, 0, 0);
         if (ok) {
             if (h == 0) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k)  // tanh(x) = 1 - 2 / (1 + e^{2x})
-                    ob[k * a.n + v] = __float2half_rn(1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * acc[k])));
-                ob[3 * a.n + v] = __float2half_rn(__builtin_amdgcn_rcpf(1.0f + __expf(-acc[3])));
+                    ob[k * a.n + v] = (t16)(1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * acc[k])));
+                ob[3 * a.n + v] = (t16)(__builtin_amdgcn_rcpf(1.0f + __expf(-acc[3])));
             } else {
-                ob[4 * a.n + v] = __float2half_rn(__builtin_amdgcn_rcpf(1.0f + __expf(-acc[0])));
+                ob[4 * a.n + v] = (t16)(__builtin_amdgcn_rcpf(1.0f + __expf(-acc[0])));
             }
         }
     }
@@ -478,10 +478,10 @@ int sk_conv3d_stem_num_blocks(int X, int Y, int Z) {
     return X * ((Y + r - 1) / r);
 }
 
-static size_t stem_lds_bytes(int Yt, int Zt) { return (size_t)3 * (stem_rows(Yt, Zt) + 2) * (Zt + 2) * sizeof(__half); }
+static size_t stem_lds_bytes(int Yt, int Zt) { return (size_t)3 * (stem_rows(Yt, Zt) + 2) * (Zt + 2) * sizeof(t16); }
 
 size_t sk_conv3d_stem_workspace_bytes(int B, int Xt, int Yt, int Zt) {
-    return (size_t)B * (Xt + 2) * (Yt + 2) * (Zt + 2) * sizeof(__half);
+    return (size_t)B * (Xt + 2) * (Yt + 2) * (Zt + 2) * sizeof(t16);
 }
 
 static int fill_stem_args(StemArgs& a, const void* image, int X, int Y, int Z, const int32_t* origins_host,
@@ -493,7 +493,7 @@ static int fill_stem_args(StemArgs& a, const void* image, int X, int Y, int Z, c
     SK_CHECK_ARG(stdv != 0.0f, "sk_conv3d_stem: std must be non-zero");
     SK_CHECK_ARG(workspace_bytes >= sk_conv3d_stem_workspace_bytes(B, Xt, Yt, Zt),
                  "sk_conv3d_stem: workspace too small");
-    a.image = (const __half*)image;
+    a.image = (const t16*)image;
     a.X = X;
     a.Y = Y;
     a.Z = Z;
@@ -515,7 +515,7 @@ static int fill_stem_args(StemArgs& a, const void* image, int X, int Y, int Z, c
     a.stdv = stdv;
     a.weight = weight;
     a.bias = bias;
-    a.norm = (__half*)workspace;
+    a.norm = (t16*)workspace;
     a.nblk = sk_conv3d_stem_num_blocks(Xt, Yt, Zt);
     a.rows = stem_rows(Yt, Zt);
     return SK_OK;
@@ -553,8 +553,8 @@ static int stem_apply_impl(int B, int Xt, int Yt, int Zt, const float* weight, c
     a.weight = weight;
     a.bias = bias;
     a.affine = affine;
-    a.norm = (__half*)workspace;
-    a.out = (__half*)out;
+    a.norm = (t16*)workspace;
+    a.out = (t16*)out;
     a.nblk = sk_conv3d_stem_num_blocks(Xt, Yt, Zt);
     a.rows = stem_rows(Yt, Zt);
     auto kern = split ? stem_kernel<3> : stem_kernel<1>;
@@ -578,7 +578,7 @@ int sk_conv3d_stem_apply_split(int B, int Xt, int Yt, int Zt, const float* weigh
 
 // ---- training, mixed precision: the stem as a fast block -------------------------------------------------------
 // image (B, X, Y, Z) fp32 -> zero-framed fp16 copy (the MFMA operand; the weights stay exact through the hi + lo split)
-__global__ void __launch_bounds__(256) stem_frame_f32_kernel(const float* __restrict__ image, __half* __restrict__ norm, int B,
+static __global__ void __launch_bounds__(256) stem_frame_f32_kernel(const float* __restrict__ image, t16* __restrict__ norm, int B,
                                                             int X, int Y, int Z) {
     const int px = X + 2, py = Y + 2, pz = Z + 2;
     const long long n = (long long)B * px * py * pz;
@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(256) stem_frame_f32_kernel(const float* __rest
         float v = 0.0f;
         if (x >= 1 && x <= X && y >= 1 && y <= Y && z >= 1 && z <= Z)
             v = image[(((long long)b * X + (x - 1)) * Y + (y - 1)) * Z + (z - 1)];
-        norm[i] = __float2half_rn(v);
+        norm[i] = (t16)(v);
     }
 }
 
@@ -608,8 +608,8 @@ int sk_train_stem_fwd_f16(const float* image, int B, int X, int Y, int Z, const 
     a.Zt = Z;
     a.weight = weight_t;
     a.bias = bias;
-    a.norm = (__half*)workspace;
-    a.out = (__half*)y16;
+    a.norm = (t16*)workspace;
+    a.out = (t16*)y16;
     a.partial = gn_partial;
     a.nblk = sk_conv3d_stem_num_blocks(X, Y, Z);
     a.rows = stem_rows(Y, Z);
@@ -662,7 +662,7 @@ int sk_groupnorm_silu(void* x, const float* affine, int B, int64_t voxels, int C
     long long nvec = voxels * (C / 8);
     unsigned gx = sk::stream_grid(nvec, 256, 4);
     dim3 grid(gx, B);
-    gn_silu_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((__half*)x, affine, C, nvec);
+    gn_silu_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((t16*)x, affine, C, nvec);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
@@ -672,7 +672,7 @@ int sk_groupnorm_silu_split(void* x, const float* affine, int B, int64_t voxels,
     SK_CHECK_ARG(C % 8 == 0 && 256 % (C / 8) == 0, "sk_groupnorm_silu_split: C=%d unsupported", C);
     long long nvec = voxels * (C / 8);
     dim3 grid(sk::stream_grid(nvec, 256, 4), B);
-    gn_silu_split_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((__half*)x, affine, C, nvec);
+    gn_silu_split_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((t16*)x, affine, C, nvec);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
@@ -683,11 +683,11 @@ static int heads_impl(const void* x, const float* affine, const float* weight, c
     SK_CHECK_ARG(C == 32, "sk_heads: C must be 32");
     SK_CHECK_ARG(X > 0 && Y > 0 && Z > 0, "sk_heads: bad extents");
     HeadArgs a{};
-    a.x = (const __half*)x;
+    a.x = (const t16*)x;
     a.affine = affine;
     a.weight = weight;
     a.bias = bias;
-    a.out5 = (__half*)out5;
+    a.out5 = (t16*)out5;
     a.n = (long long)X * Y * Z;
     a.C = C;
     a.Y = Y;

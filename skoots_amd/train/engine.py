@@ -42,6 +42,39 @@ class _Layer:
         self.cin = self.cout = 0
 
 
+TRAIN_PRECISIONS = ("fp32", "mixed", "bf16")
+
+
+class _Lib:
+    """``libskoots_hip.so`` with the 16-bit entry points resolved to one build: "" = fp16, "_bf16" = the bf16 twins
+    (include/skoots_hip_bf16.h).  Dtype-independent functions resolve to their plain names.
+
+    ``profile`` (a :class:`skoots_amd.profile.KernelProfile`): HIP-event spans around every MFMA conv launch of the
+    step -- forward and data-gradient convs (``sk_conv3d``) and weight gradients (``sk_train_conv_wgrad_f16``) -- with
+    their algorithmic FLOPs, for bench.py's training roofline."""
+
+    def __init__(self, suffix: str, device=None):
+        self._suffix = suffix
+        self._device = device
+        self.profile = None
+
+    def __getattr__(self, name: str):
+        fn = getattr(_ffi.lib, name + self._suffix if (self._suffix and name in _ffi.BF16_TWINS) else name)
+        if name in ("sk_conv3d", "sk_train_conv_wgrad_f16"):
+            raw, kind = fn, ("conv_fwd_dgrad" if name == "sk_conv3d" else "conv_wgrad")
+
+            def fn(srcs, n_src, *rest):
+                if self.profile is None:
+                    return raw(srcs, n_src, *rest)
+                # sk_conv3d: (w, bias, out, B, ox, oy, oz, cout, k, ...); wgrad: (dy, scale, B, ox, oy, oz, cout, k, ...)
+                B, ox, oy, oz, cout, k = rest[3:9] if name == "sk_conv3d" else rest[2:8]
+                cin = sum(int(srcs[i].c) for i in range(n_src))
+                with self.profile.span(kind, self._device, 2.0 * cin * cout * k ** 3 * B * ox * oy * oz):
+                    return raw(srcs, n_src, *rest)
+        setattr(self, name, fn)
+        return fn
+
+
 class TrainUNet:
     """The U-Net of oracle/unet_spec.py with fp32 master parameters on the GPU.
 
@@ -51,13 +84,19 @@ class TrainUNet:
     def __init__(self, state_dict: Dict[str, Tensor], device="cuda:0",
                  dims: Sequence[int] = (32, 64, 128, 64, 32), depths: Sequence[int] = (2, 2, 2, 2, 2),
                  precision: str = "fp32"):
-        """``precision``: "fp32" (every kernel fp32; the parity mode) or "mixed" (fp32 master weights, GroupNorm,
+        """``precision``: "fp32" (every kernel fp32; the parity mode), "bf16" (below, on bf16 tensors and bf16 matrix
+        instructions: BASELINE configs[4]'s dtype) or "mixed" (fp32 master weights, GroupNorm,
         loss and optimizer; the convolutions of the forward pass, the data gradients and the weight gradients
         on the fp16 MFMA kernels with fp32 accumulation, output gradients scaled per tensor by a power of
         two -- the counterpart of the reference's bf16 step, engine.py:68,107-109)."""
-        if precision not in ("fp32", "mixed"):
-            raise ValueError("precision must be 'fp32' or 'mixed'")
+        if precision not in TRAIN_PRECISIONS:
+            raise ValueError(f"precision must be one of {TRAIN_PRECISIONS}")
         self.precision = precision
+        # "bf16": the mixed step on the bf16 build of the same kernels (library entry points *_bf16): bf16 storage of
+        # activations / output gradients and v_mfma_*_bf16 -- the dtype the reference trains in (engine.py:68,107-109)
+        self.fast16 = precision in ("mixed", "bf16")
+        self.t16 = torch.bfloat16 if precision == "bf16" else torch.float16
+        self._L = _Lib("_bf16" if precision == "bf16" else "", torch.device(device))
         self.device = torch.device(device)
         self.dims, self.depths = tuple(dims), tuple(depths)
         # A/B switches of the mixed step (tools/bench_train.py sets them; defaults = the fast choices)
@@ -144,20 +183,20 @@ class TrainUNet:
     # -- mixed precision helpers ------------------------------------------------------------
     def _fast(self, layer: _Layer, srcs) -> bool:
         """The fp16 MFMA kernels take this layer: GroupNorm block, widths 32/64/128, channel counts % 32."""
-        return (self.precision == "mixed" and layer.norm and layer.cout in (32, 64, 128) and
+        return (self.fast16 and layer.norm and layer.cout in (32, 64, 128) and
                 all(t.shape[-1] % 32 == 0 for t, _ in srcs))
 
     def _pack(self, layer: _Layer, transposed: int = 0, c_lo: int = 0, c_n: Optional[int] = None) -> Tensor:
         c_n = layer.cin if c_n is None else c_n
         cout_eff, cin_eff = (c_n, layer.cout) if transposed else (layer.cout, layer.cin)
         buf = torch.empty(layer.ksize ** 3 * (cin_eff // 16) * (cout_eff // 32) * 1024, dtype=torch.uint8, device=self.device)
-        _ffi.check(_ffi.lib.sk_train_pack_weight(_ffi.ptr(layer.weight), layer.cout, layer.cin, layer.ksize, int(transposed),
+        _ffi.check(self._L.sk_train_pack_weight(_ffi.ptr(layer.weight), layer.cout, layer.cin, layer.ksize, int(transposed),
                                                  c_lo, c_n, _ffi.ptr(buf), _ffi.stream_ptr(self.device)))
         return buf
 
     def _to_half(self, t: Tensor, scale: Optional[Tensor] = None) -> Tensor:
-        h = torch.empty(t.shape, dtype=torch.float16, device=self.device)
-        _ffi.check(_ffi.lib.sk_train_cast_f32_f16(_ffi.ptr(t), _ffi.ptr(h), t.numel(), _ffi.ptr(scale),
+        h = torch.empty(t.shape, dtype=self.t16, device=self.device)
+        _ffi.check(self._L.sk_train_cast_f32_f16(_ffi.ptr(t), _ffi.ptr(h), t.numel(), _ffi.ptr(scale),
                                                   _ffi.stream_ptr(self.device)))
         return h
 
@@ -165,15 +204,15 @@ class TrainUNet:
                    partial: Optional[Tensor]) -> Tensor:
         B = srcs16[0][0].shape[0]
         ox, oy, oz = out_shape
-        y16 = torch.empty((B, ox, oy, oz, cout), dtype=torch.float16, device=self.device)
-        _ffi.check(_ffi.lib.sk_conv3d(self._srcs(srcs16), len(srcs16), _ffi.ptr(packed), _ffi.ptr(bias), _ffi.ptr(y16), B,
+        y16 = torch.empty((B, ox, oy, oz, cout), dtype=self.t16, device=self.device)
+        _ffi.check(self._L.sk_conv3d(self._srcs(srcs16), len(srcs16), _ffi.ptr(packed), _ffi.ptr(bias), _ffi.ptr(y16), B,
                                       ox, oy, oz, cout, ksize, _ffi.ptr(partial), _ffi.ptr(self._zero_page),
                                       _ffi.stream_ptr(self.device)))
         return y16
 
     def _h(self, t: Tensor) -> Tensor:
         """fp16 form of an activation: itself, or the registered twin of an fp32 tensor."""
-        return t if t.dtype == torch.float16 else self._half[t.data_ptr()]
+        return t if t.dtype == self.t16 else self._half[t.data_ptr()]
 
     def _block_mixed(self, layer: _Layer, srcs: List[Tuple[Tensor, int]], out_shape: Tuple[int, int, int],
                      want32: bool = False) -> Tensor:
@@ -183,18 +222,18 @@ class TrainUNet:
         ox, oy, oz = out_shape
         st = _ffi.stream_ptr(self.device)
         srcs16 = [(self._h(t), up) for t, up in srcs]
-        nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, layer.cout, layer.ksize)
+        nblk = self._L.sk_conv3d_num_blocks(B, ox, oy, oz, layer.cout, layer.ksize)
         partial = torch.empty((B, nblk, layer.cout // 4, 2), dtype=torch.float32, device=self.device)
         y16 = self._fast_conv(srcs16, self._pack(layer), layer.bias, out_shape, layer.cout, layer.ksize, partial)
         vox = ox * oy * oz
         affine = torch.empty((B, 2, layer.cout), dtype=torch.float32, device=self.device)
         stats = torch.empty((B, GN_GROUPS, 2), dtype=torch.float32, device=self.device)
-        _ffi.check(_ffi.lib.sk_groupnorm_finalize_stats(_ffi.ptr(partial), B, nblk, GN_GROUPS, layer.cout, vox,
+        _ffi.check(self._L.sk_groupnorm_finalize_stats(_ffi.ptr(partial), B, nblk, GN_GROUPS, layer.cout, vox,
                                                         _ffi.ptr(layer.gamma), _ffi.ptr(layer.beta), GN_EPS,
                                                         _ffi.ptr(affine), _ffi.ptr(stats), st))
         z16 = torch.empty_like(y16)
         z32 = torch.empty(y16.shape, dtype=torch.float32, device=self.device) if want32 else None
-        _ffi.check(_ffi.lib.sk_train_gn_silu_f16(_ffi.ptr(y16), _ffi.ptr(affine), _ffi.ptr(z16), _ffi.ptr(z32), B, vox,
+        _ffi.check(self._L.sk_train_gn_silu_f16(_ffi.ptr(y16), _ffi.ptr(affine), _ffi.ptr(z16), _ffi.ptr(z32), B, vox,
                                                  layer.cout, st))
         out = z16
         if want32:
@@ -206,7 +245,7 @@ class TrainUNet:
     def _stem_fast(self, layer: _Layer, srcs, out_shape) -> bool:
         """The stem (Cin = 1, 27 taps, Cout 32) as a fast block: fp16 image operand, exact weights (hi + lo split)."""
         B = srcs[0][0].shape[0]
-        return (self.precision == "mixed" and layer.norm and layer.cin == 1 and layer.cout == 32 and layer.ksize == 3 and
+        return (self.fast16 and layer.norm and layer.cin == 1 and layer.cout == 32 and layer.ksize == 3 and
                 len(srcs) == 1 and B <= 16 and out_shape[2] % 2 == 0 and self.fast_stem)
 
     def _block_stem_mixed(self, layer: _Layer, srcs, out_shape) -> Tensor:
@@ -214,28 +253,28 @@ class TrainUNet:
         B = image.shape[0]
         X, Y, Z = out_shape
         st = _ffi.stream_ptr(self.device)
-        nblk = _ffi.lib.sk_conv3d_stem_num_blocks(X, Y, Z)
+        nblk = self._L.sk_conv3d_stem_num_blocks(X, Y, Z)
         partial = torch.empty((B, nblk, 8, 2), dtype=torch.float32, device=self.device)
-        wsb = int(_ffi.lib.sk_conv3d_stem_workspace_bytes(B, X, Y, Z))
+        wsb = int(self._L.sk_conv3d_stem_workspace_bytes(B, X, Y, Z))
         ws = torch.empty(wsb, dtype=torch.uint8, device=self.device)
         w_t = layer.weight.reshape(32, 27).t().contiguous()   # (27, 32) tap-major, the stem kernel's layout
-        y16 = torch.empty((B, X, Y, Z, 32), dtype=torch.float16, device=self.device)
-        _ffi.check(_ffi.lib.sk_train_stem_fwd_f16(_ffi.ptr(image), B, X, Y, Z, _ffi.ptr(w_t), _ffi.ptr(layer.bias),
+        y16 = torch.empty((B, X, Y, Z, 32), dtype=self.t16, device=self.device)
+        _ffi.check(self._L.sk_train_stem_fwd_f16(_ffi.ptr(image), B, X, Y, Z, _ffi.ptr(w_t), _ffi.ptr(layer.bias),
                                                   _ffi.ptr(y16), _ffi.ptr(partial), _ffi.ptr(ws), wsb, st))
         vox = X * Y * Z
         affine = torch.empty((B, 2, 32), dtype=torch.float32, device=self.device)
         stats = torch.empty((B, GN_GROUPS, 2), dtype=torch.float32, device=self.device)
-        _ffi.check(_ffi.lib.sk_groupnorm_finalize_stats(_ffi.ptr(partial), B, nblk, GN_GROUPS, 32, vox,
+        _ffi.check(self._L.sk_groupnorm_finalize_stats(_ffi.ptr(partial), B, nblk, GN_GROUPS, 32, vox,
                                                         _ffi.ptr(layer.gamma), _ffi.ptr(layer.beta), GN_EPS,
                                                         _ffi.ptr(affine), _ffi.ptr(stats), st))
         z16 = torch.empty_like(y16)
-        _ffi.check(_ffi.lib.sk_train_gn_silu_f16(_ffi.ptr(y16), _ffi.ptr(affine), _ffi.ptr(z16), None, B, vox, 32, st))
+        _ffi.check(self._L.sk_train_gn_silu_f16(_ffi.ptr(y16), _ffi.ptr(affine), _ffi.ptr(z16), None, B, vox, 32, st))
         self._keep = getattr(self, "_keep", []) + [ws, w_t]   # alive until the stream has consumed them
         self._tape.append((layer, srcs, y16, affine, stats, z16))
         return z16
 
     def _heads_fast(self, layer: _Layer) -> bool:
-        return (self.precision == "mixed" and not layer.norm and layer.ksize == 1 and layer.cout == 5 and layer.cin == 32 and self.fast_heads)
+        return (self.fast16 and not layer.norm and layer.ksize == 1 and layer.cout == 5 and layer.cin == 32 and self.fast_heads)
 
     def _block_heads_mixed(self, layer: _Layer, srcs, out_shape) -> Tensor:
         """1x1x1 heads straight on the fp16 activation (an HBM stream: no fp32 copy of the last feature map)."""
@@ -243,7 +282,7 @@ class TrainUNet:
         B = z16.shape[0]
         ox, oy, oz = out_shape
         logits = torch.empty((B, ox, oy, oz, 5), dtype=torch.float32, device=self.device)
-        _ffi.check(_ffi.lib.sk_train_heads_fwd_f16(_ffi.ptr(z16), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
+        _ffi.check(self._L.sk_train_heads_fwd_f16(_ffi.ptr(z16), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
                                                    _ffi.ptr(logits), B * ox * oy * oz, _ffi.stream_ptr(self.device)))
         self._tape.append((layer, srcs, logits, None, None, logits))
         return logits
@@ -252,12 +291,12 @@ class TrainUNet:
                want32: bool = False) -> Tensor:
         if self._stem_fast(layer, srcs, out_shape):
             return self._block_stem_mixed(layer, srcs, out_shape)
-        if self._heads_fast(layer) and srcs[0][0].dtype == torch.float16:
+        if self._heads_fast(layer) and srcs[0][0].dtype == self.t16:
             return self._block_heads_mixed(layer, srcs, out_shape)
         if self._fast(layer, srcs):
             return self._block_mixed(layer, srcs, out_shape, want32)
         z = self._block_fp32(layer, srcs, out_shape)
-        if self.precision == "mixed" and layer.norm:
+        if self.fast16 and layer.norm:
             self._half[z.data_ptr()] = self._to_half(z)   # the stem's output feeds a fast layer
         return z
 
@@ -267,22 +306,22 @@ class TrainUNet:
         st = _ffi.stream_ptr(self.device)
         y = torch.empty((B, ox, oy, oz, layer.cout), dtype=torch.float32, device=self.device)
         if not layer.norm:
-            _ffi.check(_ffi.lib.sk_conv3d_f32(self._srcs(srcs), len(srcs), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
+            _ffi.check(self._L.sk_conv3d_f32(self._srcs(srcs), len(srcs), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
                                               _ffi.ptr(y), B, ox, oy, oz, layer.cout, layer.ksize, None, st))
             self._tape.append((layer, srcs, y, None, None, y))
             return y
-        nblk = _ffi.lib.sk_conv3d_f32_num_blocks(ox, oy, oz)
+        nblk = self._L.sk_conv3d_f32_num_blocks(ox, oy, oz)
         partial = torch.empty((B, nblk, layer.cout // 4, 2), dtype=torch.float32, device=self.device)
-        _ffi.check(_ffi.lib.sk_conv3d_f32(self._srcs(srcs), len(srcs), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
+        _ffi.check(self._L.sk_conv3d_f32(self._srcs(srcs), len(srcs), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
                                           _ffi.ptr(y), B, ox, oy, oz, layer.cout, layer.ksize, _ffi.ptr(partial), st))
         vox = ox * oy * oz
         affine = torch.empty((B, 2, layer.cout), dtype=torch.float32, device=self.device)
         stats = torch.empty((B, GN_GROUPS, 2), dtype=torch.float32, device=self.device)
-        _ffi.check(_ffi.lib.sk_groupnorm_finalize_stats(_ffi.ptr(partial), B, nblk, GN_GROUPS, layer.cout, vox,
+        _ffi.check(self._L.sk_groupnorm_finalize_stats(_ffi.ptr(partial), B, nblk, GN_GROUPS, layer.cout, vox,
                                                         _ffi.ptr(layer.gamma), _ffi.ptr(layer.beta), GN_EPS,
                                                         _ffi.ptr(affine), _ffi.ptr(stats), st))
         z = torch.empty_like(y)
-        _ffi.check(_ffi.lib.sk_train_gn_silu(_ffi.ptr(y), _ffi.ptr(affine), _ffi.ptr(z), B, vox, layer.cout, st))
+        _ffi.check(self._L.sk_train_gn_silu(_ffi.ptr(y), _ffi.ptr(affine), _ffi.ptr(z), B, vox, layer.cout, st))
         self._tape.append((layer, srcs, y, affine, stats, z))
         return z
 
@@ -334,14 +373,14 @@ class TrainUNet:
         for _, srcs_, *_rest in self._tape:
             for t_, _up in srcs_:
                 n_readers[t_.data_ptr()] = n_readers.get(t_.data_ptr(), 0) + 1
-        fast_out = {e[5].data_ptr() for e in self._tape if e[2].dtype == torch.float16}
-        k2_read = {t_.data_ptr() for l_, srcs_, y_, *_r in self._tape if l_.ksize == 2 and y_.dtype == torch.float16
+        fast_out = {e[5].data_ptr() for e in self._tape if e[2].dtype == self.t16}
+        k2_read = {t_.data_ptr() for l_, srcs_, y_, *_r in self._tape if l_.ksize == 2 and y_.dtype == self.t16
                    for t_, _u in srcs_}
         for layer, srcs, y, affine, stats, out in reversed(self._tape):
             dz = grads.pop(out.data_ptr())
             B, ox, oy, oz, cout = y.shape
             vox = ox * oy * oz
-            fast = y.dtype == torch.float16   # recorded by _block_mixed
+            fast = y.dtype == self.t16   # recorded by _block_mixed
             ws = None
             dz_scale = None
             if isinstance(dz, tuple):
@@ -349,48 +388,48 @@ class TrainUNet:
                 assert fast and n_readers.get(out.data_ptr(), 0) == 1, "a pending fp16 gradient was never summed"
             if fast:
                 # GroupNorm + SiLU backward straight to the scaled fp16 output gradient (no fp32 dy, no max / cast passes)
-                ws = self._workspace(max(_ffi.lib.sk_train_gn_bwd_f16_workspace_floats(B, vox, cout),
-                                         _ffi.lib.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, cout, layer.cin, layer.ksize)))
+                ws = self._workspace(max(self._L.sk_train_gn_bwd_f16_workspace_floats(B, vox, cout),
+                                         self._L.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, cout, layer.cin, layer.ksize)))
                 scale = torch.empty(3, dtype=torch.float32, device=self.device)
-                dy16 = torch.empty(y.shape, dtype=torch.float16, device=self.device)
+                dy16 = torch.empty(y.shape, dtype=self.t16, device=self.device)
                 if dz_scale is None:
-                    _ffi.check(_ffi.lib.sk_train_gn_silu_bwd_f16(_ffi.ptr(dz), _ffi.ptr(y), _ffi.ptr(affine), _ffi.ptr(stats),
+                    _ffi.check(self._L.sk_train_gn_silu_bwd_f16(_ffi.ptr(dz), _ffi.ptr(y), _ffi.ptr(affine), _ffi.ptr(stats),
                                                                  _ffi.ptr(layer.gamma), B, vox, cout, GN_GROUPS,
                                                                  _ffi.ptr(dy16), _ffi.ptr(scale), _ffi.ptr(layer.g_gamma),
                                                                  _ffi.ptr(layer.g_beta), _ffi.ptr(ws), st))
                 else:
-                    _ffi.check(_ffi.lib.sk_train_gn_silu_bwd_f16h(_ffi.ptr(dz), _ffi.ptr(dz_scale), _ffi.ptr(y),
+                    _ffi.check(self._L.sk_train_gn_silu_bwd_f16h(_ffi.ptr(dz), _ffi.ptr(dz_scale), _ffi.ptr(y),
                                                                   _ffi.ptr(affine), _ffi.ptr(stats), _ffi.ptr(layer.gamma), B,
                                                                   vox, cout, GN_GROUPS, _ffi.ptr(dy16), _ffi.ptr(scale),
                                                                   _ffi.ptr(layer.g_gamma), _ffi.ptr(layer.g_beta),
                                                                   _ffi.ptr(ws), st))
                 dy = None
                 if layer.cin == 1:   # the stem: taps as the GEMM's N, fp32 image x scaled fp16 dy
-                    _ffi.check(_ffi.lib.sk_train_stem_wgrad_f16(_ffi.ptr(srcs[0][0]), _ffi.ptr(dy16), _ffi.ptr(scale), B, ox,
+                    _ffi.check(self._L.sk_train_stem_wgrad_f16(_ffi.ptr(srcs[0][0]), _ffi.ptr(dy16), _ffi.ptr(scale), B, ox,
                                                                 oy, oz, _ffi.ptr(layer.g_weight), _ffi.ptr(layer.g_bias),
                                                                 _ffi.ptr(ws), st))
                 else:
                     srcs16 = [(self._h(t), up) for t, up in srcs]
-                    _ffi.check(_ffi.lib.sk_train_conv_wgrad_f16(self._srcs(srcs16), len(srcs16), _ffi.ptr(dy16), _ffi.ptr(scale),
+                    _ffi.check(self._L.sk_train_conv_wgrad_f16(self._srcs(srcs16), len(srcs16), _ffi.ptr(dy16), _ffi.ptr(scale),
                                                                 B, ox, oy, oz, cout, layer.ksize, _ffi.ptr(layer.g_weight),
                                                                 _ffi.ptr(layer.g_bias), _ffi.ptr(ws), _ffi.ptr(self._zero_page),
                                                                 st))
             else:
                 if layer.norm:
-                    ws = self._workspace(_ffi.lib.sk_train_gn_bwd_workspace_floats(B, vox, cout))
-                    _ffi.check(_ffi.lib.sk_train_gn_silu_bwd(_ffi.ptr(dz), _ffi.ptr(y), _ffi.ptr(affine), _ffi.ptr(stats),
+                    ws = self._workspace(self._L.sk_train_gn_bwd_workspace_floats(B, vox, cout))
+                    _ffi.check(self._L.sk_train_gn_silu_bwd(_ffi.ptr(dz), _ffi.ptr(y), _ffi.ptr(affine), _ffi.ptr(stats),
                                                              _ffi.ptr(layer.gamma), B, vox, cout, GN_GROUPS, _ffi.ptr(dz),
                                                              _ffi.ptr(layer.g_gamma), _ffi.ptr(layer.g_beta), _ffi.ptr(ws), st))
                 dy = dz
-                if srcs[0][0].dtype == torch.float16:   # the heads on the fp16 activation (_block_heads_mixed)
+                if srcs[0][0].dtype == self.t16:   # the heads on the fp16 activation (_block_heads_mixed)
                     nv = B * vox
-                    ws = self._workspace(_ffi.lib.sk_train_heads_wgrad_workspace_floats(nv))
-                    _ffi.check(_ffi.lib.sk_train_heads_wgrad_f16(_ffi.ptr(srcs[0][0]), _ffi.ptr(dy), _ffi.ptr(layer.g_weight),
+                    ws = self._workspace(self._L.sk_train_heads_wgrad_workspace_floats(nv))
+                    _ffi.check(self._L.sk_train_heads_wgrad_f16(_ffi.ptr(srcs[0][0]), _ffi.ptr(dy), _ffi.ptr(layer.g_weight),
                                                                  _ffi.ptr(layer.g_bias), nv, _ffi.ptr(ws), st))
                 else:
-                    ws = self._workspace(_ffi.lib.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, cout, layer.cin,
+                    ws = self._workspace(self._L.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, cout, layer.cin,
                                                                                        layer.ksize))
-                    _ffi.check(_ffi.lib.sk_train_conv_wgrad(self._srcs(srcs), len(srcs), _ffi.ptr(dy), B, ox, oy, oz, cout,
+                    _ffi.check(self._L.sk_train_conv_wgrad(self._srcs(srcs), len(srcs), _ffi.ptr(dy), B, ox, oy, oz, cout,
                                                             layer.ksize, _ffi.ptr(layer.g_weight), _ffi.ptr(layer.g_bias),
                                                             _ffi.ptr(ws), st))
             lo = 0
@@ -412,23 +451,23 @@ class TrainUNet:
                         grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
                     packed = self._pack(layer, 2, 0, c)
                     per = packed.numel() // 8
-                    t16 = torch.empty((8, B, ox, oy, oz, c), dtype=torch.float16, device=self.device)
+                    t16 = torch.empty((8, B, ox, oy, oz, c), dtype=self.t16, device=self.device)
                     for par in range(8):
-                        _ffi.check(_ffi.lib.sk_conv3d(self._srcs([(dy16, 0)]), 1, _ffi.ptr(packed[par * per:(par + 1) * per]),
+                        _ffi.check(self._L.sk_conv3d(self._srcs([(dy16, 0)]), 1, _ffi.ptr(packed[par * per:(par + 1) * per]),
                                                       _ffi.ptr(self._zero_bias), _ffi.ptr(t16[par]), B, ox, oy, oz, c, 1, None,
                                                       _ffi.ptr(self._zero_page), st))
                     if pend is not None:
-                        _ffi.check(_ffi.lib.sk_train_interleave2_add16(_ffi.ptr(t16), _ffi.ptr(pend[0]), _ffi.ptr(pend[1]),
+                        _ffi.check(self._L.sk_train_interleave2_add16(_ffi.ptr(t16), _ffi.ptr(pend[0]), _ffi.ptr(pend[1]),
                                                                        _ffi.ptr(grads[key]), B, ox, oy, oz, c, _ffi.ptr(scale),
                                                                        st))
                     else:
-                        _ffi.check(_ffi.lib.sk_train_interleave2(_ffi.ptr(t16), _ffi.ptr(grads[key]), B, ox, oy, oz, c,
+                        _ffi.check(self._L.sk_train_interleave2(_ffi.ptr(t16), _ffi.ptr(grads[key]), B, ox, oy, oz, c,
                                                                  _ffi.ptr(scale), int(have), st))
                 elif layer.ksize == 2:
                     have = key in grads
                     if not have:
                         grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
-                    _ffi.check(_ffi.lib.sk_train_conv_dgrad(_ffi.ptr(dy), _ffi.ptr(layer.weight), _ffi.ptr(grads[key]), B,
+                    _ffi.check(self._L.sk_train_conv_dgrad(_ffi.ptr(dy), _ffi.ptr(layer.weight), _ffi.ptr(grads[key]), B,
                                                             ox, oy, oz, cout, layer.cin, 0, layer.cin, 2, int(have), st))
                 elif fast:
                     # data gradient on the fast conv kernel: the layer's weight packed transposed + tap-flipped
@@ -438,7 +477,7 @@ class TrainUNet:
                         if key in grads:
                             raise RuntimeError("an upsampled tensor has one consumer in this graph")
                         grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
-                        _ffi.check(_ffi.lib.sk_train_sumpool2_f16(_ffi.ptr(dx16), _ffi.ptr(scale), _ffi.ptr(grads[key]), B,
+                        _ffi.check(self._L.sk_train_sumpool2_f16(_ffi.ptr(dx16), _ffi.ptr(scale), _ffi.ptr(grads[key]), B,
                                                                   ox // 2, oy // 2, oz // 2, c, st))
                     elif (key in fast_out and key not in grads and self.f16_grad_handoff and
                           (n_readers.get(key, 0) == 1 or (n_readers.get(key, 0) == 2 and key in k2_read))):
@@ -449,22 +488,22 @@ class TrainUNet:
                         have = key in grads
                         if not have:
                             grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
-                        _ffi.check(_ffi.lib.sk_train_cast_f16_f32(_ffi.ptr(dx16), _ffi.ptr(grads[key]), t.numel(),
+                        _ffi.check(self._L.sk_train_cast_f16_f32(_ffi.ptr(dx16), _ffi.ptr(grads[key]), t.numel(),
                                                                   _ffi.ptr(scale), int(have), st))
                 elif up:
                     fine = torch.empty((B, ox, oy, oz, c), dtype=torch.float32, device=self.device)
-                    _ffi.check(_ffi.lib.sk_train_conv_dgrad(_ffi.ptr(dy), _ffi.ptr(layer.weight), _ffi.ptr(fine), B, ox, oy,
+                    _ffi.check(self._L.sk_train_conv_dgrad(_ffi.ptr(dy), _ffi.ptr(layer.weight), _ffi.ptr(fine), B, ox, oy,
                                                             oz, cout, layer.cin, lo, c, layer.ksize, 0, st))
                     if key in grads:
                         raise RuntimeError("an upsampled tensor has one consumer in this graph")
                     grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
-                    _ffi.check(_ffi.lib.sk_train_sumpool2(_ffi.ptr(fine), _ffi.ptr(grads[key]), B, ox // 2, oy // 2,
+                    _ffi.check(self._L.sk_train_sumpool2(_ffi.ptr(fine), _ffi.ptr(grads[key]), B, ox // 2, oy // 2,
                                                           oz // 2, c, st))
                 else:
                     have = key in grads
                     if not have:
                         grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
-                    _ffi.check(_ffi.lib.sk_train_conv_dgrad(_ffi.ptr(dy), _ffi.ptr(layer.weight), _ffi.ptr(grads[key]), B,
+                    _ffi.check(self._L.sk_train_conv_dgrad(_ffi.ptr(dy), _ffi.ptr(layer.weight), _ffi.ptr(grads[key]), B,
                                                             ox, oy, oz, cout, layer.cin, lo, c, layer.ksize, int(have), st))
                 lo += c
         self._tape = []

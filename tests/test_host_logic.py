@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     from skoots_amd import _ffi
-    hdr = open(os.path.join(ROOT, "include", "skoots_hip.h")).read()
+    hdr = (open(os.path.join(ROOT, "include", "skoots_hip.h")).read() +
+           open(os.path.join(ROOT, "include", "skoots_hip_bf16.h")).read())
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(sk_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"

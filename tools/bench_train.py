@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", choices=["fp32", "mixed"], default="fp32")
+    ap.add_argument("--precision", choices=["fp32", "mixed", "bf16"], default="fp32")
     args = ap.parse_args()
     from skoots_amd.train import TrainStep, TrainUNet
     from skoots_amd.unet import random_state_dict
@@ -73,7 +73,7 @@ def main():
     ms = t0.elapsed_time(t1) / args.steps
     phases = [sum(e[i].elapsed_time(e[i + 1]) for e in rec) / len(rec) for i in range(4)]
     print(json.dumps({"metric": "train_steps_per_s", "value": round(1000.0 / ms, 4), "unit": "steps/s",
-                      "ms_per_step": round(ms, 2), "dtype": "f32" if args.precision == "fp32" else "f16 operands / f32 accumulate + master", "data": "synthetic",
+                      "ms_per_step": round(ms, 2), "dtype": {"fp32": "f32", "mixed": "f16 operands / f32 accumulate + master", "bf16": "bf16 operands / f32 accumulate + master"}[args.precision], "data": "synthetic",
                       "config": {"workload": f"{X}x{Y}x{Z} crop, batch {B}, random-init U-Net, 3 Tversky terms, AdamW"},
                       "phase_ms": {"forward": round(phases[0], 2), "loss": round(phases[1], 2),
                                    "backward": round(phases[2], 2), "optimizer": round(phases[3], 2)},
