@@ -327,6 +327,10 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             // are requested one body ahead.
             // Fully unrolling the 9 tap rows lets hipcc hoist the next row's loads: +1.5 % for
             // COUT 32 / 64, -8 % for COUT 128 (code size), measured A/B on one device.
+            // The machine scheduler sinks the weight-fragment loads towards their first use (64-100 cycles of
+            // latency hiding left in the ISA): a scheduling barrier after each load group keeps them a whole body
+            // (24 MFMAs) ahead -- -3.7 % time on COUT 64 and 128 (tools/kernel_ab.sh, round 2); the 16x16x32 kernel
+            // below loses 4 % with the same barrier and keeps the free schedule.
             constexpr int kTapUnroll = (NT <= 2) ? 9 : 1;
 #pragma unroll kTapUnroll
             for (int dydz = 0; dydz < 9; ++dydz) {
@@ -348,12 +352,14 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                     for (int d = 0; d < 3; ++d)
                         a1[d] = *reinterpret_cast<const half8*>(wrow + ((3 + d) * NT) * 1024);
                 }
+                __builtin_amdgcn_sched_barrier(0);   // see kTapUnroll's comment
                 compute(dydz, 0, a0);
                 if (dydz < 8 && !SK_ABL(a, 32)) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
                         a0[d] = *reinterpret_cast<const half8*>(wrow + ((6 + d) * NT) * 1024);
                 }
+                __builtin_amdgcn_sched_barrier(0);   // see kTapUnroll's comment
                 compute(dydz, 1, a1);
             }
         }

@@ -96,6 +96,10 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
     constexpr bool STATS = MODE == 0 || MODE == 2;
     constexpr int kOutC = MODE == 3 ? 64 : 32;   // halves per output voxel line
     __shared__ float red[4 * 16];
+    // per-wave transpose pad (2 KiB): the 32 x 32 (channel, voxel) result tile leaves the MFMA layout as whole 64-byte
+    // voxel lines, 16 B per lane -- one store instruction writes 1 KiB contiguous (the tile's 32 voxels are contiguous
+    // in the output).  8-byte stores straight from the MFMA layout ran the apply pass at 43 % of the write bandwidth.
+    __shared__ __attribute__((aligned(16))) char tpad[MODE == 0 ? 16 : 4 * 2048];
     extern __shared__ __attribute__((aligned(16))) unsigned int stem_lds[];  // [3][rows+2][Zt+2] halves
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
@@ -108,14 +112,32 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
     const int py = a.Yt + 2, pz = a.Zt + 2;
     const t16* nb = a.norm + (long long)b * (a.Xt + 2) * py * pz;
 
-    // stage the three padded x planes' rows [y0, y0 + rows + 2): contiguous (rows+2)*pz halves each
+    // stage the three padded x planes' rows [y0, y0 + rows + 2): contiguous (rows+2)*pz halves each.  Eight loads per
+    // lane are issued before the first LDS store (a plain copy loop chains load -> store, one latency per 256 dwords).
     const int seg_halves = (a.rows + 2) * pz;          // LDS pitch per plane (halves, even)
     const int seg_dw = (rows + 2) * pz / 2;               // dwords to copy (pz is even: Zt % 4 == 0)
+    {
+        const unsigned int* src[3];
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-        const unsigned int* src = reinterpret_cast<const unsigned int*>(nb + ((long long)(x + dx) * py + y0) * pz);
-        unsigned int* dst = stem_lds + dx * (seg_halves / 2);
-        for (int i = tid; i < seg_dw; i += 256) dst[i] = src[i];
+        for (int dx = 0; dx < 3; ++dx)
+            src[dx] = reinterpret_cast<const unsigned int*>(nb + ((long long)(x + dx) * py + y0) * pz);
+        for (int i0 = tid; i0 < seg_dw; i0 += 256 * 4) {
+            unsigned int v[3][4];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + 256 * k;
+                    v[dx][k] = i < seg_dw ? src[dx][i] : 0u;
+                }
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + 256 * k;
+                    if (i < seg_dw) stem_lds[dx * (seg_halves / 2) + i] = v[dx][k];
+                }
+        }
     }
     __syncthreads();
     const t16* ls = reinterpret_cast<const t16*>(stem_lds);
@@ -169,34 +191,49 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
         acc = SK_MFMA_32x32x16_T16(wlo[1], b1, acc, 0, 0, 0);
         acc = SK_MFMA_32x32x16_T16(whi[0], b0, acc, 0, 0, 0);
         acc = SK_MFMA_32x32x16_T16(whi[1], b1, acc, 0, 0, 0);
-        if (ok) {
-            if (STATS) {
+        if (STATS && ok) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v0 = acc[4 * q], v1 = acc[4 * q + 1], v2 = acc[4 * q + 2], v3 = acc[4 * q + 3];
-                    gsum[q] += (v0 + v1) + (v2 + v3);
-                    gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-                    if (MODE == 2) {
-                        const long long v = ((long long)x * a.Yt + (y0 + yl)) * a.Zt + z;
-                        half4v hv = {(t16)v0, (t16)v1, (t16)v2, (t16)v3};
-                        *reinterpret_cast<half4v*>(a.out + ((long long)b * nvox + v) * 32 + 8 * q + 4 * h) = hv;
-                    }
+            for (int q = 0; q < 4; ++q) {
+                float v0 = acc[4 * q], v1 = acc[4 * q + 1], v2 = acc[4 * q + 2], v3 = acc[4 * q + 3];
+                gsum[q] += (v0 + v1) + (v2 + v3);
+                gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+            }
+        }
+        if (MODE != 0) {
+            // result values of this lane: channels 8q + 4h + j of voxel `col`; MODE 2 stores them raw
+            float r[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (MODE == 2) {
+                    r[k] = acc[k];
+                } else {
+                    const float yv = fmaf(ga[k], acc[k], gb[k]);
+                    r[k] = yv * __builtin_amdgcn_rcpf(1.0f + __expf(-yv));
                 }
-            } else {
-                const long long v = ((long long)x * a.Yt + (y0 + yl)) * a.Zt + z;
-                t16* op = a.out + ((long long)b * nvox + v) * kOutC;
+            }
+            char* pad = tpad + w * 2048;
+            const int rv = lane >> 2, rc = lane & 3;    // read-back role: voxel (0..15), 16-byte chunk of its line
+            // the tile's 32 voxels are contiguous in the output: voxel index v0t + c, c = 0..31
+            const long long v0t = ((long long)x * a.Yt + y0) * a.Zt + (long long)t * 32;
+            t16* ob = a.out + ((long long)b * nvox + v0t) * kOutC;
+#pragma unroll
+            for (int part = 0; part < (MODE == 3 ? 2 : 1); ++part) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    half4v hv, lv;
+                    half4v hv;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float yv = fmaf(ga[4 * q + j], acc[4 * q + j], gb[4 * q + j]);
-                        const float sv = yv * __builtin_amdgcn_rcpf(1.0f + __expf(-yv));
-                        hv[j] = (t16)sv;
-                        lv[j] = (t16)(sv - (float)hv[j]);
+                        const t16 hi = (t16)r[4 * q + j];
+                        hv[j] = part == 0 ? hi : (t16)(r[4 * q + j] - (float)hi);
                     }
-                    *reinterpret_cast<half4v*>(op + 8 * q + 4 * h) = hv;
-                    if (MODE == 3) *reinterpret_cast<half4v*>(op + 32 + 8 * q + 4 * h) = lv;
+                    *reinterpret_cast<half4v*>(pad + col * 64 + ((q ^ ((col >> 1) & 3)) * 16) + 8 * h) = hv;
+                }
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int vv = rv + 16 * hh;
+                    const half8 line = *reinterpret_cast<const half8*>(pad + vv * 64 + ((rc ^ ((vv >> 1) & 3)) * 16));
+                    if (t * 32 + vv < nloc)
+                        *reinterpret_cast<half8*>(reinterpret_cast<char*>(ob + (long long)vv * kOutC) + part * 64 + rc * 16) = line;
                 }
             }
         }
