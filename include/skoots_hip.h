@@ -193,6 +193,17 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
               void* out, int B, int ox, int oy, int oz, int cout, int ksize,
               float* gn_partial, void* zero_page, void* stream);
 
+/* 2x2x2 stride-2 down conv with the GroupNorm + SiLU of its INPUT folded in (the fused form of north_star's
+ * "fused GroupNorm+SiLU" for the two skip tensors): in_raw (B, 2ox, 2oy, 2oz, cin) fp16 is the RAW output of the
+ * producing conv, affine (B, 2, cin) its GroupNorm coefficients.  The kernel stages the input through LDS, activates
+ * it there (bit-identical to sk_groupnorm_silu), WRITES THE ACTIVATED VALUES BACK to in_raw -- afterwards the
+ * tensor is activated, as its other consumer (the decoder's skip conv) needs it -- and computes the conv from LDS.
+ * (cin, cout) = (32, 64) | (64, 128); weight / bias / out / gn_partial / zero_page as sk_conv3d with ksize 2
+ * (which runs the same kernel without activation when its source has affine == NULL). */
+int sk_conv3d_down_act(void* in_raw, const float* affine, const void* weight, const float* bias, void* out,
+                       int B, int ox, int oy, int oz, int cin, int cout, float* gn_partial,
+                       void* zero_page, void* stream);
+
 /* Rows of gn_partial per batch item that sk_conv3d writes for this output shape. */
 int sk_conv3d_num_blocks(int B, int ox, int oy, int oz, int cout, int ksize);
 

@@ -174,31 +174,48 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
     float gsum[4] = {0, 0, 0, 0}, gsq[4] = {0, 0, 0, 0};
     const int nloc = rows * a.Zt;                 // voxels of this workgroup
     const int ntile = (nloc + 31) / 32;
-    for (int t = w; t < ntile; t += 4) {
-        const int i = t * 32 + col;
-        const bool ok = i < nloc;
-        const int ii = ok ? i : 0;
-        const int yl = ii / a.Zt, z = ii - yl * a.Zt;
-        const t16* p = ls + yl * pz + z;       // tap (0,0,0) in the staged planes
-        half8 b0, b1;
+    // statistics pass: two tiles per iteration with independent accumulators -- the four MFMAs of a tile form one
+    // dependent chain, and a lone chain leaves the matrix pipe waiting on itself
+    constexpr int U = MODE == 0 ? 2 : 1;
+    for (int t0 = w; t0 < ntile; t0 += 4 * U) {
+        half8 b0[U], b1[U];
+        bool oku[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            b0[j] = p[toff[0][j]];
-            b1[j] = p[toff[1][j]];
-        }
-        f32x16 acc = binit;
-        acc = SK_MFMA_32x32x16_T16(wlo[0], b0, acc, 0, 0, 0);
-        acc = SK_MFMA_32x32x16_T16(wlo[1], b1, acc, 0, 0, 0);
-        acc = SK_MFMA_32x32x16_T16(whi[0], b0, acc, 0, 0, 0);
-        acc = SK_MFMA_32x32x16_T16(whi[1], b1, acc, 0, 0, 0);
-        if (STATS && ok) {
+        for (int u = 0; u < U; ++u) {
+            const int i = (t0 + 4 * u) * 32 + col;
+            oku[u] = i < nloc;
+            const int ii = oku[u] ? i : 0;
+            const int yl = ii / a.Zt, z = ii - yl * a.Zt;
+            const t16* p = ls + yl * pz + z;       // tap (0,0,0) in the staged planes
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v0 = acc[4 * q], v1 = acc[4 * q + 1], v2 = acc[4 * q + 2], v3 = acc[4 * q + 3];
-                gsum[q] += (v0 + v1) + (v2 + v3);
-                gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+            for (int j = 0; j < 8; ++j) {
+                b0[u][j] = p[toff[0][j]];
+                b1[u][j] = p[toff[1][j]];
             }
         }
+        f32x16 accu[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) accu[u] = SK_MFMA_32x32x16_T16(wlo[0], b0[u], binit, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) accu[u] = SK_MFMA_32x32x16_T16(wlo[1], b1[u], accu[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) accu[u] = SK_MFMA_32x32x16_T16(whi[0], b0[u], accu[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) accu[u] = SK_MFMA_32x32x16_T16(whi[1], b1[u], accu[u], 0, 0, 0);
+        if (STATS) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (oku[u]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v0 = accu[u][4 * q], v1 = accu[u][4 * q + 1], v2 = accu[u][4 * q + 2], v3 = accu[u][4 * q + 3];
+                        gsum[q] += (v0 + v1) + (v2 + v3);
+                        gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                    }
+                }
+        }
+        const int t = t0;              // MODE != 0: one tile per iteration
+        const f32x16 acc = accu[0];
         if (MODE != 0) {
             // result values of this lane: channels 8q + 4h + j of voxel `col`; MODE 2 stores them raw
             float r[16];
@@ -233,7 +250,7 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
                     const int vv = rv + 16 * hh;
                     const half8 line = *reinterpret_cast<const half8*>(pad + vv * 64 + ((rc ^ ((vv >> 1) & 3)) * 16));
                     if (t * 32 + vv < nloc)
-                        *reinterpret_cast<half8*>(reinterpret_cast<char*>(ob + (long long)vv * kOutC) + part * 64 + rc * 16) = line;
+                        __builtin_nontemporal_store(line, reinterpret_cast<half8*>(reinterpret_cast<char*>(ob + (long long)vv * kOutC) + part * 64 + rc * 16));
                 }
             }
         }
@@ -351,7 +368,7 @@ __global__ void __launch_bounds__(256) gn_silu_kernel(t16* __restrict__ x,
     }
     half8* p = reinterpret_cast<half8*>(x) + (long long)b * nvec_per_batch;
     for (; i < nvec_per_batch; i += stride) {
-        half8 v = p[i];
+        half8 v = __builtin_nontemporal_load(&p[i]);
         half8 r;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -359,7 +376,7 @@ __global__ void __launch_bounds__(256) gn_silu_kernel(t16* __restrict__ x,
             float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
             r[j] = (t16)(y * sg);
         }
-        p[i] = r;
+        __builtin_nontemporal_store(r, &p[i]);
     }
 }
 

@@ -216,6 +216,23 @@ class HipUNet:
         aff = self._norm_act(layer, out, partial, nblk, apply=activate)
         return out if activate else (out, aff)
 
+    def _down(self, layer: _ConvLayer, src: Tensor, aff: Optional[Tensor], out_shape, tag: str):
+        """Stride-2 down conv whose input is the RAW output of the previous block: the kernel activates it while staging
+        it (GroupNorm affine + SiLU in LDS) and writes the activated values back -- ``src`` is activated afterwards, as
+        the decoder's skip conv needs it.  Saves the separate in-place GroupNorm pass over the skip tensor."""
+        if aff is None:
+            return self._conv(layer, [(src, 0)], out_shape, tag)
+        B = src.shape[0]
+        ox, oy, oz = out_shape
+        out = self._buf(tag, (B, ox, oy, oz, layer.cout))
+        nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, layer.cout, 2)
+        partial = self._buf("partial", (B * nblk * (layer.cout // 4) * 2,), torch.float32)
+        _ffi.check(_ffi.lib.sk_conv3d_down_act(_ffi.ptr(src), _ffi.ptr(aff), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
+                                               _ffi.ptr(out), B, ox, oy, oz, layer.cin, layer.cout, _ffi.ptr(partial),
+                                               _ffi.ptr(self.zeros), _ffi.stream_ptr(self.device)))
+        self._norm_act(layer, out, partial, nblk, apply=True)
+        return out
+
     def _stem(self, layer: _ConvLayer, image: Tensor, origins, tile, mean: float, std: float,
               tag: str = "L0a") -> Tensor:
         """First block (Cin = 1): normalise + conv statistics, GroupNorm finalize, then the conv again
@@ -272,19 +289,31 @@ class HipUNet:
         a = self._stem(self.enc0[0], image, origins, L0, float(mean), float(std),
                        "skip0" if len(self.enc0) == 1 else "L0a")
         keep("enc0.0", a)
+        # a skip tensor is read by the stride-2 down conv and by the decoder: the down conv activates it (see _down)
+        fuse_down = self.defer_activation and not self.split and not keep_features
         tags = ["L0b", "L0a"]
+        aff = None
         for i, layer in enumerate(self.enc0[1:]):
-            a = self._conv(layer, [(a, 0)], L0, "skip0" if i == len(self.enc0) - 2 else tags[i % 2])
+            last = i == len(self.enc0) - 2
+            a = self._conv(layer, [(a, 0)], L0, "skip0" if last else tags[i % 2],
+                           activate=not (last and fuse_down and self.down0.cin == 32 and self.down0.cout == 64))
+            if isinstance(a, tuple):
+                a, aff = a
             keep(layer.name, a)
         s0 = a
-        a = self._conv(self.down0, [(s0, 0)], L1, "L1a")
+        a = self._down(self.down0, s0, aff, L1, "L1a")
         keep("down0", a)
         tags = ["L1b", "L1a"]
+        aff = None
         for i, layer in enumerate(self.enc1):
-            a = self._conv(layer, [(a, 0)], L1, "skip1" if i == len(self.enc1) - 1 else tags[i % 2])
+            last = i == len(self.enc1) - 1
+            a = self._conv(layer, [(a, 0)], L1, "skip1" if last else tags[i % 2],
+                           activate=not (last and fuse_down and self.down1.cin == 64 and self.down1.cout == 128))
+            if isinstance(a, tuple):
+                a, aff = a
             keep(layer.name, a)
         s1 = a
-        a = self._conv(self.down1, [(s1, 0)], L2, "L2a")
+        a = self._down(self.down1, s1, aff, L2, "L2a")
         keep("down1", a)
         tags = ["L2b", "L2a"]
         aff = None

@@ -118,6 +118,42 @@ def test_conv_split_vs_torch(U, B, osp, srcdef, cout, ksize):
     assert torch.allclose(p[..., 1], (wq ** 2).sum(dim=(2, 3)), rtol=1e-4)
 
 
+@pytest.mark.parametrize("B,osp,cin,cout", [(1, (6, 7, 10), 32, 64), (2, (5, 9, 5), 64, 128), (1, (13, 11, 10), 32, 64),
+                                            (1, (3, 4, 3), 64, 128)])
+def test_down_conv_with_fused_activation(U, B, osp, cin, cout):
+    """sk_conv3d_down_act: the stride-2 down conv that activates its RAW input while staging it (GroupNorm affine +
+    SiLU in LDS) and writes the activated tensor back.  The written-back tensor equals sk_groupnorm_silu's result
+    bit for bit; the conv output equals the plain kernel's on the activated tensor (same operands, same K order)."""
+    from skoots_amd import _ffi
+    gen = torch.Generator().manual_seed(cin + cout + osp[0])
+    isp = tuple(2 * v for v in osp)
+    raw = (torch.randn((B,) + isp + (cin,), generator=gen) * 2).half().to(DEV)
+    aff = torch.stack([torch.rand((B, cin), generator=gen) + 0.5, torch.randn((B, cin), generator=gen) * 0.5], dim=1).to(DEV)
+    w = torch.randn((cout, cin, 2, 2, 2), generator=gen) / (cin * 8) ** 0.5
+    bias = (torch.randn(cout, generator=gen) * 0.1).to(DEV)
+    wp = U.pack_conv_weight(w, DEV)
+    zeros = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    st = _ffi.stream_ptr(torch.device(DEV))
+    # reference path: in-place GroupNorm pass, then the plain conv on the activated tensor
+    act = raw.clone()
+    vox = isp[0] * isp[1] * isp[2]
+    _ffi.check(_ffi.lib.sk_groupnorm_silu(_ffi.ptr(act), _ffi.ptr(aff), B, vox, cin, st))
+    want, want_partial = U.conv3d([(act, 0)], wp, bias, cout, 2, osp, zeros)
+    # fused path
+    x = raw.clone()
+    got = torch.empty((B,) + osp + (cout,), dtype=torch.float16, device=DEV)
+    nblk = _ffi.lib.sk_conv3d_num_blocks(B, osp[0], osp[1], osp[2], cout, 2)
+    partial = torch.zeros((B, nblk, cout // 4, 2), dtype=torch.float32, device=DEV)
+    _ffi.check(_ffi.lib.sk_conv3d_down_act(_ffi.ptr(x), _ffi.ptr(aff), _ffi.ptr(wp), _ffi.ptr(bias), _ffi.ptr(got), B,
+                                           osp[0], osp[1], osp[2], cin, cout, _ffi.ptr(partial), _ffi.ptr(zeros), st))
+    assert torch.equal(x, act), "written-back activation differs from sk_groupnorm_silu"
+    assert torch.equal(got, want)
+    assert torch.allclose(partial.sum(1), want_partial.sum(1), rtol=1e-5, atol=1e-4)
+    # and against torch on the activated operands
+    ref = F.conv3d(_cf(act.cpu().float()), w.half().float(), bias.cpu(), stride=2)
+    assert (_cf(got.cpu().float()) - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
 def test_conv_exact_integer_layout(U):
     """Asymmetric small-integer operands: checks the MFMA operand / accumulator maps exactly."""
     gen = torch.Generator().manual_seed(1)
