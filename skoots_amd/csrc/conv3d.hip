@@ -73,6 +73,10 @@ struct Conv3Args {
     int mode;           // 0: linear (y,z) ranges (small Zt), 1: TY x TZ rectangles
     int TZ, nzc;
     int pitch, nposp;
+    // act[i] != NULL: source i is the RAW output of its producing conv and act[i] (B, 2, C_i) the affine of its GroupNorm:
+    // every lane applies silu(a*x + b) to the chunks it staged itself, in LDS, once its own LDS-DMA has landed -- the
+    // fused form of GroupNorm + SiLU (no separate pass over the tensor; same arithmetic as gn_silu_kernel, bit-identical)
+    const float* act[2];
     int alt;            // multi-chunk layers: visit the chunks in alternating order (see `reuse` in the kernels)
     int ablate;         // timing experiments only (-DSK_TUNING builds, SK_CONV_ABLATE): 1 skip DMA, 2 reuse first weights, 4 skip stores
     // per phase chunk: bit 0 = source, bit 1 = "same LDS image as the previous chunk: no DMA", bits 8.. = byte offset of
@@ -222,7 +226,11 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     // reuses -- 1/6 (two chunks, XS 4) of the plane loads; holding two planes of EVERY chunk across a step would
     // need (XS + 2) + 2 (n - 1) plane slots, more than 80 KiB at any XS that keeps two workgroups per CU.
     const int nck = a.nchunks;
-    auto chunk_of = [&](int step, int k) { return (a.alt && (step & 1)) ? nck - 1 - k : k; };
+    // the order is a function of the ABSOLUTE x position of the step (x-chunks start at multiples of XS), so that the
+    // summation order of an output plane -- and with it every bit of the result -- does not depend on how the launch
+    // was cut into x-chunks (which varies with the batch size)
+    auto chunk_of = [&](int step, int k) { return (a.alt && ((xc * (a.XC / XS) + step) & 1)) ? nck - 1 - k : k; };
+    const int ch0 = chunk_of(0, 0);
     // SPLIT: the output voxel line is [hi (COUT fp16) | lo (COUT fp16)], value = hi + lo (~22 significant bits)
     constexpr int kOvs = COUT * 2 * (SPLIT ? 2 : 1);   // bytes per output voxel
     const long long out_plane = (long long)a.Yt * a.Zt * kOvs;
@@ -275,6 +283,44 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             }
         }
     };
+    // GroupNorm affine + SiLU of a RAW source, applied in LDS by the lane that staged the chunk (its own `vmcnt` wait
+    // covers its own LDS-DMA: no barrier in between); halo / padding lanes staged zeros, which stay zeros
+    auto activate = [&](int step, int ch, bool reuse, int rot_n) {
+        const unsigned ci = a.chinfo[ch];
+        const int si = ci & 1;
+        const float* af = a.act[si];
+        if (af == nullptr) return;
+        const SrcDev s = a.src[si];
+        const int x0 = xa + step * XS;
+        const int c0 = (int)(ci >> 8) / 2 + (d_cs[0] / 16) * 8;   // first channel (of source si) of this lane's 16-byte chunk
+        float ga[8], gb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ga[j] = af[((long long)b * 2) * (s.C) + c0 + j];
+            gb[j] = af[((long long)b * 2 + 1) * (s.C) + c0 + j];
+        }
+        for (int i = reuse ? 2 : 0; i < R; ++i) {
+            const int x = x0 - 1 + i;
+            if (x < 0 || x >= a.Xt) continue;
+            char* lbase = lds + ((rot_n + i) % R) * plane_bytes;
+#pragma unroll
+            for (int k = 0; k < kMaxDma; ++k) {
+                const int t = w + 4 * k;
+                if (t < ndma && (s.up ? d_up[k] : d_vox[k]) >= 0) {
+                    half8* lp = reinterpret_cast<half8*>(lbase + t * 1024 + lane * 16);
+                    const half8 v = *lp;
+                    half8 r;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {   // gn_silu_kernel's arithmetic, op for op
+                        const float y = fmaf(ga[e], (float)v[e], gb[e]);
+                        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+                        r[e] = (t16)(y * sg);
+                    }
+                    *lp = r;
+                }
+            }
+        }
+    };
     // weight fragment index: (((ch*9 + dydz)*2 + ks)*3 + d)*NT + nt
     auto wbase = [&](int ch) { return a.wpk + ((long long)ch * (9 * 2 * 3 * NT) + wn) * 1024 + lane * 16; };
 
@@ -288,15 +334,16 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     }
     if (tid < R * 4)
         *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
-    issue_dma(0, 0, false, 0);
+    issue_dma(0, ch0, false, 0);
     if constexpr (RES == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(0) + (d * NT) * 1024);
+        for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(ch0) + (d * NT) * 1024);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!SPLIT) activate(0, ch0, false, 0);
     __syncthreads();
 
-    int step = 0, k = 0, ch = 0, rot = 0;   // k: position of the phase in its step's chunk order
+    int step = 0, k = 0, ch = ch0, rot = 0;   // k: position of the phase in its step's chunk order
     for (int ph = 0; ph < nphases; ++ph) {
         const int x0 = xa + step * XS;
         if (k == 0) {
@@ -458,6 +505,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                 constexpr int kStores = P * XS * 2 * (SPLIT ? 2 : 1);  // global stores the epilogue just issued
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
             }
+            if (!SPLIT && !(a.chinfo[nch] & 2)) activate(nstep, nch, reuse_n, rot_n);   // own DMA has landed (waits above)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         step = nstep;
@@ -641,7 +689,11 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     // reuses -- 1/6 (two chunks, XS 4) of the plane loads; holding two planes of EVERY chunk across a step would
     // need (XS + 2) + 2 (n - 1) plane slots, more than 80 KiB at any XS that keeps two workgroups per CU.
     const int nck = a.nchunks;
-    auto chunk_of = [&](int step, int k) { return (a.alt && (step & 1)) ? nck - 1 - k : k; };
+    // the order is a function of the ABSOLUTE x position of the step (x-chunks start at multiples of XS), so that the
+    // summation order of an output plane -- and with it every bit of the result -- does not depend on how the launch
+    // was cut into x-chunks (which varies with the batch size)
+    auto chunk_of = [&](int step, int k) { return (a.alt && ((xc * (a.XC / XS) + step) & 1)) ? nck - 1 - k : k; };
+    const int ch0 = chunk_of(0, 0);
     // SPLIT: the output voxel line is [hi (COUT fp16) | lo (COUT fp16)], value = hi + lo (~22 significant bits)
     constexpr int kOvs = COUT * 2 * (SPLIT ? 2 : 1);   // bytes per output voxel
     const long long out_plane = (long long)a.Yt * a.Zt * kOvs;
@@ -686,6 +738,44 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
             }
         }
     };
+    // GroupNorm affine + SiLU of a RAW source, applied in LDS by the lane that staged the chunk (its own `vmcnt` wait
+    // covers its own LDS-DMA: no barrier in between); halo / padding lanes staged zeros, which stay zeros
+    auto activate = [&](int step, int ch, bool reuse, int rot_n) {
+        const unsigned ci = a.chinfo[ch];
+        const int si = ci & 1;
+        const float* af = a.act[si];
+        if (af == nullptr) return;
+        const SrcDev s = a.src[si];
+        const int x0 = xa + step * XS;
+        const int c0 = (int)(ci >> 8) / 2 + (d_cs / 16) * 8;   // first channel (of source si) of this lane's 16-byte chunk
+        float ga[8], gb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ga[j] = af[((long long)b * 2) * (s.C) + c0 + j];
+            gb[j] = af[((long long)b * 2 + 1) * (s.C) + c0 + j];
+        }
+        for (int i = reuse ? 2 : 0; i < R; ++i) {
+            const int x = x0 - 1 + i;
+            if (x < 0 || x >= a.Xt) continue;
+            char* lbase = lds + ((rot_n + i) % R) * plane_bytes;
+#pragma unroll
+            for (int k = 0; k < kMaxDma; ++k) {
+                const int t = w + 4 * k;
+                if (t < ndma && (s.up ? d_up[k] : d_vox[k]) >= 0) {
+                    half8* lp = reinterpret_cast<half8*>(lbase + t * 1024 + lane * 16);
+                    const half8 v = *lp;
+                    half8 r;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {   // gn_silu_kernel's arithmetic, op for op
+                        const float y = fmaf(ga[e], (float)v[e], gb[e]);
+                        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+                        r[e] = (t16)(y * sg);
+                    }
+                    *lp = r;
+                }
+            }
+        }
+    };
     // weight fragment index: (((ch*9 + dydz)*2 + ks)*3 + d)*NT + nt
     auto wbase = [&](int ch) { return a.wpk + ((long long)ch * (9 * 2 * 3 * NT) + wn) * 1024 + lane * 16; };
 
@@ -699,15 +789,16 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     }
     if (tid < R * 4)
         *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
-    issue_dma(0, 0, false, 0);
+    issue_dma(0, ch0, false, 0);
     if constexpr (RES == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(0) + (d * NT) * 1024);
+        for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(ch0) + (d * NT) * 1024);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!SPLIT) activate(0, ch0, false, 0);
     __syncthreads();
 
-    int step = 0, k = 0, ch = 0, rot = 0;   // k: position of the phase in its step's chunk order
+    int step = 0, k = 0, ch = ch0, rot = 0;   // k: position of the phase in its step's chunk order
     for (int ph = 0; ph < nphases; ++ph) {
         const int x0 = xa + step * XS;
         if (k == 0) {
@@ -877,6 +968,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                 constexpr int kStores = P * XS * 2 * (SPLIT ? 2 : 1);  // global stores the epilogue just issued
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
             }
+            if (!SPLIT && !(a.chinfo[nch] & 2)) activate(nstep, nch, reuse_n, rot_n);   // own DMA has landed (waits above)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         step = nstep;
@@ -1543,9 +1635,9 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
         for (int i = 0; i < n_src; ++i) {
             SK_CHECK_ARG(srcs[i].data && srcs[i].c > 0 && srcs[i].c % kChunk == 0,
                          "sk_conv3d: source %d must have a multiple of 32 channels", i);
-            SK_CHECK_ARG(srcs[i].affine == nullptr,
-                         "sk_conv3d: ksize 3 stages its input by LDS-DMA and needs ACTIVATED sources "
-                         "(affine must be NULL)");
+            SK_CHECK_ARG(srcs[i].affine == nullptr || !split,
+                         "sk_conv3d_split: sources must be activated (affine must be NULL)");
+            a.act[i] = srcs[i].affine;   // RAW source: activated in LDS by the lanes that stage it
             SK_CHECK_ARG(i == 1 || !srcs[i].upsample, "sk_conv3d: only the second source may be upsampled");
             int up = srcs[i].upsample ? 1 : 0;
             SK_CHECK_ARG(!up || (ox % 2 == 0 && oy % 2 == 0 && oz % 2 == 0),
@@ -1560,7 +1652,10 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
             a.src[i].batch = a.src[i].plane * xs;
             cin += srcs[i].c;
         }
-        if (n_src == 1) a.src[1] = a.src[0];
+        if (n_src == 1) {
+            a.src[1] = a.src[0];
+            a.act[1] = a.act[0];
+        }
         a.c0chunks = srcs[0].c / kChunk;
         // phase chunks of a step.  Plain: the 32-channel chunks of the concatenated sources in order.  Split: per
         // logical chunk three phases -- (x_hi, w_lo), (x_hi again: no DMA, w_hi), (x_lo, w_hi); the packed weight

@@ -216,22 +216,25 @@ class HipUNet:
         aff = self._norm_act(layer, out, partial, nblk, apply=activate)
         return out if activate else (out, aff)
 
-    def _down(self, layer: _ConvLayer, src: Tensor, aff: Optional[Tensor], out_shape, tag: str):
-        """Stride-2 down conv whose input is the RAW output of the previous block: the kernel activates it while staging
-        it (GroupNorm affine + SiLU in LDS) and writes the activated values back -- ``src`` is activated afterwards, as
-        the decoder's skip conv needs it.  Saves the separate in-place GroupNorm pass over the skip tensor."""
+    def _down(self, layer: _ConvLayer, src, out_shape, tag: str, want_raw: bool):
+        """Stride-2 down conv.  ``src`` = (tensor, affine | None).  With an affine the tensor is the RAW output of the
+        previous block: the kernel activates it while staging it (GroupNorm affine + SiLU in LDS) and writes the
+        activated values back -- the tensor is activated afterwards, as the decoder's skip conv needs it -- which saves
+        the separate in-place GroupNorm pass over the skip tensor.  Returns (output, affine | None)."""
+        t, aff = src
         if aff is None:
-            return self._conv(layer, [(src, 0)], out_shape, tag)
-        B = src.shape[0]
+            out = self._conv(layer, [(t, 0, None)], out_shape, tag, activate=not want_raw)
+            return out if want_raw else (out, None)
+        B = t.shape[0]
         ox, oy, oz = out_shape
         out = self._buf(tag, (B, ox, oy, oz, layer.cout))
         nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, layer.cout, 2)
         partial = self._buf("partial", (B * nblk * (layer.cout // 4) * 2,), torch.float32)
-        _ffi.check(_ffi.lib.sk_conv3d_down_act(_ffi.ptr(src), _ffi.ptr(aff), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
+        _ffi.check(_ffi.lib.sk_conv3d_down_act(_ffi.ptr(t), _ffi.ptr(aff), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
                                                _ffi.ptr(out), B, ox, oy, oz, layer.cin, layer.cout, _ffi.ptr(partial),
                                                _ffi.ptr(self.zeros), _ffi.stream_ptr(self.device)))
-        self._norm_act(layer, out, partial, nblk, apply=True)
-        return out
+        aff_out = self._norm_act(layer, out, partial, nblk, apply=not want_raw)
+        return (out, aff_out if want_raw else None)
 
     def _stem(self, layer: _ConvLayer, image: Tensor, origins, tile, mean: float, std: float,
               tag: str = "L0a") -> Tensor:
@@ -281,71 +284,76 @@ class HipUNet:
         B = len(origins)
         L0, L1, L2 = (xt, yt, zt), (xt // 2, yt // 2, zt // 2), (xt // 4, yt // 4, zt // 4)
         feats = self.last_features = {}
+        # Fused GroupNorm + SiLU: a conv writes its RAW output and hands (tensor, affine) on; the consumer applies
+        # silu(a*x + b) while it stages the tensor -- the stride-2 down convs and the single-chunk 3x3x3 convs in LDS, the
+        # 1x1x1 convs and the heads on load -- so no separate normalisation pass touches HBM for that tensor.  The two
+        # skip tensors are activated (and written back) by their stride-2 down conv, since the decoder reads them as well.
+        # Where it was measured to cost more than the pass it saves, the pass stays (tools/kernel_ab.sh, 8 tiles of
+        # 300x300x20: in-LDS activation inside the 64/128-channel convs +413 us for 325 us of passes; inside a conv that
+        # reads an UPSAMPLED raw tensor +252 us for a 45 us pass over the low-resolution tensor; inside the single-chunk
+        # 32->32 conv +188 us for a 345 us pass: kept).  ``keep_features`` and the split mode take the unfused path.
+        fuse = self.defer_activation and not self.split and not keep_features
+
+        def lds_act(nxt):   # does the consuming 3x3x3 conv activate a raw input in LDS at a profit?
+            return fuse and nxt.ksize == 3 and nxt.cin == 32
 
         def keep(name, t):
             if keep_features:
-                feats[name] = t.clone()
+                feats[name] = (t[0] if isinstance(t, tuple) else t).clone()
 
-        a = self._stem(self.enc0[0], image, origins, L0, float(mean), float(std),
-                       "skip0" if len(self.enc0) == 1 else "L0a")
+        def block(layer, srcs, shape, tag, want_raw):
+            """srcs: [((tensor, affine | None), upsample)]; returns (tensor, affine | None)."""
+            flat = [(t, up, aff) for (t, aff), up in srcs]
+            out = self._conv(layer, flat, shape, tag, activate=not want_raw)
+            return out if want_raw else (out, None)
+
+        a = (self._stem(self.enc0[0], image, origins, L0, float(mean), float(std),
+                        "skip0" if len(self.enc0) == 1 else "L0a"), None)
         keep("enc0.0", a)
-        # a skip tensor is read by the stride-2 down conv and by the decoder: the down conv activates it (see _down)
-        fuse_down = self.defer_activation and not self.split and not keep_features
         tags = ["L0b", "L0a"]
-        aff = None
         for i, layer in enumerate(self.enc0[1:]):
             last = i == len(self.enc0) - 2
-            a = self._conv(layer, [(a, 0)], L0, "skip0" if last else tags[i % 2],
-                           activate=not (last and fuse_down and self.down0.cin == 32 and self.down0.cout == 64))
-            if isinstance(a, tuple):
-                a, aff = a
+            raw = (fuse and (self.down0.cin, self.down0.cout) == (32, 64)) if last else lds_act(self.enc0[i + 2])
+            a = block(layer, [(a, 0)], L0, "skip0" if last else tags[i % 2], raw)
             keep(layer.name, a)
         s0 = a
-        a = self._down(self.down0, s0, aff, L1, "L1a")
+        a = self._down(self.down0, s0, L1, "L1a", False)   # activates s0 in place when it came in raw
+        s0 = (s0[0], None)
         keep("down0", a)
         tags = ["L1b", "L1a"]
-        aff = None
         for i, layer in enumerate(self.enc1):
             last = i == len(self.enc1) - 1
-            a = self._conv(layer, [(a, 0)], L1, "skip1" if last else tags[i % 2],
-                           activate=not (last and fuse_down and self.down1.cin == 64 and self.down1.cout == 128))
-            if isinstance(a, tuple):
-                a, aff = a
+            raw = last and fuse and (self.down1.cin, self.down1.cout) == (64, 128)
+            a = block(layer, [(a, 0)], L1, "skip1" if last else tags[i % 2], raw)
             keep(layer.name, a)
         s1 = a
-        a = self._down(self.down1, s1, aff, L2, "L2a")
+        a = self._down(self.down1, s1, L2, "L2a", False)
+        s1 = (s1[0], None)
         keep("down1", a)
         tags = ["L2b", "L2a"]
-        aff = None
         for i, layer in enumerate(self.mid):
-            # only red1 (1x1x1, gather GEMM) reads it: activate on load (the split gather GEMM takes activated input)
-            last = self.defer_activation and not self.split and i == len(self.mid) - 1
-            a = self._conv(layer, [(a, 0)], L2, tags[i % 2], activate=not last)
-            if last:
-                a, aff = a
+            # the last one is read only by red1 (1x1x1, gather GEMM): activated on load there (split mode: not supported)
+            raw = self.defer_activation and not self.split and i == len(self.mid) - 1
+            a = block(layer, [(a, 0)], L2, tags[i % 2], raw)
             keep(layer.name, a)
-        r1 = self._conv(self.red1, [(a, 0, aff)], L2, "L2r")
+        r1 = block(self.red1, [(a, 0)], L2, "L2r", False)
         keep("red1", r1)
         tags = ["L1a", "L1b"]
-        aff = None
         for i, layer in enumerate(self.dec1):
-            last = self.defer_activation and not self.split and i == len(self.dec1) - 1  # consumed only by red0
+            raw = self.defer_activation and not self.split and i == len(self.dec1) - 1  # last: consumed by red0
             src = [(s1, 0), (r1, 1)] if i == 0 else [(a, 0)]
-            a = self._conv(layer, src, L1, tags[i % 2], activate=not last)
-            if last:
-                a, aff = a
+            a = block(layer, src, L1, tags[i % 2], raw)
             keep(layer.name, a)
-        r0 = self._conv(self.red0, [(a, 0, aff)], L1, "L1r")
+        r0 = block(self.red0, [(a, 0)], L1, "L1r", False)
         keep("red0", r0)
         tags = ["L0a", "L0b"]
-        aff = None
         for i, layer in enumerate(self.dec0):
-            last = self.defer_activation and i == len(self.dec0) - 1  # consumed only by the heads
+            last = i == len(self.dec0) - 1
+            raw = (self.defer_activation and last) or (not last and lds_act(self.dec0[i + 1]))  # last: consumed by the heads
             src = [(s0, 0), (r0, 1)] if i == 0 else [(a, 0)]
-            a = self._conv(layer, src, L0, tags[i % 2], activate=not last)
-            if last:
-                a, aff = a
+            a = block(layer, src, L0, tags[i % 2], raw)
             keep(layer.name, a)
+        a, aff = a
         out5 = self._buf("out5", (B, 5, xt, yt, zt))
         i3 = C.c_int32 * 3
         blo = i3(*[int(v) for v in out_box[0]]) if out_box is not None else None
