@@ -21,8 +21,10 @@ class Sigma:
         return [s * m for s in self.initial_sigma]
 
 
-def init_sigma(cfg) -> Sigma:
-    """``cfg.TRAIN.INITIAL_SIGMA`` / ``cfg.TRAIN.SIGMA_DECAY`` ([multiplier, epoch] pairs), sigma.py:57-60."""
+def init_sigma(cfg, device=None) -> Sigma:
+    """``cfg.TRAIN.INITIAL_SIGMA`` / ``cfg.TRAIN.SIGMA_DECAY`` ([multiplier, epoch] pairs), sigma.py:57-60.
+    ``device`` is accepted for signature compatibility with the reference (``init_sigma(cfg, device)``) and not
+    needed: the values travel to the kernels as host floats."""
     tr = cfg["TRAIN"] if isinstance(cfg, dict) else cfg.TRAIN
     get = (lambda k: tr[k]) if isinstance(tr, dict) else (lambda k: getattr(tr, k))
     return Sigma([{"multiplier": a, "epoch": b} for a, b in get("SIGMA_DECAY")], get("INITIAL_SIGMA"))
