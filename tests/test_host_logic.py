@@ -141,16 +141,44 @@ def test_thresholds_follow_torch_scalar_casting():
 
 
 def test_zarr_store_roundtrip(tmp_path):
-    """The uncompressed zarr v2 stores eval() leaves behind: metadata per the v2 spec, ragged edge chunks."""
+    """The zarr v2 stores eval() leaves behind: metadata per the v2 spec, ragged edge chunks; numcodecs-zlib chunks
+    (what a zarr reader decodes with the stdlib codec) and raw ones; all-fill-value chunks are left out; a gzip store
+    written by another tool reads back; a Blosc store (the reference's default codec) is refused by name."""
+    import gzip
     import json
+    import os
+    import zlib
     import numpy as np
     from skoots_amd.lib import zarr_store
     rng = np.random.default_rng(0)
+    sparse = np.zeros((1, 40, 40, 16), np.uint8)
+    sparse[0, 3:9, 20:30, 2:5] = 1
     for arr, chunks in ((rng.integers(0, 2, (1, 37, 29, 11)).astype(np.uint8), (1, 16, 16, 8)),
-                        (rng.standard_normal((3, 20, 9, 5)).astype(np.float16), None)):
-        path = str(tmp_path / f"a{arr.ndim}{arr.dtype}.zarr")
-        zarr_store.save(path, arr, chunks)
-        meta = json.load(open(path + "/.zarray"))
-        assert meta["zarr_format"] == 2 and meta["shape"] == list(arr.shape) and meta["compressor"] is None
-        assert meta["dtype"] in ("|u1", "<f2") and meta["order"] == "C"
-        assert np.array_equal(zarr_store.load(path), arr)
+                        (rng.standard_normal((3, 20, 9, 5)).astype(np.float16), None), (sparse, (1, 16, 16, 8))):
+        for comp in ("zlib", None):
+            path = str(tmp_path / f"a{arr.ndim}{arr.dtype}{comp}{arr.shape[1]}.zarr")
+            zarr_store.save(path, arr, chunks, compressor=comp)
+            meta = json.load(open(path + "/.zarray"))
+            assert meta["zarr_format"] == 2 and meta["shape"] == list(arr.shape)
+            assert meta["compressor"] == ({"id": "zlib", "level": 1} if comp else None)
+            assert meta["dtype"] in ("|u1", "<f2") and meta["order"] == "C"
+            assert np.array_equal(zarr_store.load(path), arr)
+            files = [f for f in os.listdir(path) if f != ".zarray"]
+            if arr is sparse:
+                assert files == ["0.0.1.0"]   # the one chunk that holds foreground; fill-value chunks are not written
+            if comp:   # a chunk decodes with the plain zlib codec to chunk-shaped raw bytes
+                raw = zlib.decompress(open(os.path.join(path, files[0]), "rb").read())
+                assert len(raw) == int(np.prod(meta["chunks"])) * arr.dtype.itemsize
+    # a gzip-compressed store from elsewhere
+    path = str(tmp_path / "g.zarr")
+    arr = rng.integers(0, 200, (2, 5, 6)).astype(np.uint8)
+    os.makedirs(path)
+    json.dump({"zarr_format": 2, "shape": [2, 5, 6], "chunks": [2, 5, 6], "dtype": "|u1", "compressor": {"id": "gzip", "level": 1},
+               "fill_value": 0, "order": "C", "filters": None}, open(path + "/.zarray", "w"))
+    open(path + "/0.0.0", "wb").write(gzip.compress(arr.tobytes()))
+    assert np.array_equal(zarr_store.load(path), arr)
+    json.dump({"zarr_format": 2, "shape": [2, 5, 6], "chunks": [2, 5, 6], "dtype": "|u1",
+               "compressor": {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0},
+               "fill_value": 0, "order": "C", "filters": None}, open(path + "/.zarray", "w"))
+    with pytest.raises(RuntimeError, match="blosc"):
+        zarr_store.load(path)
