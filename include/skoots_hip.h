@@ -410,7 +410,7 @@ int sk_train_sumpool2_f16(const void* fine16, const float* scale, float* coarse,
 /* The stem as a fast block of the mixed step.  sk_train_stem_fwd_f16: image (B, X, Y, Z) fp32 (rounded to fp16 as the
  *   MFMA operand, weights exact through a hi + lo split), weight_t (27, 32) fp32 tap-major, bias (32) -> RAW y16
  *   (B, X, Y, Z, 32) fp16 + gn_partial (B, sk_conv3d_stem_num_blocks(X, Y, Z), 8, 2); workspace:
- *   sk_conv3d_stem_workspace_bytes(B, X, Y, Z).  B <= 16, Z even.
+ *   sk_conv3d_stem_workspace_bytes(B, X, Y, Z).  B <= 32, Z even.
  * sk_train_stem_wgrad_f16: image fp32 and the scaled fp16 dy (B, X, Y, Z, 32) -> dweight (32, 1, 3, 3, 3), dbias (32),
  *   multiplied by dy_scale[1]; workspace: sk_train_conv_wgrad_workspace_floats(B, X, Y, Z, 32, 1, 3). */
 int sk_train_stem_fwd_f16(const float* image, int B, int X, int Y, int Z, const float* weight_t, const float* bias,

@@ -1476,9 +1476,14 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
         p.xs = 3;
         p.lds = (size_t)(p.xs + 2) * (p.nposp + 1) * kPosBytes + 4 * kPadBytes;
     }
-    // x-chunks: enough workgroups to fill the CUs (2 per CU) several times over
+    // x-chunks: enough workgroups to fill the CUs (2 per CU) several times over at the batch sizes the pipeline runs
+    // (8-32 tiles).  The cut is a function of the tile geometry ONLY, not of B: the GroupNorm partial sums are fp32 sums
+    // per workgroup, so a batch-dependent cut would make a tile's statistics -- and through them its output bits --
+    // depend on how many tiles share its launch (tests/test_hip_geometry.py: batch invariance).
+    (void)B;
+    const int kPlanBatch = 8;
     int target = 256 * 2 * 6;
-    int nxc = (target + p.npatch * B - 1) / (p.npatch * B);
+    int nxc = (target + p.npatch * kPlanBatch - 1) / (p.npatch * kPlanBatch);
     int max_nxc = (Xt + 2 * p.xs - 1) / (2 * p.xs);  // at least two steps per chunk
     if (nxc > max_nxc) nxc = max_nxc;
     if (nxc < 1) nxc = 1;

@@ -21,10 +21,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef t16 half4v __attribute__((ext_vector_type(4)));
 
+constexpr int kStemMaxB = 32;   // tiles per launch (origins travel by value in the kernel arguments)
+
 struct StemArgs {
     const t16* image;   // (X, Y, Z) fp16 volume
     int X, Y, Z;           // volume extents
-    int ox[16], oy[16], oz[16];  // tile origins (B <= 16)
+    int ox[kStemMaxB], oy[kStemMaxB], oz[kStemMaxB];  // tile origins
     int B, Xt, Yt, Zt;     // tile extents
     float mean, stdv;
     const float* weight;   // (27, 32) fp32: [tap = (dx*3+dy)*3+dz][cout]
@@ -543,7 +545,7 @@ static int fill_stem_args(StemArgs& a, const void* image, int X, int Y, int Z, c
                           const float* bias, int cout, void* workspace, size_t workspace_bytes) {
     SK_CHECK_ARG(image && origins_host && weight && bias && workspace, "sk_conv3d_stem: NULL pointer");
     SK_CHECK_ARG(cout == 32, "sk_conv3d_stem: cout must be 32");
-    SK_CHECK_ARG(B >= 1 && B <= 16, "sk_conv3d_stem: batch must be in [1,16]");
+    SK_CHECK_ARG(B >= 1 && B <= kStemMaxB, "sk_conv3d_stem: batch must be in [1,%d]", kStemMaxB);
     SK_CHECK_ARG(stdv != 0.0f, "sk_conv3d_stem: std must be non-zero");
     SK_CHECK_ARG(workspace_bytes >= sk_conv3d_stem_workspace_bytes(B, Xt, Yt, Zt),
                  "sk_conv3d_stem: workspace too small");
@@ -598,7 +600,7 @@ int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origin
 static int stem_apply_impl(int B, int Xt, int Yt, int Zt, const float* weight, const float* bias,
                            const float* affine, void* out, int cout, const void* workspace, void* stream, bool split) {
     SK_CHECK_ARG(weight && bias && affine && out && workspace, "sk_conv3d_stem_apply: NULL pointer");
-    SK_CHECK_ARG(cout == 32 && B >= 1 && B <= 16, "sk_conv3d_stem_apply: bad cout / batch");
+    SK_CHECK_ARG(cout == 32 && B >= 1 && B <= kStemMaxB, "sk_conv3d_stem_apply: bad cout / batch");
     StemArgs a{};
     a.B = B;
     a.Xt = Xt;
@@ -652,7 +654,7 @@ static __global__ void __launch_bounds__(256) stem_frame_f32_kernel(const float*
 int sk_train_stem_fwd_f16(const float* image, int B, int X, int Y, int Z, const float* weight_t, const float* bias,
                           void* y16, float* gn_partial, void* workspace, size_t workspace_bytes, void* stream) {
     SK_CHECK_ARG(image && weight_t && bias && y16 && gn_partial && workspace, "sk_train_stem_fwd_f16: NULL pointer");
-    SK_CHECK_ARG(B >= 1 && B <= 16 && X >= 1 && Y >= 1 && Z >= 2 && Z % 2 == 0, "sk_train_stem_fwd_f16: bad extents");
+    SK_CHECK_ARG(B >= 1 && B <= kStemMaxB && X >= 1 && Y >= 1 && Z >= 2 && Z % 2 == 0, "sk_train_stem_fwd_f16: bad extents");
     SK_CHECK_ARG(workspace_bytes >= sk_conv3d_stem_workspace_bytes(B, X, Y, Z), "sk_train_stem_fwd_f16: workspace too small");
     SK_CHECK_ARG(stem_lds_bytes(Y, Z) <= 60 * 1024, "sk_train_stem_fwd_f16: depth %d unsupported", Z);
     StemArgs a{};

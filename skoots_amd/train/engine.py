@@ -246,7 +246,7 @@ class TrainUNet:
         """The stem (Cin = 1, 27 taps, Cout 32) as a fast block: fp16 image operand, exact weights (hi + lo split)."""
         B = srcs[0][0].shape[0]
         return (self.fast16 and layer.norm and layer.cin == 1 and layer.cout == 32 and layer.ksize == 3 and
-                len(srcs) == 1 and B <= 16 and out_shape[2] % 2 == 0 and self.fast_stem)
+                len(srcs) == 1 and B <= 32 and out_shape[2] % 2 == 0 and self.fast_stem)
 
     def _block_stem_mixed(self, layer: _Layer, srcs, out_shape) -> Tensor:
         image = srcs[0][0]                       # (B, X, Y, Z, 1) fp32

@@ -95,15 +95,24 @@ def test_production_batch_vs_oracle(production, precision, boxed):
         assert e.max().item() <= tol_max and rms <= tol_rms, (precision, b, e.max().item(), rms)
 
 
-def test_production_batch_is_batch_invariant(production):
-    """A tile's output must not depend on its position in the batch or on its batch mates (per-sample
-    GroupNorm, batch strides): tile 2 of the 8-batch == the same tile evaluated alone, bit for bit."""
+@pytest.mark.parametrize("nb", [8, 16, 32])
+def test_production_batch_is_batch_invariant(production, nb):
+    """A tile's output must not depend on its position in the batch, on its batch mates or on the batch size (per-sample
+    GroupNorm, batch strides; the x-chunking of a conv launch is a function of the tile geometry only, because a
+    batch-dependent cut changes the grouping of the fp32 GroupNorm partial sums and with it the last bits of the
+    statistics): tiles of an nb-batch (the pipeline runs 32) == the same tiles evaluated alone, bit for bit."""
     from skoots_amd import unet
+    from skoots_amd.lib import cropper
     ref, vol, origins, mean, std, _ = production
+    grid = cropper.distinct_origins(SHAPE, list(TILE), OVERLAP)
+    batch = (origins + [o for o in grid if o not in origins])[:nb]
     hip = unet.HipUNet.from_module(ref, DEV)
-    a = hip.forward_tiles(vol, origins, TILE, mean, std)[2].clone()
-    b = hip.forward_tiles(vol, [origins[2]], TILE, mean, std)[0]
-    assert torch.equal(a, b)
+    out = hip.forward_tiles(vol, batch, TILE, mean, std)
+    picks = [2, nb - 1]
+    kept = [out[i].clone() for i in picks]
+    for i, a in zip(picks, kept):
+        b = hip.forward_tiles(vol, [batch[i]], TILE, mean, std)[0]
+        assert torch.equal(a, b), (nb, i)
 
 
 # ---- configs[1]: one 512x512x128 tile ---------------------------------------------------------------
