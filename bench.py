@@ -352,6 +352,14 @@ def eval_main(args, rank, world, local):
         conv_ms, conv_flops, conv_launches = prof.totals()
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         traffic, traffic_src = conv_hbm_traffic()
+        per_layer = {}
+        for e0, e1, fl, name in prof.named():
+            d = per_layer.setdefault(name, [0.0, 0.0, 0])
+            d[0] += e0.elapsed_time(e1)
+            d[1] += fl
+            d[2] += 1
+        layers = {k: {"tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1), "avg_launch_ms": round(v[0] / v[2], 4)}
+                  for k, v in per_layer.items() if v[0] > 0}
         line = {
             "metric": "Mvoxels/s end-to-end (3D U-Net fwd + instance assign)",
             "value": round(voxels / (dt / args.steps) / 1e6, 3), "unit": "Mvoxels/s",
@@ -370,7 +378,9 @@ def eval_main(args, rank, world, local):
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic if args.precision == "fp16" else None,
                          "traffic_unit": f"bytes per launch (PMC, profiles/{traffic_src})",
                          "launches": conv_launches, "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
-                         "flops_counted": "algorithmic 2*Cin*Cout*27 per output voxel (split mode issues 3x that on the MFMA pipe)"},
+                         "flops_counted": "algorithmic 2*Cin*Cout*27 per output voxel (split mode issues 3x that on the MFMA pipe); "
+                                          "dec0.1's launches also contain the GroupNorm + SiLU of their input (fused, fp16 mode)",
+                         "layers": layers},
         }
         if args.precision == "fp32":  # the MFMA conv profile only instruments the fp16 / split kernels
             line["roofline"] = None
