@@ -175,7 +175,7 @@ int sk_renumber(int32_t* labels, int64_t n, int max_label, void* workspace,
 typedef struct sk_conv_src {
     const void* data;    /* (B, sx, sy, sz, c) fp16 channels-last                            */
     const float* affine; /* NULL: data is activated.  (B, 2, c) fp32: data is a RAW conv output, */
-                         /* silu(a*x + b) is applied on load (ksize 1 / 2 only)               */
+                         /* silu(a*x + b) is applied while it is staged / loaded              */
     int c;               /* channels of this source (multiple of 32 for ksize 3)            */
     int upsample;        /* 1: source is half resolution, read at (x>>1, y>>1, z>>1)        */
 } sk_conv_src;
@@ -188,7 +188,9 @@ typedef struct sk_conv_src {
  * gn_partial: (B, sk_conv3d_num_blocks, cout/4, 2) fp32 per-block (sum, sumsq) of
  * the fp32 accumulators per channel quad, or NULL.  zero_page: 4 KiB; bytes [0, 1024) must
  * be zero and stay zero (source of the halo / padding lanes of the LDS-DMA), bytes
- * [2048, 3072) are write-only scratch for the ksize-3 kernel's masked store lanes. */
+ * [2048, 3072) are write-only scratch for the ksize-3 kernel's masked store lanes.  Required for ksize 3 and for
+ * the LDS-staged ksize-2 kernel ((cin, cout) = (32, 64) | (64, 128)).  A RAW source (affine != NULL) is activated
+ * while it is staged / loaded: ksize 3 in LDS by the staging lanes, ksize 2 and 1 on load. */
 int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias,
               void* out, int B, int ox, int oy, int oz, int cout, int ksize,
               float* gn_partial, void* zero_page, void* stream);

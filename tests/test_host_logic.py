@@ -182,3 +182,22 @@ def test_zarr_store_roundtrip(tmp_path):
                "fill_value": 0, "order": "C", "filters": None}, open(path + "/.zarray", "w"))
     with pytest.raises(RuntimeError, match="blosc"):
         zarr_store.load(path)
+
+
+def test_cfg_to_model_refuses_networks_it_does_not_implement():
+    """cfg_to_bism_model's counterpart (skoots/lib/utils.py:17-107) runs the build's own U-Net only: the reference's
+    default config (bism_unext, LayerNorm, GELU, 7^3 kernels: skoots/config.py:20-34) must raise, not run another net."""
+    from skoots_amd.unet import cfg_to_model
+    base = {"DIMS": [32, 64, 128, 64, 32], "DEPTHS": [2, 2, 2, 2, 2], "IN_CHANNELS": 1}
+    for key, val in (("ARCHITECTURE", "bism_unext"), ("NORMALIZATION", "layernorm"), ("ACTIVATION", "gelu"), ("KERNEL_SIZE", 7)):
+        with pytest.raises(RuntimeError, match="not implemented"):
+            cfg_to_model({"MODEL": dict(base, **{key: val})}, "cuda:0", {})
+    with pytest.raises(RuntimeError, match="IN_CHANNELS"):
+        cfg_to_model({"MODEL": dict(base, IN_CHANNELS=3)}, "cuda:0", {})
+
+
+def test_precision_names_are_validated():
+    from skoots_amd.unet import HipUNet, PRECISIONS
+    assert PRECISIONS == ("fp16", "split", "fp32")
+    with pytest.raises(ValueError, match="precision"):
+        HipUNet({}, "cuda:0", precision="bf16")
