@@ -414,7 +414,7 @@ def eval_main(args, rank, world, local):
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             log("timing the CPU restatement (bounded sample)")
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -424,7 +424,7 @@ def eval_main(args, rank, world, local):
 # ---------------------------------------------------------------------------------------------------
 # BASELINE configs[4]: one training step
 # ---------------------------------------------------------------------------------------------------
-def train_cpu_baseline(crop=(64, 64, 64)):
+def train_cpu_baseline(crop=(64, 64, 64), budget_s: float = 8.0):
     """oracle/train_step.py (torch autograd + torch.optim.AdamW on oracle/unet_spec.py, fp32) on a sub-crop."""
     from oracle import train_step as O
     from oracle import unet_spec
@@ -442,7 +442,7 @@ def train_cpu_baseline(crop=(64, 64, 64)):
     O.train_step(model, opt, images, masks, skele, baked, sigma, scale)   # warm-up, untimed
     t0 = time.perf_counter()
     n = 0
-    while n < 2 or time.perf_counter() - t0 < 8.0:
+    while n < 2 or time.perf_counter() - t0 < budget_s:
         O.train_step(model, opt, images, masks, skele, baked, sigma, scale)
         n += 1
     dt = (time.perf_counter() - t0) / n
@@ -532,7 +532,7 @@ def train_main(args, rank, world, local):
                                 "tflops": {k: round(v[1] / (v[0] * 1e-3) / 1e12, 1) for k, v in tot.items() if v[0] > 0}}
         if not args.no_cpu_baseline and world == 1:
             log("timing the CPU restatement of the training step (bounded sample)")
-            line["cpu_baseline"] = train_cpu_baseline()
+            line["cpu_baseline"] = train_cpu_baseline(budget_s=args.cpu_budget)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -555,6 +555,7 @@ def main():
     ap.add_argument("--precision", choices=["fp16", "split", "fp32", "bf16", "mixed"], default=None,
                     help="eval: fp16 (default) | split (<= 1e-3 vs fp32) | fp32; train: bf16 (default) | mixed (fp16) | fp32")
     ap.add_argument("--launcher-dry-run", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds of stage-1 CPU work in the cpu_baseline sample")
     args = ap.parse_args()
     if args.precision is None:
         args.precision = "fp16" if args.config == "eval" else "bf16"

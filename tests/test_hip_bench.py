@@ -1,0 +1,51 @@
+"""The driver's contract with bench.py, checked on the GPU box on a reduced volume: ONE JSON line with the metric of
+BASELINE.json, the roofline of the dominant kernel measured live, the per-stage HBM rooflines, the measured parity of
+the benched precision and the CPU baseline; and the training leg (configs[4]) on a reduced crop."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=900,
+                       env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("precision", ["fp16", "split"])
+def test_eval_line_contract(precision):
+    d = _run("--steps", "1", "--warmup", "1", "--shape", "512,512,64", "--precision", precision, "--cpu-budget", "1")
+    assert d["metric"].startswith("Mvoxels/s end-to-end") and d["unit"] == "Mvoxels/s" and d["n_gpus"] == 1
+    assert d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 512 * 512 * 64 / d["ms_per_step"] / 1e3) < 0.01 * d["value"]
+    assert d["config"]["workload"].startswith("512x512x64") and d["config"]["precision"] == precision
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and r["launches"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.02 < r["frac"] < 1.0
+    assert r["layers"] and all(v["tflops"] > 0 for v in r["layers"].values())
+    for k, b in (("roofline_gate", 17), ("roofline_ccl", 9), ("roofline_assign", 64)):
+        assert d[k]["bound"] == "hbm" and d[k]["peak"] == 8000.0 and d[k]["algorithmic_bytes_per_voxel"] == b and d[k]["achieved"] > 0
+    par = d["parity_vs_fp32_mode"]
+    assert par["max_abs"] <= (1e-2 if precision == "fp16" else 1e-3)   # the line states the tolerance of what it measured
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mvoxels/s" and "936" in c["sample"]
+    assert d["config"]["instances"] > 0   # the injected blob field went through stages 2-3
+
+
+def test_train_line_contract():
+    d = _run("--config", "train", "--steps", "2", "--warmup", "1", "--shape", "64,64,64", "--cpu-budget", "1")
+    assert d["dtype"] == "bf16" and d["config"]["precision"] == "bf16" and d["n_gpus"] == 1 and d["value"] > 0
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["launches"] > 0 and d["roofline"]["achieved"] > 0
+    assert set(d["roofline"]["ms_per_step"]) == {"conv_fwd_dgrad", "conv_wgrad"}
+    assert all(0 < v < 3 for v in d["config"]["losses"][:3])
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0

@@ -325,11 +325,13 @@ def test_network_fp32_mode_vs_oracle(U, tile, origins):
         assert err <= 1e-3
 
 
-@pytest.mark.parametrize("shape", [(140, 132, 34), (190, 186, 18)])  # second: thinner than the tile, no extent % 4 == 0
-def test_end_to_end_with_network_fp32_mode(U, shape):
-    """Whole eval path WITH the network (no injected field) in fp32 mode against the CPU oracle on
+@pytest.mark.parametrize("shape,precision", [((140, 132, 34), "fp32"), ((190, 186, 18), "fp32"),  # second: thinner than the
+                                             ((140, 132, 34), "split")])                          # tile, no extent % 4 == 0
+def test_end_to_end_with_network_fp32_mode(U, shape, precision):
+    """Whole eval path WITH the network (no injected field) in the two <= 1e-3 modes against the CPU oracle on
     the same volume: vectors within 1e-3 wherever both gates agree, and the thresholded skeleton /
-    final instance masks differ only where a probability sits within ~1e-5 of the 0.8 threshold."""
+    final instance masks differ only where a probability sits within the mode's error (fp32 ~1e-5, split ~2.5e-4)
+    of the 0.8 threshold."""
     import numpy as np
     from oracle import pipeline as O
     from oracle import unet_spec
@@ -339,7 +341,7 @@ def test_end_to_end_with_network_fp32_mode(U, shape):
         ref.heads.bias[4] = 3.0
         ref.heads.bias[3] = 1.4
         ref.heads.weight[0:3].mul_(0.15)
-    hip = U.HipUNet.from_module(ref, DEV, precision="fp32")
+    hip = U.HipUNet.from_module(ref, DEV, precision=precision)
     gen = torch.Generator().manual_seed(3)
     vol = torch.randint(0, 256, (1,) + shape, generator=gen).to(torch.float16)
     with torch.no_grad():
@@ -347,10 +349,11 @@ def test_end_to_end_with_network_fp32_mode(U, shape):
     got = E.eval_volume(vol.to(DEV), hip, (60, 60, 12), keep_planar_vectors=True)
     sk_w, sk_g = want["skeleton"][0], got["skeleton"].cpu().numpy()
     assert sk_w.sum() > 1e-3 * sk_w.size
-    assert (sk_w != sk_g).mean() < 1e-4
+    flips = 1e-4 if precision == "fp32" else 2e-3   # voxels whose probability lies within the mode's error of 0.8
+    assert (sk_w != sk_g).mean() < flips
     v_w, v_g = want["vectors"].astype(np.float32), got["state"].vec_planar.cpu().numpy().astype(np.float32)
     both = (np.abs(v_w).sum(0) > 0) == (np.abs(v_g).sum(0) > 0)
-    assert both.mean() > 0.9999
+    assert both.mean() > 1 - flips
     assert np.abs(v_w - v_g)[:, both].max() <= 1e-3
     if (sk_w == sk_g).all() and both.all():
         # identical gates -> the integer stages must agree bit for bit
