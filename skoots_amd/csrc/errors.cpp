@@ -18,5 +18,5 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 const char* sk_last_error(void) { return sk::g_err; }
-int sk_abi_version(void) { return 1; }
+int sk_abi_version(void) { return 2; }  // 2: round 2 (split mode, fused down conv, bf16 twins; sk_conv3d ksize 2 needs the zero page)
 }
