@@ -77,6 +77,7 @@ struct Conv3Args {
     // every lane applies silu(a*x + b) to the chunks it staged itself, in LDS, once its own LDS-DMA has landed -- the
     // fused form of GroupNorm + SiLU (no separate pass over the tensor; same arithmetic as gn_silu_kernel, bit-identical)
     const float* act[2];
+    long long* dbg;     // -DSK_TIMING builds: per-wave phase cycle sums
     int alt;            // multi-chunk layers: visit the chunks in alternating order (see `reuse` in the kernels)
     int ablate;         // timing experiments only (-DSK_TUNING builds, SK_CONV_ABLATE): 1 skip DMA, 2 reuse first weights, 4 skip stores
     // per phase chunk: bit 0 = source, bit 1 = "same LDS image as the previous chunk: no DMA", bits 8.. = byte offset of
@@ -89,6 +90,17 @@ struct Conv3Args {
 // (non-temporal epilogue stores: -1.7 % on the conv kernels, +4.5 % on the GroupNorm pass that reads the tensor next --
 // it loses what the conv's stores leave in the Infinity Cache; net zero, not used)
 #define SK_STORE16(v, p) (*reinterpret_cast<half8*>(p) = (v))
+// Phase timing (tools/conv_phase_timing.py, -DSK_TIMING build only): per wave, cycles between the marks of a phase
+#ifdef SK_TIMING
+#define SK_T_DECL long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tprev_ = __builtin_readcyclecounter();
+#define SK_T(i) { const long long t_ = __builtin_readcyclecounter(); tacc_[i] += t_ - tprev_; tprev_ = t_; }
+#define SK_T_DUMP(a, w, lane) if ((a).dbg && blockIdx.x < 4096 && (lane) == 0) { \
+        for (int i_ = 0; i_ < 8; ++i_) (a).dbg[((long long)blockIdx.x * 4 + (w)) * 8 + i_] = tacc_[i_]; }
+#else
+#define SK_T_DECL
+#define SK_T(i)
+#define SK_T_DUMP(a, w, lane)
+#endif
 #ifdef SK_TUNING
 #define SK_ABL(a, bits) ((a).ablate & (bits))
 #else
@@ -344,6 +356,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     __syncthreads();
 
     int step = 0, k = 0, ch = ch0, rot = 0;   // k: position of the phase in its step's chunk order
+    SK_T_DECL
     for (int ph = 0; ph < nphases; ++ph) {
         const int x0 = xa + step * XS;
         if (k == 0) {
@@ -433,7 +446,9 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
         const bool have_next = ph + 1 < nphases;
         const bool reuse_n = step_done && nch == ch;   // same chunk, next step: its planes XS, XS + 1 stay
         const int rot_n = reuse_n ? (rot + XS) % R : rot;
+        SK_T(0)           // MFMA phase
         __syncthreads();  // every wave is done reading the planes about to be overwritten
+        SK_T(1)           // barrier: waiting for the slowest wave of the workgroup
         if (have_next) {
             if (!(a.chinfo[nch] & 2)) issue_dma(nstep, nch, reuse_n, rot_n);   // bit 1: the next chunk multiplies the SAME staged planes
             if constexpr (RES == 0) {
@@ -450,6 +465,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             if (!kLateWait || !step_done || SK_ABL(a, ~0)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 
+        SK_T(2)           // LDS-DMA issue + weight prefetch (+ the landing wait where it is not deferred)
         // ---------------- epilogue (overlaps the DMA): raw fp16 store + GroupNorm partials ------
         // The accumulator tile is [cout rows in registers][voxel columns on lanes]; the output
         // is channels-last.  Each wave transposes its 32x32 tile through a private 2 KiB LDS
@@ -500,13 +516,17 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                 }
             }
         }
+        SK_T(3)           // epilogue
         if (have_next) {
             if (kLateWait && step_done && !SK_ABL(a, ~0)) {
                 constexpr int kStores = P * XS * 2 * (SPLIT ? 2 : 1);  // global stores the epilogue just issued
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
             }
+            SK_T(4)       // deferred landing wait
             if (!SPLIT && !(a.chinfo[nch] & 2)) activate(nstep, nch, reuse_n, rot_n);   // own DMA has landed (waits above)
+            SK_T(5)       // in-LDS activation
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            SK_T(6)       // closing barrier
         }
         step = nstep;
         k = nk;
@@ -514,6 +534,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
         rot = rot_n;
     }
 
+    SK_T_DUMP(a, w, lane)
     // ---- block-level reduction of the GroupNorm partials ------------------------------------
     if (a.partial) {
         __syncthreads();
@@ -799,6 +820,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     __syncthreads();
 
     int step = 0, k = 0, ch = ch0, rot = 0;   // k: position of the phase in its step's chunk order
+    SK_T_DECL
     for (int ph = 0; ph < nphases; ++ph) {
         const int x0 = xa + step * XS;
         if (k == 0) {
@@ -852,6 +874,55 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
             // Fully unrolling the 9 tap rows lets hipcc hoist the next row's loads: +1.5 % for
             // COUT 32 / 64, -8 % for COUT 128 (code size), measured A/B on one device.
             constexpr int kTapUnroll = (NT <= 1) ? 9 : 1;
+            // Without resident weight rows the registers hold the B fragments of TWO tap rows instead: a row's 12
+            // fragments are read once for both cout halves, and the next row's are requested before this row's 48
+            // MFMAs.  tools/conv_phase_timing.py: a wave spends 70-73 % of its life in the MFMA phase and that phase
+            // takes 2.1x its MFMA cycles -- 2x is the share of the pipe when the co-resident wave multiplies too, the
+            // rest is a wave that has the SIMD to itself exposing one LDS latency per body.  dec0.0 (two chunks):
+            // 1.316 -> 1.228 ms per 8 tiles (-6.7 %); the single-chunk layers keep RES = 2 (resident rows beat it, +3 %).
+            if constexpr (RES == 0 && NT == 1) {
+                half8 bb[2][2][R];
+                auto load_row = [&](int dydz, half8 (&dst)[2][R]) {
+                    const int dz = dydz % 3 - 1;
+                    const int q = q_row[0] + (dydz / 3 - 1) * pitch + dz;
+                    const int base = (q * 4 + (g ^ (((q >> 2) & 1) << 1))) * 16;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        int addr = base + 1024 * j;
+                        if (dz < 0) addr = zlo(0, j) ? zero_addr : addr;
+                        if (dz > 0) addr = zhi(0, j) ? zero_addr : addr;
+#pragma unroll
+                        for (int i = 0; i < R; ++i) dst[j][i] = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
+                    }
+                };
+                auto mma_row = [&](int ks, const half8 (&afr)[3], const half8 (&src)[2][R]) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < R; ++i)
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) {
+                                const int o = i - d;
+                                if (o >= 0 && o < XS)
+                                    acc[0][o][ks][j] = SK_MFMA_16x16x32_T16(afr[d], src[j][i], acc[0][o][ks][j], 0, 0, 0);
+                            }
+                };
+                load_row(0, bb[0]);
+#pragma unroll
+                for (int dydz = 0; dydz < 9; ++dydz) {
+                    const char* wrow = wch + (long long)(dydz * 2) * (3 * NT) * 1024;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) a1[d] = *reinterpret_cast<const half8*>(wrow + ((3 + d) * NT) * 1024);
+                    if (dydz < 8) load_row(dydz + 1, bb[(dydz + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_row(0, a0, bb[dydz & 1]);
+                    if (dydz < 8) {
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wrow + ((6 + d) * NT) * 1024);
+                    }
+                    mma_row(1, a1, bb[dydz & 1]);
+                }
+            } else
 #pragma unroll kTapUnroll
             for (int dydz = 0; dydz < 9; ++dydz) {
                 const char* wrow = wch + (long long)((SK_ABL(a, 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
@@ -893,7 +964,9 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
         const bool have_next = ph + 1 < nphases;
         const bool reuse_n = step_done && nch == ch;   // same chunk, next step: its planes XS, XS + 1 stay
         const int rot_n = reuse_n ? (rot + XS) % R : rot;
+        SK_T(0)           // MFMA phase
         __syncthreads();  // every wave is done reading the planes about to be overwritten
+        SK_T(1)           // barrier: waiting for the slowest wave of the workgroup
         if (have_next) {
             if (!(a.chinfo[nch] & 2)) issue_dma(nstep, nch, reuse_n, rot_n);   // bit 1: the next chunk multiplies the SAME staged planes
             if constexpr (RES == 0) {
@@ -910,6 +983,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
             if (!kLateWait || !step_done || SK_ABL(a, ~0)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 
+        SK_T(2)           // LDS-DMA issue + weight prefetch (+ the landing wait where it is not deferred)
         // ---------------- epilogue (overlaps the DMA): raw fp16 store + GroupNorm partials ------
         // The accumulator tile is [cout rows in registers][voxel columns on lanes]; the output
         // is channels-last.  Each wave transposes its 32x32 tile through a private 2 KiB LDS
@@ -963,13 +1037,17 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                 }
             }
         }
+        SK_T(3)           // epilogue
         if (have_next) {
             if (kLateWait && step_done && !SK_ABL(a, ~0)) {
                 constexpr int kStores = P * XS * 2 * (SPLIT ? 2 : 1);  // global stores the epilogue just issued
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
             }
+            SK_T(4)       // deferred landing wait
             if (!SPLIT && !(a.chinfo[nch] & 2)) activate(nstep, nch, reuse_n, rot_n);   // own DMA has landed (waits above)
+            SK_T(5)       // in-LDS activation
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            SK_T(6)       // closing barrier
         }
         step = nstep;
         k = nk;
@@ -977,6 +1055,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
         rot = rot_n;
     }
 
+    SK_T_DUMP(a, w, lane)
     // ---- block-level reduction of the GroupNorm partials ------------------------------------
     if (a.partial) {
         __syncthreads();
@@ -1701,6 +1780,10 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
         // two-chunk layers only: with four chunks the reuse is 1/12 of the loads and measured +1.6 % time (COUT 128);
         // split mode: the chunk triples carry their own reuse flags
         a.alt = (!split && a.nchunks == 2) ? 1 : 0;
+        a.dbg = nullptr;
+#ifdef SK_TIMING
+        if (const char* e = getenv("SK_CONV_DBG")) a.dbg = (long long*)strtoull(e, nullptr, 0);
+#endif
         a.ablate = 0;
 #ifdef SK_TUNING
         if (const char* e = getenv("SK_CONV_ABLATE")) a.ablate = atoi(e);

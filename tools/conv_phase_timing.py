@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Where do the cycles of a conv3 workgroup go?  Runs each 3x3x3 layer shape of the production tile batch on the
+-DSK_TIMING build (make -C skoots_amd/csrc timing), whose kernels sum, per wave, the cycles between the marks of a phase:
+MFMA loop | barrier | LDS-DMA issue (+ landing wait where not deferred) | epilogue | deferred landing wait | in-LDS
+activation | closing barrier.  Prints the mean split over the first 4096 workgroups.
+
+    SKOOTS_HIP_LIB=skoots_amd/libskoots_hip_timing.so python tools/conv_phase_timing.py
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+NAMES = ["mfma", "barrier1", "dma_issue", "epilogue", "landing_wait", "activation", "barrier2", "-"]
+LAYERS = [("32->32 (enc0.1 / dec0.1)", (300, 300, 20), [(32, 0)], 32, False),
+          ("32->32 + fused activation (dec0.1)", (300, 300, 20), [(32, 0)], 32, True),
+          ("32+32up->32 (dec0.0)", (300, 300, 20), [(32, 0), (32, 1)], 32, False),
+          ("64->64 (enc1.*, dec1.1)", (150, 150, 10), [(64, 0)], 64, False),
+          ("64+64up->64 (dec1.0)", (150, 150, 10), [(64, 0), (64, 1)], 64, False),
+          ("128->128 (mid.*)", (75, 75, 5), [(128, 0)], 128, False)]
+
+
+def main():
+    from skoots_amd import _ffi, unet
+    dev = torch.device("cuda", 0)
+    B = 8
+    dbg = torch.zeros((4096, 4, 8), dtype=torch.int64, device=dev)
+    os.environ["SK_CONV_DBG"] = hex(dbg.data_ptr())
+    zeros = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    out = {}
+    for name, ext, srcdef, cout, act in LAYERS:
+        g = torch.Generator(device=dev).manual_seed(1)
+        srcs = [(torch.randn((B,) + (tuple(s // 2 for s in ext) if up else ext) + (c,), generator=g, device=dev).half(), up)
+                for c, up in srcdef]
+        cin = sum(c for c, _ in srcdef)
+        w = torch.randn((cout, cin, 3, 3, 3)) / (cin * 27) ** 0.5
+        wp = unet.pack_conv_weight(w, dev)
+        bias = torch.zeros(cout, device=dev)
+        aff = torch.stack([torch.ones((B, srcdef[0][0])), torch.zeros((B, srcdef[0][0]))], dim=1).to(dev) if act else None
+        res = torch.empty((B,) + ext + (cout,), dtype=torch.float16, device=dev)
+        nblk = _ffi.lib.sk_conv3d_num_blocks(B, *ext, cout, 3)
+        partial = torch.zeros((B, nblk, cout // 4, 2), device=dev)
+        arr = (_ffi.ConvSrc * len(srcs))()
+        for i, (t, up) in enumerate(srcs):
+            arr[i].data, arr[i].affine, arr[i].c, arr[i].upsample = t.data_ptr(), (aff.data_ptr() if act and i == 0 else None), t.shape[-1], up
+        for it in range(2):
+            dbg.zero_()
+            _ffi.check(_ffi.lib.sk_conv3d(arr, len(srcs), _ffi.ptr(wp), _ffi.ptr(bias), _ffi.ptr(res), B, *ext, cout, 3,
+                                          _ffi.ptr(partial), _ffi.ptr(zeros), _ffi.stream_ptr(dev)))
+            torch.cuda.synchronize()
+        d = dbg.double()
+        used = d.sum(dim=(1, 2)) > 0
+        m = d[used].mean(dim=(0, 1))
+        tot = m.sum().item()
+        out[name] = {"cycles_per_wave": round(tot), **{n: round(v / tot, 4) for n, v in zip(NAMES[:7], m.tolist())}}
+        print(name, json.dumps(out[name]), flush=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
