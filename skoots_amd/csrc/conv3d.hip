@@ -730,9 +730,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     // partials) -> bare s_barrier.  The epilogue's global stores are never waited for.
     const int nsteps = (xb - xa + XS - 1) / XS;
     const int nphases = nsteps * a.nchunks;
-    char* pad = lds + R * plane_bytes + w * kPadBytes;
     char* trash = const_cast<char*>(a.zeros) + 2048 + lane * 16;  // upper half of the zero page: write-only scratch
-    const int rv = lane >> 2, rc = lane & 3;  // epilogue read-back: voxel (0..15), 16-byte chunk
 
     auto issue_dma = [&](int step, int ch, bool reuse, int rot_n) {
         const int x0 = xa + step * XS;
@@ -998,8 +996,15 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                     const int x = x0 + o;
 #pragma unroll
                     for (int part = 0; part < (SPLIT ? 2 : 1); ++part) {   // SPLIT: the hi halves, then the lo halves
+                        // The accumulator layout gives a lane 4 channels (16 i + 4 g ..) of voxel c16 (j = 0) and of voxel
+                        // 16 + c16 (j = 1); the lane 16 further on holds the next 4 channels of the same two voxels.
+                        // v_permlane16_swap_b32 (gfx950) exchanges the odd 16-lane rows of one register with the even rows
+                        // of another: afterwards even rows hold 8 consecutive channels of voxel c16, odd rows 8 channels of
+                        // voxel 16 + c16 -- 16 contiguous bytes per lane with no trip through LDS (the transposing pad
+                        // cost two LDS round trips per plane: 17 % of a wave's cycles in tools/conv_phase_timing.py).
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
+                        for (int i = 0; i < 2; ++i) {
+                            unsigned d[2][2];   // [j][dword]: channels 16 i + 4 g + (0,1 | 2,3)
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
                                 const f32x4 r = acc[p][o][i][j];
@@ -1007,29 +1012,28 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                                 if (part == 1)   // lo = fp16(v - hi): exact difference, rounded once
                                     hv = half4{(t16)(r[0] - (float)hv[0]), (t16)(r[1] - (float)hv[1]),
                                                (t16)(r[2] - (float)hv[2]), (t16)(r[3] - (float)hv[3])};
-                                // voxel 16 j + c16, channels 16 i + 4 g .. +3 of the tile: 16-byte chunk 2 i + (g >> 1), half g & 1
-                                const int vx = 16 * j + c16;
-                                *reinterpret_cast<half4*>(pad + vx * kPadStride + (((2 * i + (g >> 1)) ^ ((vx >> 1) & 3)) * 16) +
-                                                          8 * (g & 1)) = hv;
+                                const uint2 u = __builtin_bit_cast(uint2, hv);
+                                d[j][0] = u.x;
+                                d[j][1] = u.y;
                                 if (part == 0 && vvalid(p, j) && x < xb) {
                                     gsum[i] += (r[0] + r[1]) + (r[2] + r[3]);
                                     gsq[i] += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
                                 }
                             }
-                        if (!SK_ABL(a, 4)) {
-                            char* op = outb + (long long)x * out_plane + (long long)tile_vox0 * kOvs + wn * 64 + part * (COUT * 2);
-#pragma unroll
-                            for (int hh = 0; hh < 2; ++hh) {
-                                const int vv = rv + 16 * hh;
-                                const half8 line = *reinterpret_cast<const half8*>(
-                                    pad + vv * kPadStride + ((rc ^ ((vv >> 1) & 3)) * 16));
+                            const auto s0 = __builtin_amdgcn_permlane16_swap(d[0][0], d[1][0], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane16_swap(d[0][1], d[1][1], false, false);
+                            // this lane now owns channels 16 i + 8 (g >> 1) .. +7 of voxel c16 + 16 (g & 1)
+                            const uint4 line = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                            if (!SK_ABL(a, 4)) {
+                                const int vv = c16 + 16 * (g & 1);
+                                char* op = outb + (long long)x * out_plane + (long long)tile_vox0 * kOvs + wn * 64 + part * (COUT * 2);
                                 const bool sok = x < xb && tile_vox0 + vv < tile_nvox[p];
+                                char* dst = op + (long long)vv * kOvs + 32 * i + 16 * (g >> 1);
                                 if constexpr (kLateWait) {
                                     // always issued (the counted wait below relies on it); masked lanes hit the scratch line
-                                    char* dst = sok ? op + (long long)vv * kOvs + rc * 16 : trash;
-                                    SK_STORE16(line, dst);
+                                    *reinterpret_cast<uint4*>(sok ? dst : trash) = line;
                                 } else if (sok) {
-                                    SK_STORE16(line, op + (long long)vv * kOvs + rc * 16);
+                                    *reinterpret_cast<uint4*>(dst) = line;
                                 }
                             }
                         }
