@@ -295,44 +295,6 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             }
         }
     };
-    // GroupNorm affine + SiLU of a RAW source, applied in LDS by the lane that staged the chunk (its own `vmcnt` wait
-    // covers its own LDS-DMA: no barrier in between); halo / padding lanes staged zeros, which stay zeros
-    auto activate = [&](int step, int ch, bool reuse, int rot_n) {
-        const unsigned ci = a.chinfo[ch];
-        const int si = ci & 1;
-        const float* af = a.act[si];
-        if (af == nullptr) return;
-        const SrcDev s = a.src[si];
-        const int x0 = xa + step * XS;
-        const int c0 = (int)(ci >> 8) / 2 + (d_cs[0] / 16) * 8;   // first channel (of source si) of this lane's 16-byte chunk
-        float ga[8], gb[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            ga[j] = af[((long long)b * 2) * (s.C) + c0 + j];
-            gb[j] = af[((long long)b * 2 + 1) * (s.C) + c0 + j];
-        }
-        for (int i = reuse ? 2 : 0; i < R; ++i) {
-            const int x = x0 - 1 + i;
-            if (x < 0 || x >= a.Xt) continue;
-            char* lbase = lds + ((rot_n + i) % R) * plane_bytes;
-#pragma unroll
-            for (int k = 0; k < kMaxDma; ++k) {
-                const int t = w + 4 * k;
-                if (t < ndma && (s.up ? d_up[k] : d_vox[k]) >= 0) {
-                    half8* lp = reinterpret_cast<half8*>(lbase + t * 1024 + lane * 16);
-                    const half8 v = *lp;
-                    half8 r;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {   // gn_silu_kernel's arithmetic, op for op
-                        const float y = fmaf(ga[e], (float)v[e], gb[e]);
-                        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
-                        r[e] = (t16)(y * sg);
-                    }
-                    *lp = r;
-                }
-            }
-        }
-    };
     // weight fragment index: (((ch*9 + dydz)*2 + ks)*3 + d)*NT + nt
     auto wbase = [&](int ch) { return a.wpk + ((long long)ch * (9 * 2 * 3 * NT) + wn) * 1024 + lane * 16; };
 
@@ -352,7 +314,6 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
         for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(ch0) + (d * NT) * 1024);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!SPLIT) activate(0, ch0, false, 0);
     __syncthreads();
 
     int step = 0, k = 0, ch = ch0, rot = 0;   // k: position of the phase in its step's chunk order
@@ -523,7 +484,6 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
             }
             SK_T(4)       // deferred landing wait
-            if (!SPLIT && !(a.chinfo[nch] & 2)) activate(nstep, nch, reuse_n, rot_n);   // own DMA has landed (waits above)
             SK_T(5)       // in-LDS activation
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             SK_T(6)       // closing barrier
@@ -777,20 +737,25 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
             const int x = x0 - 1 + i;
             if (x < 0 || x >= a.Xt) continue;
             char* lbase = lds + ((rot_n + i) % R) * plane_bytes;
+            // the plane's pieces of this lane: all reads first, then branch-free arithmetic (padding lanes keep their
+            // zeros through a select, not a divergent branch, so the reads of a plane are in flight together)
+            half8 v[kMaxDma];
+#pragma unroll
+            for (int k = 0; k < kMaxDma; ++k)
+                if (w + 4 * k < ndma) v[k] = *reinterpret_cast<const half8*>(lbase + (w + 4 * k) * 1024 + lane * 16);
 #pragma unroll
             for (int k = 0; k < kMaxDma; ++k) {
                 const int t = w + 4 * k;
-                if (t < ndma && (s.up ? d_up[k] : d_vox[k]) >= 0) {
-                    half8* lp = reinterpret_cast<half8*>(lbase + t * 1024 + lane * 16);
-                    const half8 v = *lp;
+                if (t < ndma) {
+                    const bool real = (s.up ? d_up[k] : d_vox[k]) >= 0;
                     half8 r;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {   // gn_silu_kernel's arithmetic, op for op
-                        const float y = fmaf(ga[e], (float)v[e], gb[e]);
+                        const float y = fmaf(ga[e], (float)v[k][e], gb[e]);
                         const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
-                        r[e] = (t16)(y * sg);
+                        r[e] = real ? (t16)(y * sg) : v[k][e];
                     }
-                    *lp = r;
+                    *reinterpret_cast<half8*>(lbase + t * 1024 + lane * 16) = r;
                 }
             }
         }
@@ -1725,6 +1690,9 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
                          "sk_conv3d: source %d must have a multiple of 32 channels", i);
             SK_CHECK_ARG(srcs[i].affine == nullptr || !split,
                          "sk_conv3d_split: sources must be activated (affine must be NULL)");
+            SK_CHECK_ARG(srcs[i].affine == nullptr || cout == 32,
+                         "sk_conv3d: ksize 3 activates a RAW source in LDS only in the COUT 32 kernel (for wider layers the "
+                         "separate pass is cheaper: activate the tensor with sk_groupnorm_silu first)");
             a.act[i] = srcs[i].affine;   // RAW source: activated in LDS by the lanes that stage it
             SK_CHECK_ARG(i == 1 || !srcs[i].upsample, "sk_conv3d: only the second source may be upsampled");
             int up = srcs[i].upsample ? 1 : 0;
