@@ -89,7 +89,6 @@ struct Conv3Args {
 // library no environment variable can change what a kernel computes.
 // (non-temporal epilogue stores: -1.7 % on the conv kernels, +4.5 % on the GroupNorm pass that reads the tensor next --
 // it loses what the conv's stores leave in the Infinity Cache; net zero, not used)
-#define SK_STORE16(v, p) (*reinterpret_cast<half8*>(p) = (v))
 // Phase timing (tools/conv_phase_timing.py, -DSK_TIMING build only): per wave, cycles between the marks of a phase
 #ifdef SK_TIMING
 #define SK_T_DECL long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tprev_ = __builtin_readcyclecounter();
@@ -267,9 +266,14 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     const int nsteps = (xb - xa + XS - 1) / XS;
     const int nphases = nsteps * a.nchunks;
     char* pad = lds + R * plane_bytes + w * kPadBytes;
-    char* trash = const_cast<char*>(a.zeros) + 2048 + lane * 16;  // upper half of the zero page: write-only scratch
     const int rv = lane >> 2, rc = lane & 3;  // epilogue read-back: voxel (0..15), 16-byte chunk
 
+    // buffer-resource LDS-DMA and stores: 32-bit offsets into this batch item's tensors (one address VGPR instead of
+    // two, 32-bit address arithmetic: -2 % time); an out-of-range offset reads zeros -- what the halo / padding lanes
+    // want -- and drops a masked store
+    const __amdgpu_buffer_rsrc_t rsrc0 = sk::make_rsrc(a.src[0].data + (long long)b * a.src[0].batch, (unsigned)a.src[0].batch);
+    const __amdgpu_buffer_rsrc_t rsrc1 = sk::make_rsrc(a.src[1].data + (long long)b * a.src[1].batch, (unsigned)a.src[1].batch);
+    const __amdgpu_buffer_rsrc_t rout = sk::make_rsrc(outb, (unsigned)(a.Xt * out_plane));
     auto issue_dma = [&](int step, int ch, bool reuse, int rot_n) {
         const int x0 = xa + step * XS;
         const unsigned ci = a.chinfo[ch];
@@ -281,16 +285,19 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             const int x = x0 - 1 + i;
             const int slotp = (rot_n + i) % R;
             const bool xok = x >= 0 && x < a.Xt;
-            const char* pbase = s.data + (long long)b * s.batch + (long long)(s.up ? (x >> 1) : x) * s.plane + choff;
             char* lbase = lds + slotp * plane_bytes;
+            const unsigned xoff = (unsigned)((s.up ? (x >> 1) : x) * (int)s.plane + choff);
+            const unsigned vstride = (unsigned)(s.C * 2);
 #pragma unroll
             for (int k = 0; k < kMaxDma; ++k) {
                 const int t = w + 4 * k;
                 if (t < ndma) {
                     const int vox = s.up ? d_up[k] : d_vox[k];
-                    const char* g = (xok && vox >= 0) ? pbase + (long long)vox * (s.C * 2) + d_cs[k]
-                                                      : a.zeros + lane * 16;
-                    dma16(g, lbase + t * 1024);
+                    const unsigned voff = (xok && vox >= 0) ? xoff + (unsigned)vox * vstride + (unsigned)d_cs[k] : sk::kOob;
+                    if (si)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)(lbase + t * 1024), 16, voff, 0, 0, 0);
+                    else
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (__attribute__((address_space(3))) void*)(lbase + t * 1024), 16, voff, 0, 0, 0);
                 }
             }
         }
@@ -464,13 +471,10 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                                 const half8 line = *reinterpret_cast<const half8*>(
                                     pad + vv * kPadStride + ((rc ^ ((vv >> 1) & 3)) * 16));
                                 const bool sok = x < xb && tile_vox0 + vv < tile_nvox[p];
-                                if constexpr (kLateWait) {
-                                    // always issued (the counted wait below relies on it); masked lanes hit the scratch line
-                                    char* dst = sok ? op + (long long)vv * kOvs + rc * 16 : trash;
-                                    SK_STORE16(line, dst);
-                                } else if (sok) {
-                                    SK_STORE16(line, op + (long long)vv * kOvs + rc * 16);
-                                }
+                                // always issued (the counted wait relies on it); a masked lane's offset is out of range: dropped
+                                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, line), rout,
+                                                                       sok ? (unsigned)(op + (long long)vv * kOvs + rc * 16 - outb) : sk::kOob, 0, 0);
                             }
                         }
                     }
@@ -690,8 +694,11 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     // partials) -> bare s_barrier.  The epilogue's global stores are never waited for.
     const int nsteps = (xb - xa + XS - 1) / XS;
     const int nphases = nsteps * a.nchunks;
-    char* trash = const_cast<char*>(a.zeros) + 2048 + lane * 16;  // upper half of the zero page: write-only scratch
 
+    // buffer-resource LDS-DMA and stores (see conv3_kernel)
+    const __amdgpu_buffer_rsrc_t rsrc0 = sk::make_rsrc(a.src[0].data + (long long)b * a.src[0].batch, (unsigned)a.src[0].batch);
+    const __amdgpu_buffer_rsrc_t rsrc1 = sk::make_rsrc(a.src[1].data + (long long)b * a.src[1].batch, (unsigned)a.src[1].batch);
+    const __amdgpu_buffer_rsrc_t rout = sk::make_rsrc(outb, (unsigned)(a.Xt * out_plane));
     auto issue_dma = [&](int step, int ch, bool reuse, int rot_n) {
         const int x0 = xa + step * XS;
         const unsigned ci = a.chinfo[ch];
@@ -703,16 +710,19 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
             const int x = x0 - 1 + i;
             const int slotp = (rot_n + i) % R;
             const bool xok = x >= 0 && x < a.Xt;
-            const char* pbase = s.data + (long long)b * s.batch + (long long)(s.up ? (x >> 1) : x) * s.plane + choff;
             char* lbase = lds + slotp * plane_bytes;
+            const unsigned xoff = (unsigned)((s.up ? (x >> 1) : x) * (int)s.plane + choff + d_cs);
+            const unsigned vstride = (unsigned)(s.C * 2);
 #pragma unroll
             for (int k = 0; k < kMaxDma; ++k) {
                 const int t = w + 4 * k;
                 if (t < ndma) {
                     const int vox = s.up ? d_up[k] : d_vox[k];
-                    const char* g = (xok && vox >= 0) ? pbase + (long long)vox * (s.C * 2) + d_cs
-                                                      : a.zeros + lane * 16;
-                    dma16(g, lbase + t * 1024);
+                    const unsigned voff = (xok && vox >= 0) ? xoff + (unsigned)vox * vstride : sk::kOob;
+                    if (si)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)(lbase + t * 1024), 16, voff, 0, 0, 0);
+                    else
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (__attribute__((address_space(3))) void*)(lbase + t * 1024), 16, voff, 0, 0, 0);
                 }
             }
         }
@@ -994,12 +1004,10 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                                 char* op = outb + (long long)x * out_plane + (long long)tile_vox0 * kOvs + wn * 64 + part * (COUT * 2);
                                 const bool sok = x < xb && tile_vox0 + vv < tile_nvox[p];
                                 char* dst = op + (long long)vv * kOvs + 32 * i + 16 * (g >> 1);
-                                if constexpr (kLateWait) {
-                                    // always issued (the counted wait below relies on it); masked lanes hit the scratch line
-                                    *reinterpret_cast<uint4*>(sok ? dst : trash) = line;
-                                } else if (sok) {
-                                    *reinterpret_cast<uint4*>(dst) = line;
-                                }
+                                // always issued (the counted wait relies on it); a masked lane's offset is out of range: dropped
+                                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                                const u32x4 lv = {line.x, line.y, line.z, line.w};
+                                __builtin_amdgcn_raw_buffer_store_b128(lv, rout, sok ? (unsigned)(dst - outb) : sk::kOob, 0, 0);
                             }
                         }
                     }
