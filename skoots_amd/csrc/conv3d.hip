@@ -303,7 +303,14 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
         }
     };
     // weight fragment index: (((ch*9 + dydz)*2 + ks)*3 + d)*NT + nt
-    auto wbase = [&](int ch) { return a.wpk + ((long long)ch * (9 * 2 * 3 * NT) + wn) * 1024 + lane * 16; };
+    // weight fragments through a buffer resource: wave-uniform byte offset in an SGPR + the constant lane * 16 in one VGPR
+    // (no 64-bit address arithmetic in the tap loop)
+    auto wbase = [&](int ch) { return (unsigned)((ch * (9 * 2 * 3 * NT) + wn) * 1024); };
+    const __amdgpu_buffer_rsrc_t wrsrc = sk::make_rsrc(a.wpk, (unsigned)(a.nchunks * (9 * 2 * 3 * NT) * 1024));
+    const unsigned wlane = lane * 16;
+    auto wload = [&](unsigned off) {
+        return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, __builtin_amdgcn_readfirstlane(off), 0));
+    };
 
     half8 a0[3], a1[3];
     half8 wres[RES > 0 ? 2 * RES : 1][3];
@@ -311,14 +318,14 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
 #pragma unroll
         for (int r = 0; r < 2 * RES; ++r)
 #pragma unroll
-            for (int d = 0; d < 3; ++d) wres[r][d] = *reinterpret_cast<const half8*>(wbase(0) + ((r * 3 + d) * NT) * 1024);
+            for (int d = 0; d < 3; ++d) wres[r][d] = wload(wbase(0) + ((r * 3 + d) * NT) * 1024);
     }
     if (tid < R * 4)
         *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
     issue_dma(0, ch0, false, 0);
     if constexpr (RES == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(ch0) + (d * NT) * 1024);
+        for (int d = 0; d < 3; ++d) a0[d] = wload(wbase(ch0) + (d * NT) * 1024);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -335,7 +342,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
         }
         // ---------------- MFMA over the 27 taps of this chunk ---------------------------
         {
-            const char* wch = wbase(ch);
+            const unsigned wch = wbase(ch);
             int pslot[R];
 #pragma unroll
             for (int i = 0; i < R; ++i) pslot[i] = ((rot + i) % R) * plane_bytes;
@@ -373,14 +380,14 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             constexpr int kTapUnroll = (NT <= 2) ? 9 : 1;
 #pragma unroll kTapUnroll
             for (int dydz = 0; dydz < 9; ++dydz) {
-                const char* wrow = wch + (long long)((SK_ABL(a, 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
+                const unsigned wrow = wch + (unsigned)((SK_ABL(a, 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
                 if constexpr (RES > 0) {
                     if (dydz < RES) {
                         compute(dydz, 0, wres[2 * dydz]);
                         if (dydz == RES - 1) {  // first streamed row's ks = 0 fragments, one body ahead
 #pragma unroll
                             for (int d = 0; d < 3; ++d)
-                                a0[d] = *reinterpret_cast<const half8*>(wrow + ((6 + d) * NT) * 1024);
+                                a0[d] = wload(wrow + ((6 + d) * NT) * 1024);
                         }
                         compute(dydz, 1, wres[2 * dydz + 1]);
                         continue;
@@ -389,14 +396,14 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                 if (!SK_ABL(a, 32) || dydz == 0) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
-                        a1[d] = *reinterpret_cast<const half8*>(wrow + ((3 + d) * NT) * 1024);
+                        a1[d] = wload(wrow + ((3 + d) * NT) * 1024);
                 }
                 __builtin_amdgcn_sched_barrier(0);   // see kTapUnroll's comment
                 compute(dydz, 0, a0);
                 if (dydz < 8 && !SK_ABL(a, 32)) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
-                        a0[d] = *reinterpret_cast<const half8*>(wrow + ((6 + d) * NT) * 1024);
+                        a0[d] = wload(wrow + ((6 + d) * NT) * 1024);
                 }
                 __builtin_amdgcn_sched_barrier(0);   // see kTapUnroll's comment
                 compute(dydz, 1, a1);
@@ -421,7 +428,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             if (!(a.chinfo[nch] & 2)) issue_dma(nstep, nch, reuse_n, rot_n);   // bit 1: the next chunk multiplies the SAME staged planes
             if constexpr (RES == 0) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(nch) + (d * NT) * 1024);
+                for (int d = 0; d < 3; ++d) a0[d] = wload(wbase(nch) + (d * NT) * 1024);
             }
             // The DMA must have landed before this wave passes the closing barrier.  vmcnt retires in issue
             // order, so after an epilogue that issues a FIXED number of stores (invalid lanes / planes store to
@@ -771,7 +778,14 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
         }
     };
     // weight fragment index: (((ch*9 + dydz)*2 + ks)*3 + d)*NT + nt
-    auto wbase = [&](int ch) { return a.wpk + ((long long)ch * (9 * 2 * 3 * NT) + wn) * 1024 + lane * 16; };
+    // weight fragments through a buffer resource: wave-uniform byte offset in an SGPR + the constant lane * 16 in one VGPR
+    // (no 64-bit address arithmetic in the tap loop)
+    auto wbase = [&](int ch) { return (unsigned)((ch * (9 * 2 * 3 * NT) + wn) * 1024); };
+    const __amdgpu_buffer_rsrc_t wrsrc = sk::make_rsrc(a.wpk, (unsigned)(a.nchunks * (9 * 2 * 3 * NT) * 1024));
+    const unsigned wlane = lane * 16;
+    auto wload = [&](unsigned off) {
+        return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, __builtin_amdgcn_readfirstlane(off), 0));
+    };
 
     half8 a0[3], a1[3];
     half8 wres[RES > 0 ? 2 * RES : 1][3];
@@ -779,14 +793,14 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
 #pragma unroll
         for (int r = 0; r < 2 * RES; ++r)
 #pragma unroll
-            for (int d = 0; d < 3; ++d) wres[r][d] = *reinterpret_cast<const half8*>(wbase(0) + ((r * 3 + d) * NT) * 1024);
+            for (int d = 0; d < 3; ++d) wres[r][d] = wload(wbase(0) + ((r * 3 + d) * NT) * 1024);
     }
     if (tid < R * 4)
         *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
     issue_dma(0, ch0, false, 0);
     if constexpr (RES == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(ch0) + (d * NT) * 1024);
+        for (int d = 0; d < 3; ++d) a0[d] = wload(wbase(ch0) + (d * NT) * 1024);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!SPLIT) activate(0, ch0, false, 0);
@@ -807,7 +821,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
         }
         // ---------------- MFMA over the 27 taps of this chunk ---------------------------
         {
-            const char* wch = wbase(ch);
+            const unsigned wch = wbase(ch);
             int pslot[R];
 #pragma unroll
             for (int i = 0; i < R; ++i) pslot[i] = ((rot + i) % R) * plane_bytes;
@@ -883,29 +897,29 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                 load_row(0, bb[0]);
 #pragma unroll
                 for (int dydz = 0; dydz < 9; ++dydz) {
-                    const char* wrow = wch + (long long)(dydz * 2) * (3 * NT) * 1024;
+                    const unsigned wrow = wch + (unsigned)(dydz * 2) * (3 * NT) * 1024;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) a1[d] = *reinterpret_cast<const half8*>(wrow + ((3 + d) * NT) * 1024);
+                    for (int d = 0; d < 3; ++d) a1[d] = wload(wrow + ((3 + d) * NT) * 1024);
                     if (dydz < 8) load_row(dydz + 1, bb[(dydz + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
                     mma_row(0, a0, bb[dydz & 1]);
                     if (dydz < 8) {
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wrow + ((6 + d) * NT) * 1024);
+                        for (int d = 0; d < 3; ++d) a0[d] = wload(wrow + ((6 + d) * NT) * 1024);
                     }
                     mma_row(1, a1, bb[dydz & 1]);
                 }
             } else
 #pragma unroll kTapUnroll
             for (int dydz = 0; dydz < 9; ++dydz) {
-                const char* wrow = wch + (long long)((SK_ABL(a, 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
+                const unsigned wrow = wch + (unsigned)((SK_ABL(a, 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
                 if constexpr (RES > 0) {
                     if (dydz < RES) {
                         compute(dydz, 0, wres[2 * dydz]);
                         if (dydz == RES - 1) {  // first streamed row's ks = 0 fragments, one body ahead
 #pragma unroll
                             for (int d = 0; d < 3; ++d)
-                                a0[d] = *reinterpret_cast<const half8*>(wrow + ((6 + d) * NT) * 1024);
+                                a0[d] = wload(wrow + ((6 + d) * NT) * 1024);
                         }
                         compute(dydz, 1, wres[2 * dydz + 1]);
                         continue;
@@ -914,13 +928,13 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                 if (!SK_ABL(a, 32) || dydz == 0) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
-                        a1[d] = *reinterpret_cast<const half8*>(wrow + ((3 + d) * NT) * 1024);
+                        a1[d] = wload(wrow + ((3 + d) * NT) * 1024);
                 }
                 compute(dydz, 0, a0);
                 if (dydz < 8 && !SK_ABL(a, 32)) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
-                        a0[d] = *reinterpret_cast<const half8*>(wrow + ((6 + d) * NT) * 1024);
+                        a0[d] = wload(wrow + ((6 + d) * NT) * 1024);
                 }
                 compute(dydz, 1, a1);
             }
@@ -944,7 +958,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
             if (!(a.chinfo[nch] & 2)) issue_dma(nstep, nch, reuse_n, rot_n);   // bit 1: the next chunk multiplies the SAME staged planes
             if constexpr (RES == 0) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) a0[d] = *reinterpret_cast<const half8*>(wbase(nch) + (d * NT) * 1024);
+                for (int d = 0; d < 3; ++d) a0[d] = wload(wbase(nch) + (d * NT) * 1024);
             }
             // The DMA must have landed before this wave passes the closing barrier.  vmcnt retires in issue
             // order, so after an epilogue that issues a FIXED number of stores (invalid lanes / planes store to
@@ -1775,7 +1789,7 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
         }
         if (cout == 32) {   // 16x16x32 kernel
             if (p.xs == 3) return launch_conv3_m16<3>(a, p, stream);
-            if (a.nchunks == 1 && !a.ablate) return launch_conv3_m16<4, 2>(a, p, stream);
+            if (a.nchunks == 1 && !a.ablate) return launch_conv3_m16<4, 3>(a, p, stream);
             return launch_conv3_m16<4>(a, p, stream);
         }
         if (cout == 64) return p.xs == 3 ? launch_conv3<64, 3>(a, p, stream) : launch_conv3<64, 4>(a, p, stream);
