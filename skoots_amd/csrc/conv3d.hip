@@ -271,9 +271,9 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     // buffer-resource LDS-DMA and stores: 32-bit offsets into this batch item's tensors (one address VGPR instead of
     // two, 32-bit address arithmetic: -2 % time); an out-of-range offset reads zeros -- what the halo / padding lanes
     // want -- and drops a masked store
-    const __amdgpu_buffer_rsrc_t rsrc0 = sk::make_rsrc(a.src[0].data + (long long)b * a.src[0].batch, (unsigned)a.src[0].batch);
-    const __amdgpu_buffer_rsrc_t rsrc1 = sk::make_rsrc(a.src[1].data + (long long)b * a.src[1].batch, (unsigned)a.src[1].batch);
-    const __amdgpu_buffer_rsrc_t rout = sk::make_rsrc(outb, (unsigned)(a.Xt * out_plane));
+    // A descriptor covers only the x-planes of ONE step (built per phase from wave-uniform values: a few scalar
+    // instructions): a tensor of one batch item may exceed the 4 GiB a descriptor / a 32-bit offset can span
+    // (the split mode's 512x512x128 tile: 4.3 GB per 32-channel tensor).
     auto issue_dma = [&](int step, int ch, bool reuse, int rot_n) {
         const int x0 = xa + step * XS;
         const unsigned ci = a.chinfo[ch];
@@ -281,12 +281,15 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
         const SrcDev s = a.src[si];
         const int choff = ci >> 8;  // byte offset of the chunk in the voxel line
         const int first_new = reuse ? 2 : 0;  // planes 0,1 are the previous phase's planes XS, XS + 1
+        const int xlo = s.up ? (max(x0 - 1, 0) >> 1) : max(x0 - 1, 0);   // first source plane of the step
+        const long long wbytes = min((long long)(R + 1) * s.plane, s.batch - (long long)xlo * s.plane);
+        const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(s.data + (long long)b * s.batch + (long long)xlo * s.plane, (unsigned)wbytes);
         for (int i = SK_ABL(a, 1) ? R : first_new; i < R; ++i) {
             const int x = x0 - 1 + i;
             const int slotp = (rot_n + i) % R;
             const bool xok = x >= 0 && x < a.Xt;
             char* lbase = lds + slotp * plane_bytes;
-            const unsigned xoff = (unsigned)((s.up ? (x >> 1) : x) * (int)s.plane + choff);
+            const unsigned xoff = (unsigned)(((s.up ? (x >> 1) : x) - xlo) * (int)s.plane + choff);
             const unsigned vstride = (unsigned)(s.C * 2);
 #pragma unroll
             for (int k = 0; k < kMaxDma; ++k) {
@@ -294,10 +297,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                 if (t < ndma) {
                     const int vox = s.up ? d_up[k] : d_vox[k];
                     const unsigned voff = (xok && vox >= 0) ? xoff + (unsigned)vox * vstride + (unsigned)d_cs[k] : sk::kOob;
-                    if (si)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)(lbase + t * 1024), 16, voff, 0, 0, 0);
-                    else
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (__attribute__((address_space(3))) void*)(lbase + t * 1024), 16, voff, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lbase + t * 1024), 16, voff, 0, 0, 0);
                 }
             }
         }
@@ -447,6 +447,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
         // pad (16-B chunks XOR-swizzled) so that every lane stores 16 contiguous bytes and one
         // store instruction writes 1 KiB of whole 64-B voxel lines (4 lanes per line).
         if (step_done) {
+            char* outw = outb + (long long)x0 * out_plane;   // the step's XS output planes: one descriptor
+            const __amdgpu_buffer_rsrc_t rout = sk::make_rsrc(outw, (unsigned)(XS * out_plane));
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const long long tile_vox0 = out_vox0[p];  // in-plane index of the tile's first voxel
@@ -481,7 +483,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                                 // always issued (the counted wait relies on it); a masked lane's offset is out of range: dropped
                                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, line), rout,
-                                                                       sok ? (unsigned)(op + (long long)vv * kOvs + rc * 16 - outb) : sk::kOob, 0, 0);
+                                                                       sok ? (unsigned)(op + (long long)vv * kOvs + rc * 16 - outw) : sk::kOob, 0, 0);
                             }
                         }
                     }
@@ -703,9 +705,9 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     const int nphases = nsteps * a.nchunks;
 
     // buffer-resource LDS-DMA and stores (see conv3_kernel)
-    const __amdgpu_buffer_rsrc_t rsrc0 = sk::make_rsrc(a.src[0].data + (long long)b * a.src[0].batch, (unsigned)a.src[0].batch);
-    const __amdgpu_buffer_rsrc_t rsrc1 = sk::make_rsrc(a.src[1].data + (long long)b * a.src[1].batch, (unsigned)a.src[1].batch);
-    const __amdgpu_buffer_rsrc_t rout = sk::make_rsrc(outb, (unsigned)(a.Xt * out_plane));
+    // A descriptor covers only the x-planes of ONE step (built per phase from wave-uniform values: a few scalar
+    // instructions): a tensor of one batch item may exceed the 4 GiB a descriptor / a 32-bit offset can span
+    // (the split mode's 512x512x128 tile: 4.3 GB per 32-channel tensor).
     auto issue_dma = [&](int step, int ch, bool reuse, int rot_n) {
         const int x0 = xa + step * XS;
         const unsigned ci = a.chinfo[ch];
@@ -713,12 +715,15 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
         const SrcDev s = a.src[si];
         const int choff = ci >> 8;  // byte offset of the chunk in the voxel line
         const int first_new = reuse ? 2 : 0;  // planes 0,1 are the previous phase's planes XS, XS + 1
+        const int xlo = s.up ? (max(x0 - 1, 0) >> 1) : max(x0 - 1, 0);   // first source plane of the step
+        const long long wbytes = min((long long)(R + 1) * s.plane, s.batch - (long long)xlo * s.plane);
+        const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(s.data + (long long)b * s.batch + (long long)xlo * s.plane, (unsigned)wbytes);
         for (int i = SK_ABL(a, 1) ? R : first_new; i < R; ++i) {
             const int x = x0 - 1 + i;
             const int slotp = (rot_n + i) % R;
             const bool xok = x >= 0 && x < a.Xt;
             char* lbase = lds + slotp * plane_bytes;
-            const unsigned xoff = (unsigned)((s.up ? (x >> 1) : x) * (int)s.plane + choff + d_cs);
+            const unsigned xoff = (unsigned)(((s.up ? (x >> 1) : x) - xlo) * (int)s.plane + choff + d_cs);
             const unsigned vstride = (unsigned)(s.C * 2);
 #pragma unroll
             for (int k = 0; k < kMaxDma; ++k) {
@@ -726,10 +731,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                 if (t < ndma) {
                     const int vox = s.up ? d_up[k] : d_vox[k];
                     const unsigned voff = (xok && vox >= 0) ? xoff + (unsigned)vox * vstride : sk::kOob;
-                    if (si)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)(lbase + t * 1024), 16, voff, 0, 0, 0);
-                    else
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (__attribute__((address_space(3))) void*)(lbase + t * 1024), 16, voff, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lbase + t * 1024), 16, voff, 0, 0, 0);
                 }
             }
         }
@@ -977,6 +979,8 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
         // pad (16-B chunks XOR-swizzled) so that every lane stores 16 contiguous bytes and one
         // store instruction writes 1 KiB of whole 64-B voxel lines (4 lanes per line).
         if (step_done) {
+            char* outw = outb + (long long)x0 * out_plane;   // the step's XS output planes: one descriptor
+            const __amdgpu_buffer_rsrc_t rout = sk::make_rsrc(outw, (unsigned)(XS * out_plane));
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const int tile_vox0 = out_vox0[p];  // in-plane index of the tile's first voxel
@@ -1021,7 +1025,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                                 // always issued (the counted wait relies on it); a masked lane's offset is out of range: dropped
                                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                                 const u32x4 lv = {line.x, line.y, line.z, line.w};
-                                __builtin_amdgcn_raw_buffer_store_b128(lv, rout, sok ? (unsigned)(dst - outb) : sk::kOob, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(lv, rout, sok ? (unsigned)(dst - outw) : sk::kOob, 0, 0);
                             }
                         }
                     }
