@@ -18,13 +18,16 @@ typedef __bf16 t16;
 #define SK_MFMA_16x16x32_T16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
 #define SK_DS_READ_TR16_B64 __builtin_amdgcn_ds_read_tr16_b64_v4bf16
 #define SK_TR16_ELEM __bf16
+#define SK_DOT2_T16(a, b, c) __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false)
 #else
 typedef _Float16 t16;
 #define SK_MFMA_32x32x16_T16 __builtin_amdgcn_mfma_f32_32x32x16_f16
 #define SK_MFMA_16x16x32_T16 __builtin_amdgcn_mfma_f32_16x16x32_f16
 #define SK_DS_READ_TR16_B64 __builtin_amdgcn_ds_read_tr16_b64_v4f16
 #define SK_TR16_ELEM __fp16
+#define SK_DOT2_T16(a, b, c) __builtin_amdgcn_fdot2(a, b, c, false)
 #endif
+typedef t16 t16x2 __attribute__((ext_vector_type(2)));
 
 namespace sk {
 

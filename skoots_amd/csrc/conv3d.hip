@@ -467,9 +467,18 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                                 hv = half4{(t16)(v0 - (float)hv[0]), (t16)(v1 - (float)hv[1]),
                                            (t16)(v2 - (float)hv[2]), (t16)(v3 - (float)hv[3])};
                             *reinterpret_cast<half4*>(pad + col * kPadStride + ((q ^ ((col >> 1) & 3)) * 16) + 8 * h) = hv;
-                            if (ok && part == 0) {
-                                gsum[q] += (v0 + v1) + (v2 + v3);
-                                gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                            if (SPLIT) {
+                                if (ok && part == 0) {   // split: statistics of the fp32 accumulators
+                                    gsum[q] += (v0 + v1) + (v2 + v3);
+                                    gsq[q] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                                }
+                            } else {   // statistics of the stored 16-bit values on v_dot2c (see conv3_m16_kernel)
+                                const t16x2 z2 = {(t16)0.0f, (t16)0.0f}, one2 = {(t16)1.0f, (t16)1.0f};
+                                const t16x2 lo2 = ok ? t16x2{hv[0], hv[1]} : z2, hi2 = ok ? t16x2{hv[2], hv[3]} : z2;
+                                gsum[q] = SK_DOT2_T16(lo2, one2, gsum[q]);
+                                gsum[q] = SK_DOT2_T16(hi2, one2, gsum[q]);
+                                gsq[q] = SK_DOT2_T16(lo2, lo2, gsq[q]);
+                                gsq[q] = SK_DOT2_T16(hi2, hi2, gsq[q]);
                             }
                         }
                         if (!SK_ABL(a, 4)) {
@@ -1008,9 +1017,22 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                                 const uint2 u = __builtin_bit_cast(uint2, hv);
                                 d[j][0] = u.x;
                                 d[j][1] = u.y;
-                                if (part == 0 && vvalid(p, j) && x < xb) {
-                                    gsum[i] += (r[0] + r[1]) + (r[2] + r[3]);
-                                    gsq[i] += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+                                if (SPLIT) {
+                                    if (part == 0 && vvalid(p, j) && x < xb) {   // split: statistics of the fp32 accumulators
+                                        gsum[i] += (r[0] + r[1]) + (r[2] + r[3]);
+                                        gsq[i] += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+                                    }
+                                } else {
+                                    // statistics of the values as STORED (16-bit), on v_dot2c: exact products, fp32 sums,
+                                    // 4 instructions per 4 values instead of 4 multiplies + 7 adds; a voxel outside the
+                                    // tile contributes zeros
+                                    const bool in = vvalid(p, j) && x < xb;
+                                    const t16x2 z2 = {(t16)0.0f, (t16)0.0f}, one2 = {(t16)1.0f, (t16)1.0f};
+                                    const t16x2 lo2 = in ? t16x2{hv[0], hv[1]} : z2, hi2 = in ? t16x2{hv[2], hv[3]} : z2;
+                                    gsum[i] = SK_DOT2_T16(lo2, one2, gsum[i]);
+                                    gsum[i] = SK_DOT2_T16(hi2, one2, gsum[i]);
+                                    gsq[i] = SK_DOT2_T16(lo2, lo2, gsq[i]);
+                                    gsq[i] = SK_DOT2_T16(hi2, hi2, gsq[i]);
                                 }
                             }
                             const auto s0 = __builtin_amdgcn_permlane16_swap(d[0][0], d[1][0], false, false);
