@@ -206,6 +206,23 @@ int sk_conv3d_down_act(void* in_raw, const float* affine, const void* weight, co
                        int B, int ox, int oy, int oz, int cin, int cout, float* gn_partial,
                        void* zero_page, void* stream);
 
+/* Decoder conv over cat([skip, nearest-upsample x2 (up)]) with the upsample FOLDED INTO THE WEIGHTS of the upsampled
+ * channels (csrc/conv3d_up.hip): 3x3x3, stride 1, zero pad 1, the same function as sk_conv3d(ksize 3) with sources
+ * {skip, up (upsample = 1)} -- the first conv of each decoder level (oracle/unet_spec.py; skoots/lib/utils.py:17-107)
+ * -- at 8 instead of 27 tap-chunks for the upsampled channels: an output voxel of parity p along an axis reads
+ * U[x-1], U[x], U[x+1] = two distinct voxels of the low-resolution tensor, so per parity class (px, py, pz) the 27 taps
+ * collapse to 2x2x2 taps whose weights are sums of the kernel's (formed on the host in fp32, rounded to fp16 once:
+ * results agree with sk_conv3d to the fp16 rounding of those sums, exactly on integer-valued weights).
+ * skip (B, ox, oy, oz, c_skip), up (B, ox/2, oy/2, oz/2, c_up): fp16, ACTIVATED; weight: sk_conv3d_pack_weight_upfold_host;
+ * out (B, ox, oy, oz, cout) fp16 raw; gn_partial (B, sk_conv3d_upfold_num_blocks, cout/4, 2) or NULL.  cout = 32.
+ * sk_conv3d_upfold_num_blocks < 0: the geometry is not covered (ox % 4, odd oy / oz, oz/2 > 32) -- use sk_conv3d. */
+int sk_conv3d_upfold(const void* skip, int c_skip, const void* up, int c_up, const void* weight,
+                     const float* bias, void* out, int B, int ox, int oy, int oz, int cout,
+                     float* gn_partial, void* stream);
+int sk_conv3d_upfold_num_blocks(int ox, int oy, int oz, int cout);
+/* HOST: torch-layout weight (cout, c_skip + c_up, 3, 3, 3) fp32 -> fragments of sk_conv3d_upfold.  Bytes needed / written. */
+int64_t sk_conv3d_pack_weight_upfold_host(const float* w_host, int cout, int c_skip, int c_up, void* dst_host);
+
 /* Rows of gn_partial per batch item that sk_conv3d writes for this output shape. */
 int sk_conv3d_num_blocks(int B, int ox, int oy, int oz, int cout, int ksize);
 

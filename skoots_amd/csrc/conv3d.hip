@@ -156,8 +156,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     const int pitch = a.pitch;
     int off, ybase, zbase;      // region position q -> (y, z): Pq = q + off; y = ybase + Pq/pitch; z = zbase + Pq%pitch
     int q_row[P];               // region position of this lane's voxel in column tile p
-    long long out_vox0[P];      // in-plane voxel index of column 0 of tile p (the 32 columns are contiguous)
-    long long tile_nvox[P];     // columns with out_vox0 + c < tile_nvox are inside the tile
+    int out_vox0[P];            // in-plane voxel index of column 0 of tile p (the 32 columns are contiguous)
+    int tile_nvox[P];           // columns with out_vox0 + c < tile_nvox are inside the tile
     bool vvalid[P];
     bool zlo[P], zhi[P];        // linear mode: this lane's voxel sits on the z = 0 / z = Zt-1 face
     if (a.mode == 0) {
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             zhi[p] = vz == a.Zt - 1;
             q_row[p] = v - off;
             out_vox0[p] = v0 + 32 * (wm * P + p);
-            tile_nvox[p] = (long long)a.Yt * a.Zt;
+            tile_nvox[p] = a.Yt * a.Zt;
         }
     } else {
         const int TY = kPatch / a.TZ;
@@ -199,14 +199,17 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             q_row[p] = (yl + 1) * pitch + (zl + 1);
             // a column tile is one 32-voxel z segment of one line (TZ == 32)
             const int ty = y0 + (32 * (wm * P + p)) / a.TZ;
-            out_vox0[p] = (long long)ty * a.Zt + zc0;
-            tile_nvox[p] = ty < a.Yt ? (long long)ty * a.Zt + a.Zt : 0;
+            out_vox0[p] = ty * a.Zt + zc0;
+            tile_nvox[p] = ty < a.Yt ? ty * a.Zt + a.Zt : 0;
         }
     }
 
     // ---- DMA bookkeeping: this lane's slots of a plane --------------------------------
     const int ndma = a.nposp / 16;  // wave-instructions per plane
-    int d_vox[kMaxDma], d_up[kMaxDma], d_cs[kMaxDma];
+    int d_vox[kMaxDma], d_up[kMaxDma];
+    // source 16-byte chunk (swizzle on the SOURCE side): slot c of position q holds chunk c ^ ((q >> 2) & 3); q >> 2 =
+    // 4 t + (lane >> 4), so the term is the same for every DMA instruction t of this lane
+    const int d_cs = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
 #pragma unroll
     for (int k = 0; k < kMaxDma; ++k) {
         int t = w + 4 * k;
@@ -217,7 +220,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
         bool ok = (t < ndma) && y >= 0 && y < a.Yt && z >= 0 && z < a.Zt;
         d_vox[k] = ok ? y * a.Zt + z : -1;
         d_up[k] = ok ? (y >> 1) * a.src[1].Zs + (z >> 1) : -1;
-        d_cs[k] = (c ^ ((q >> 2) & 3)) * 16;  // source 16-byte chunk (swizzle on the SOURCE side)
+        (void)c;
     }
 
     // ---- accumulators + GroupNorm partials ----------------------------------------------
@@ -247,16 +250,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     const long long out_plane = (long long)a.Yt * a.Zt * kOvs;
     char* outb = a.out + (long long)b * a.Xt * out_plane;
 
-    // bias as the initial accumulator: row (cout) = 32*wn + (r&3) + 8(r>>2) + 4h
-    f32x16 binit;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + 32 * wn + 8 * q + 4 * h);
-        binit[4 * q + 0] = bv[0];
-        binit[4 * q + 1] = bv[1];
-        binit[4 * q + 2] = bv[2];
-        binit[4 * q + 3] = bv[3];
-    }
+    // bias is the initial accumulator: row (cout) = 32*wn + (r&3) + 8(r>>2) + 4h (re-read per step: 16 registers less in the loop)
+    const float* biasp = a.bias + 32 * wn + 4 * h;
 
     // ---- phase sequence ---------------------------------------------------------------------
     // A phase = (step, chunk): 27 taps of one 32-channel chunk for the XS output planes of a step.
@@ -289,14 +284,14 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             const int slotp = (rot_n + i) % R;
             const bool xok = x >= 0 && x < a.Xt;
             char* lbase = lds + slotp * plane_bytes;
-            const unsigned xoff = (unsigned)(((s.up ? (x >> 1) : x) - xlo) * (int)s.plane + choff);
+            const unsigned xoff = (unsigned)(((s.up ? (x >> 1) : x) - xlo) * (int)s.plane + choff + d_cs);
             const unsigned vstride = (unsigned)(s.C * 2);
 #pragma unroll
             for (int k = 0; k < kMaxDma; ++k) {
                 const int t = w + 4 * k;
                 if (t < ndma) {
                     const int vox = s.up ? d_up[k] : d_vox[k];
-                    const unsigned voff = (xok && vox >= 0) ? xoff + (unsigned)vox * vstride + (unsigned)d_cs[k] : sk::kOob;
+                    const unsigned voff = (xok && vox >= 0) ? xoff + (unsigned)vox * vstride : sk::kOob;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lbase + t * 1024), 16, voff, 0, 0, 0);
                 }
             }
@@ -335,6 +330,15 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     for (int ph = 0; ph < nphases; ++ph) {
         const int x0 = xa + step * XS;
         if (k == 0) {
+            f32x16 binit;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(biasp + 8 * q);
+                binit[4 * q + 0] = bv[0];
+                binit[4 * q + 1] = bv[1];
+                binit[4 * q + 2] = bv[2];
+                binit[4 * q + 3] = bv[3];
+            }
 #pragma unroll
             for (int p = 0; p < P; ++p)
 #pragma unroll
@@ -378,6 +382,75 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             // (24 MFMAs) ahead -- -3.7 % time on COUT 64 and 128 (tools/kernel_ab.sh, round 2); the 16x16x32 kernel
             // below loses 4 % with the same barrier and keeps the free schedule.
             constexpr int kTapUnroll = (NT <= 2) ? 9 : 1;
+            if constexpr (NT == 4) {
+            // COUT 128 (measured: -6 % on the 128 -> 128 layers, nothing on COUT 64, tools/layer_ab.py) -- B fragments one body ahead: a body = (dydz, ks, p) = R fragments (one per staged plane) feeding 3 XS MFMAs.
+            // The compiler's own schedule requests a fragment one or two MFMAs before its first use (`ds_read ;
+            // s_waitcnt lgkmcnt(1) ; v_mfma` all along the tap loop): a wave that has the SIMD to itself then waits out
+            // most of every LDS latency.  Here body n + 1's fragments are requested before body n's MFMAs.
+            half8 bq[2][R];
+            auto bload = [&](int dydz, int ks, int p, half8 (&dst)[R]) {
+                const int dz = dydz % 3 - 1;
+                const int tapoff = (dydz / 3 - 1) * pitch + dz;
+                const int q = q_row[p] + tapoff;
+                int addr = (q * 4 + ((ks * 2 + h) ^ ((q >> 2) & 3))) * 16;
+                if (dz < 0) addr = zlo[p] ? zero_addr : addr;
+                if (dz > 0) addr = zhi[p] ? zero_addr : addr;
+#pragma unroll
+                for (int i = 0; i < R; ++i) dst[i] = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
+            };
+            auto bmma = [&](int p, const half8 (&afr)[3], const half8 (&src)[R]) {
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const int o = i - d;  // x_in = x_out + (d - 1)
+                        if (o >= 0 && o < XS) acc[p][o] = SK_MFMA_32x32x16_T16(afr[d], src[i], acc[p][o], 0, 0, 0);
+                    }
+            };
+            bload(0, 0, 0, bq[0]);
+#pragma unroll kTapUnroll
+            for (int dydz = 0; dydz < 9; ++dydz) {
+                const unsigned wrow = wch + (unsigned)(dydz * 2) * (3 * NT) * 1024;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) a1[d] = wload(wrow + ((3 + d) * NT) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const int n = ks * P + p;   // a row has 2 P bodies: the buffer of a body is a compile-time index
+                        int nd = dydz, nks = ks, np = p + 1;
+                        if (np == P) {
+                            np = 0;
+                            ++nks;
+                        }
+                        if (nks == 2) {
+                            nks = 0;
+                            ++nd;
+                        }
+                        if (nd < 9) bload(nd, nks, np, bq[(n + 1) & 1]);
+                        // one LDS read of the next body per MFMA gap of this one, the rest of the MFMAs behind them
+                        // (all R reads in one burst ahead of the MFMAs: +2 % instead)
+#pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3 * XS - R, 0);
+                        if (ks == 0)
+                            bmma(p, a0, bq[n & 1]);
+                        else
+                            bmma(p, a1, bq[n & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (ks == 0 && dydz < 8) {
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) a0[d] = wload(wrow + ((6 + d) * NT) * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            } else
 #pragma unroll kTapUnroll
             for (int dydz = 0; dydz < 9; ++dydz) {
                 const unsigned wrow = wch + (unsigned)((SK_ABL(a, 2) ? 0 : dydz) * 2) * (3 * NT) * 1024;
@@ -451,7 +524,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             const __amdgpu_buffer_rsrc_t rout = sk::make_rsrc(outw, (unsigned)(XS * out_plane));
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const long long tile_vox0 = out_vox0[p];  // in-plane index of the tile's first voxel
+                const int tile_vox0 = out_vox0[p];  // in-plane index of the tile's first voxel
 #pragma unroll
                 for (int o = 0; o < XS; ++o) {
                     const int x = x0 + o;
@@ -482,7 +555,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                             }
                         }
                         if (!SK_ABL(a, 4)) {
-                            char* op = outb + (long long)x * out_plane + tile_vox0 * kOvs + wn * 64 + part * (COUT * 2);
+                            char* op = outb + (long long)x * out_plane + (long long)tile_vox0 * kOvs + wn * 64 + part * (COUT * 2);
 #pragma unroll
                             for (int hh = 0; hh < 2; ++hh) {
                                 const int vv = rv + 16 * hh;

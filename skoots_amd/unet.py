@@ -65,6 +65,22 @@ class _ConvLayer:
     def weight(self) -> Tensor:
         return self.packed(False)
 
+    def packed_upfold(self, c_skip: int) -> Tensor:
+        """Fragments of ``sk_conv3d_upfold`` (decoder conv, the nearest-upsample of the last ``cin - c_skip`` input
+        channels folded into their weights); packed on first use."""
+        key = ("upfold", c_skip)
+        t = self._packed.get(key)
+        if t is None:
+            fn = _ffi.lib.sk_conv3d_pack_weight_upfold_host
+            fpt = self._w_cpu.numpy().ctypes.data_as(C.POINTER(C.c_float))
+            nbytes = fn(fpt, self.cout, c_skip, self.cin - c_skip, None)
+            if nbytes < 0:
+                _ffi.check(int(nbytes))
+            buf = np.empty(nbytes, dtype=np.uint8)
+            fn(fpt, self.cout, c_skip, self.cin - c_skip, buf.ctypes.data_as(C.c_void_p))
+            t = self._packed[key] = torch.from_numpy(buf).to(self._device)
+        return t
+
 
 class ConvProfile:
     """HIP-event timing of every 3x3x3 MFMA conv launch (the dominant kernel), recorded on
@@ -130,6 +146,7 @@ class HipUNet:
         self.last_features: Dict[str, Tensor] = {}
         self.profile: Optional[ConvProfile] = None
         self.defer_activation = True  # single-consumer tensors stay RAW and are activated on load (tools/ A/B switch)
+        self.fold_upsample = True     # decoder convs: nearest-upsample folded into the weights (sk_conv3d_upfold; tools/ A/B switch)
 
     @property
     def split(self) -> bool:
@@ -188,10 +205,6 @@ class HipUNet:
         split = self.split
         lanes = 2 if split else 1   # split tensors hold [hi | lo] per voxel: twice the channels
         out = self._buf(tag, (B, ox, oy, oz, layer.cout * lanes))
-        nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, layer.cout, layer.ksize)
-        if nblk <= 0:
-            raise ValueError(f"{layer.name}: unsupported output shape {out_shape}")
-        partial = self._buf("partial", (B * nblk * (layer.cout // 4) * 2,), torch.float32)
         arr = (_ffi.ConvSrc * len(srcs))()
         cin = 0
         for i, src in enumerate(srcs):
@@ -202,14 +215,30 @@ class HipUNet:
             arr[i].upsample = up
             cin += t.shape[-1] // lanes
         assert cin == layer.cin, (layer.name, cin, layer.cin)
+        # decoder conv over cat([skip, upsample(x)]): the folded kernel where it covers the shape (fp16 mode, both
+        # sources activated); it has its own workgroup count, hence its own number of partial-sum rows
+        fold = (self.fold_upsample and not split and layer.ksize == 3 and len(srcs) == 2 and bool(srcs[1][1])
+                and not srcs[0][1] and arr[0].affine is None and arr[1].affine is None)
+        nblk = _ffi.lib.sk_conv3d_upfold_num_blocks(ox, oy, oz, layer.cout) if fold else -1
+        fold = nblk > 0
+        if not fold:
+            nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, layer.cout, layer.ksize)
+        if nblk <= 0:
+            raise ValueError(f"{layer.name}: unsupported output shape {out_shape}")
+        partial = self._buf("partial", (B * nblk * (layer.cout // 4) * 2,), torch.float32)
         timed = self.profile is not None and layer.ksize == 3
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
-        fn = _ffi.lib.sk_conv3d_split if split else _ffi.lib.sk_conv3d
-        _ffi.check(fn(arr, len(srcs), _ffi.ptr(layer.packed(split)), _ffi.ptr(layer.bias),
-                      _ffi.ptr(out), B, ox, oy, oz, layer.cout, layer.ksize,
-                      _ffi.ptr(partial), _ffi.ptr(self.zeros), _ffi.stream_ptr(self.device)))
+        if fold:
+            _ffi.check(_ffi.lib.sk_conv3d_upfold(arr[0].data, arr[0].c, arr[1].data, arr[1].c,
+                                                 _ffi.ptr(layer.packed_upfold(arr[0].c)), _ffi.ptr(layer.bias), _ffi.ptr(out),
+                                                 B, ox, oy, oz, layer.cout, _ffi.ptr(partial), _ffi.stream_ptr(self.device)))
+        else:
+            fn = _ffi.lib.sk_conv3d_split if split else _ffi.lib.sk_conv3d
+            _ffi.check(fn(arr, len(srcs), _ffi.ptr(layer.packed(split)), _ffi.ptr(layer.bias),
+                          _ffi.ptr(out), B, ox, oy, oz, layer.cout, layer.ksize,
+                          _ffi.ptr(partial), _ffi.ptr(self.zeros), _ffi.stream_ptr(self.device)))
         if timed:
             e1.record(torch.cuda.current_stream(self.device))
             self.profile.events.append((e0, e1, layer.flops_per_out_voxel * B * ox * oy * oz, layer.name))
@@ -552,6 +581,39 @@ def conv3d(srcs: List[Tuple[Tensor, int]], packed_weight: Tensor, bias: Tensor, 
     fn = _ffi.lib.sk_conv3d_split if split else _ffi.lib.sk_conv3d
     _ffi.check(fn(arr, len(srcs), _ffi.ptr(packed_weight), _ffi.ptr(bias), _ffi.ptr(out), B,
                   ox, oy, oz, cout, ksize, _ffi.ptr(partial), _ffi.ptr(zeros), _ffi.stream_ptr(dev)))
+    return out, partial
+
+
+def pack_conv_weight_upfold(weight: Tensor, c_skip: int, device) -> Tensor:
+    """Torch-layout (cout, c_skip + c_up, 3, 3, 3) fp32 weight -> the fragments of ``sk_conv3d_upfold`` on ``device``."""
+    w = weight.detach().float().cpu().contiguous()
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    fn = _ffi.lib.sk_conv3d_pack_weight_upfold_host
+    fpt = w.numpy().ctypes.data_as(C.POINTER(C.c_float))
+    nbytes = fn(fpt, cout, c_skip, cin - c_skip, None)
+    if nbytes < 0:
+        _ffi.check(int(nbytes))
+    buf = np.empty(nbytes, dtype=np.uint8)
+    fn(fpt, cout, c_skip, cin - c_skip, buf.ctypes.data_as(C.c_void_p))
+    return torch.from_numpy(buf).to(device)
+
+
+def conv3d_upfold(skip: Tensor, up: Tensor, packed_weight: Tensor, bias: Tensor, cout: int, want_stats: bool = True):
+    """Raw decoder conv over cat([skip, nearest-upsample(up)]) with the upsample folded into the weights:
+    skip (B, x, y, z, c) fp16, up (B, x/2, y/2, z/2, c') fp16 -> ((B, x, y, z, cout) fp16, gn_partial or None)."""
+    _ffi.require_gpu(skip, "skip")
+    _ffi.require_gpu(up, "up")
+    B, ox, oy, oz = (int(v) for v in skip.shape[:4])
+    if tuple(up.shape[:4]) != (B, ox // 2, oy // 2, oz // 2):
+        raise ValueError(f"up {tuple(up.shape)} is not half of skip {tuple(skip.shape)}")
+    nblk = _ffi.lib.sk_conv3d_upfold_num_blocks(ox, oy, oz, cout)
+    if nblk <= 0:
+        raise ValueError(f"sk_conv3d_upfold does not cover the output shape {(ox, oy, oz)} / cout {cout}")
+    out = torch.empty((B, ox, oy, oz, cout), dtype=torch.float16, device=skip.device)
+    partial = torch.zeros((B, nblk, cout // 4, 2), dtype=torch.float32, device=skip.device) if want_stats else None
+    _ffi.check(_ffi.lib.sk_conv3d_upfold(_ffi.ptr(skip), skip.shape[-1], _ffi.ptr(up), up.shape[-1], _ffi.ptr(packed_weight),
+                                         _ffi.ptr(bias), _ffi.ptr(out), B, ox, oy, oz, cout, _ffi.ptr(partial),
+                                         _ffi.stream_ptr(skip.device)))
     return out, partial
 
 

@@ -22,11 +22,13 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-fold", action="store_true", help="decoder convs on the direct kernel (sk_conv3d) instead of sk_conv3d_upfold")
     args = ap.parse_args()
     from skoots_amd import unet
     dev = torch.device("cuda", 0)
     tile = tuple(int(v) for v in args.tile.split(","))
     model = unet.smoke_model(dev)
+    model.fold_upsample = not args.no_fold
     g = torch.Generator(device=dev).manual_seed(0)
     vol = torch.randint(0, 256, (tile[0], tile[1], tile[2] + args.batch - 1), generator=g, device=dev,
                         dtype=torch.uint8).to(torch.float16)

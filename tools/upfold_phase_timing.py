@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Where do the cycles of a folded decoder conv workgroup go (csrc/conv3d_up.hip)?  -DSK_TIMING build
+(make -C skoots_amd/csrc timing): per wave, cycles between the marks of a step's phases, mean over 4096 workgroups.
+
+    SKOOTS_HIP_LIB=skoots_amd/libskoots_hip_timing.so python tools/upfold_phase_timing.py
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+NAMES = ["skip_mfma", "barrier", "dma_low_issue", "landing_wait", "barrier", "up_mfma", "barrier", "dma_fine_issue",
+         "epilogue", "landing_wait2", "closing_barrier"]
+
+
+def main():
+    from skoots_amd import unet
+    dev = torch.device("cuda", 0)
+    B, ext = 8, (300, 300, 20)
+    dbg = torch.zeros((4096, 4, 16), dtype=torch.int64, device=dev)
+    os.environ["SK_CONV_DBG"] = hex(dbg.data_ptr())
+    g = torch.Generator(device=dev).manual_seed(1)
+    skip = torch.randn((B,) + ext + (32,), generator=g, device=dev).half()
+    up = torch.randn((B,) + tuple(e // 2 for e in ext) + (32,), generator=g, device=dev).half()
+    w = torch.randn((32, 64, 3, 3, 3)) / (64 * 27) ** 0.5
+    wp = unet.pack_conv_weight_upfold(w, 32, dev)
+    bias = torch.zeros(32, device=dev)
+    for _ in range(2):
+        dbg.zero_()
+        unet.conv3d_upfold(skip, up, wp, bias, 32)
+        torch.cuda.synchronize()
+    d = dbg.double()
+    used = d.sum(dim=(1, 2)) > 0
+    m = d[used].mean(dim=(0, 1))
+    tot = m.sum().item()
+    print(json.dumps({"cycles_per_wave": round(tot), **{f"{i}_{n}": round(v / tot, 4) for i, (n, v) in enumerate(zip(NAMES, m.tolist()))}}))
+
+
+if __name__ == "__main__":
+    main()
