@@ -214,8 +214,9 @@ int sk_conv3d_down_act(void* in_raw, const float* affine, const void* weight, co
  * collapse to 2x2x2 taps whose weights are sums of the kernel's (formed on the host in fp32, rounded to fp16 once:
  * results agree with sk_conv3d to the fp16 rounding of those sums, exactly on integer-valued weights).
  * skip (B, ox, oy, oz, c_skip), up (B, ox/2, oy/2, oz/2, c_up): fp16, ACTIVATED; weight: sk_conv3d_pack_weight_upfold_host;
- * out (B, ox, oy, oz, cout) fp16 raw; gn_partial (B, sk_conv3d_upfold_num_blocks, cout/4, 2) or NULL.  cout = 32.
- * sk_conv3d_upfold_num_blocks < 0: the geometry is not covered (ox % 4, odd oy / oz, oz/2 > 32) -- use sk_conv3d. */
+ * out (B, ox, oy, oz, cout) fp16 raw; gn_partial (B, sk_conv3d_upfold_num_blocks, cout/4, 2) or NULL.  cout = 32 | 64
+ * (64: two launches of 32 output channels each).
+ * sk_conv3d_upfold_num_blocks < 0: the geometry is not covered (an odd extent, oz/2 > 24) -- use sk_conv3d. */
 int sk_conv3d_upfold(const void* skip, int c_skip, const void* up, int c_up, const void* weight,
                      const float* bias, void* out, int B, int ox, int oy, int oz, int cout,
                      float* gn_partial, void* stream);

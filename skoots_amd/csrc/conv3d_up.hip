@@ -59,6 +59,8 @@ struct UpfArgs {
     int XC, nxc, npatch;
     int K;                       // low-resolution rows per workgroup
     int SUBP, nposp, nposl;      // positions per fine sub-plane / fine plane / low-resolution plane
+    int out_vs, cout_off;        // bytes per output voxel line; first output channel of this launch (a launch computes 32)
+    int pstride, poff;           // floats per gn_partial row (cout/4 * 2); offset of this launch's 16 in it
     long long* dbg;              // -DSK_TIMING builds: per-wave phase cycle sums (tools/upfold_phase_timing.py)
 };
 
@@ -165,9 +167,9 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
     const int Xl = a.Xt >> 1;
     const int plane_bytes = (a.nposp + 1) * kPosBytes;
     const int zero_addr = a.nposp * kPosBytes;   // never written by either image's DMA (nposl <= nposp)
-    const long long out_plane = (long long)a.Yt * Zt * 64;
+    const long long out_plane = (long long)a.Yt * Zt * a.out_vs;
     char* outb = a.out + (long long)b * a.Xt * out_plane;
-    const float* biasp = a.bias + 4 * g;
+    const float* biasp = a.bias + a.cout_off + 4 * g;
 
     const int nsteps = (xb - xa + XS - 1) / XS;
 
@@ -438,7 +440,7 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
                         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                         const u32x4 lv = {s0[0], s1[0], s0[1], s1[1]};
                         const bool sok = x < xb && ovox >= 0;
-                        const unsigned off = (unsigned)(o * (int)out_plane + ovox * 64 + 32 * i + 16 * (g >> 1));
+                        const unsigned off = (unsigned)(o * (int)out_plane + ovox * a.out_vs + a.cout_off * 2 + 32 * i + 16 * (g >> 1));
                         // always issued (the counted wait below relies on it); a masked lane's offset is out of range: dropped
                         __builtin_amdgcn_raw_buffer_store_b128(lv, rout, sok ? off : sk::kOob, 0, 0);
                     }
@@ -481,7 +483,7 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
             float t = 0.0f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) t += red[q * 16 + tid];
-            a.partial[((long long)b * nblk + block_in_batch) * 16 + tid] = t;
+            a.partial[((long long)b * nblk + block_in_batch) * a.pstride + a.poff + tid] = t;
         }
     }
 }
@@ -493,7 +495,7 @@ struct UpfPlan {
 
 // 0: supported.  The folded kernel covers the geometries whose low-resolution rows fit a 32-column segment.
 int make_upf_plan(UpfPlan& p, int Xt, int Yt, int Zt) {
-    if (Xt % 4 || Yt % 2 || Zt % 2) return -1;
+    if (Xt % 2 || Yt % 2 || Zt % 2) return -1;
     const int Zl = Zt / 2, Yl = Yt / 2;
     if (Zl < 1 || Zl > 32) return -1;
     p.K = 32 / Zl;
@@ -525,50 +527,54 @@ extern "C" {
 
 int sk_conv3d_upfold_num_blocks(int ox, int oy, int oz, int cout) {
     UpfPlan p;
-    if (cout != 32 || make_upf_plan(p, ox, oy, oz)) return -1;
+    if ((cout != 32 && cout != 64) || make_upf_plan(p, ox, oy, oz)) return -1;
     return p.npatch * p.nxc;
 }
 
 int64_t sk_conv3d_pack_weight_upfold_host(const float* w, int cout, int c_skip, int c_up, void* dst) {
-    if (cout != 32 || c_skip <= 0 || c_up <= 0 || c_skip % 32 || c_up % 32) {
+    if ((cout != 32 && cout != 64) || c_skip <= 0 || c_up <= 0 || c_skip % 32 || c_up % 32) {
         sk::set_error("sk_conv3d_pack_weight_upfold_host: unsupported shape cout=%d c_skip=%d c_up=%d", cout, c_skip, c_up);
         return SK_ERR_ARG;
     }
     const int ns = c_skip / 32, nu = c_up / 32, cin = c_skip + c_up;
-    const int64_t nfrag = (int64_t)ns * kSkipFrags + (int64_t)nu * kUpFrags;
+    const int64_t nfrag = ((int64_t)ns * kSkipFrags + (int64_t)nu * kUpFrags) * (cout / 32);
     if (!dst) return nfrag * 1024;
     t16* out = (t16*)dst;
     auto W = [&](int co, int ci, int kx, int ky, int kz) { return w[((((int64_t)co * cin + ci) * 3 + kx) * 3 + ky) * 3 + kz]; };
     int64_t f = 0;
-    // skip chunks: conv3_m16_kernel's order [chunk][dy*3+dz][cout half][dx]; lane l holds W[16 i + (l&15)][c0 + 8 (l>>4) + e]
-    for (int ch = 0; ch < ns; ++ch)
-        for (int dydz = 0; dydz < 9; ++dydz)
-            for (int i = 0; i < 2; ++i)
-                for (int dx = 0; dx < 3; ++dx, ++f)
-                    for (int l = 0; l < 64; ++l)
-                        for (int e = 0; e < 8; ++e)
-                            out[f * 512 + l * 8 + e] = (t16)W(16 * i + (l & 15), ch * 32 + 8 * (l >> 4) + e, dx, dydz / 3, dydz % 3);
-    // upsampled chunks: [chunk][class 2 py + pz][ty*2+tz][cout half][px][tx]; the folded weight of parity p, tap t along an
-    // axis sums the kernel taps k (0..2) that read the same low-resolution voxel: p=0: t=0 {0}, t=1 {1,2}; p=1: t=0 {0,1}, t=1 {2}
+    // the folded weight of parity p, tap t along an axis sums the kernel taps k (0..2) that read the same low-resolution
+    // voxel: p=0: t=0 {0}, t=1 {1,2}; p=1: t=0 {0,1}, t=1 {2}
     auto lo = [](int p, int t) { return p == 0 ? (t == 0 ? 0 : 1) : (t == 0 ? 0 : 2); };
     auto hi = [](int p, int t) { return p == 0 ? (t == 0 ? 0 : 2) : (t == 0 ? 1 : 2); };
-    for (int ch = 0; ch < nu; ++ch)
-        for (int cls = 0; cls < 4; ++cls)
-            for (int tytz = 0; tytz < 4; ++tytz)
+    for (int cg = 0; cg < cout / 32; ++cg) {   // one fragment set per 32 output channels (= per launch of the kernel)
+        // skip chunks: conv3_m16_kernel's order [chunk][dy*3+dz][cout half][dx]; lane l holds W[16 i + (l&15)][c0 + 8 (l>>4) + e]
+        for (int ch = 0; ch < ns; ++ch)
+            for (int dydz = 0; dydz < 9; ++dydz)
                 for (int i = 0; i < 2; ++i)
-                    for (int px = 0; px < 2; ++px)
-                        for (int tx = 0; tx < 2; ++tx, ++f) {
-                            const int py = cls >> 1, pz = cls & 1, ty = tytz >> 1, tz = tytz & 1;
-                            for (int l = 0; l < 64; ++l)
-                                for (int e = 0; e < 8; ++e) {
-                                    const int co = 16 * i + (l & 15), ci = c_skip + ch * 32 + 8 * (l >> 4) + e;
-                                    float s = 0.0f;
-                                    for (int kx = lo(px, tx); kx <= hi(px, tx); ++kx)
-                                        for (int ky = lo(py, ty); ky <= hi(py, ty); ++ky)
-                                            for (int kz = lo(pz, tz); kz <= hi(pz, tz); ++kz) s += W(co, ci, kx, ky, kz);
-                                    out[f * 512 + l * 8 + e] = (t16)s;
-                                }
-                        }
+                    for (int dx = 0; dx < 3; ++dx, ++f)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e)
+                                out[f * 512 + l * 8 + e] =
+                                    (t16)W(32 * cg + 16 * i + (l & 15), ch * 32 + 8 * (l >> 4) + e, dx, dydz / 3, dydz % 3);
+        // upsampled chunks: [chunk][class 2 py + pz][ty*2+tz][cout half][px][tx]
+        for (int ch = 0; ch < nu; ++ch)
+            for (int cls = 0; cls < 4; ++cls)
+                for (int tytz = 0; tytz < 4; ++tytz)
+                    for (int i = 0; i < 2; ++i)
+                        for (int px = 0; px < 2; ++px)
+                            for (int tx = 0; tx < 2; ++tx, ++f) {
+                                const int py = cls >> 1, pz = cls & 1, ty = tytz >> 1, tz = tytz & 1;
+                                for (int l = 0; l < 64; ++l)
+                                    for (int e = 0; e < 8; ++e) {
+                                        const int co = 32 * cg + 16 * i + (l & 15), ci = c_skip + ch * 32 + 8 * (l >> 4) + e;
+                                        float s = 0.0f;
+                                        for (int kx = lo(px, tx); kx <= hi(px, tx); ++kx)
+                                            for (int ky = lo(py, ty); ky <= hi(py, ty); ++ky)
+                                                for (int kz = lo(pz, tz); kz <= hi(pz, tz); ++kz) s += W(co, ci, kx, ky, kz);
+                                        out[f * 512 + l * 8 + e] = (t16)s;
+                                    }
+                            }
+    }
     return nfrag * 1024;
 }
 
@@ -576,7 +582,7 @@ int sk_conv3d_upfold(const void* skip, int c_skip, const void* up, int c_up, con
                      void* out, int B, int ox, int oy, int oz, int cout, float* gn_partial, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     SK_CHECK_ARG(skip && up && weight && bias && out, "sk_conv3d_upfold: NULL pointer");
-    SK_CHECK_ARG(cout == 32, "sk_conv3d_upfold: cout must be 32 (got %d)", cout);
+    SK_CHECK_ARG(cout == 32 || cout == 64, "sk_conv3d_upfold: cout must be 32 or 64 (got %d)", cout);
     SK_CHECK_ARG(c_skip > 0 && c_up > 0 && c_skip % 32 == 0 && c_up % 32 == 0 && c_skip + c_up <= 256,
                  "sk_conv3d_upfold: channel counts must be multiples of 32 (got %d + %d)", c_skip, c_up);
     SK_CHECK_ARG(B > 0 && ox > 0 && oy > 0 && oz > 0, "sk_conv3d_upfold: bad output extents");
@@ -619,8 +625,17 @@ int sk_conv3d_upfold(const void* skip, int c_skip, const void* up, int c_up, con
     if (p.lds > 48 * 1024)
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
     const unsigned grid = (unsigned)(p.npatch * p.nxc * B);
-    kern<<<grid, 256, p.lds, stream>>>(a);
-    SK_CHECK_LAUNCH();
+    // 32 output channels per launch (COUT 64: two launches over the same inputs -- twice the staging, but on the
+    // 16x16x32 matrix instruction and at 70 instead of 108 tap-chunks; measured against conv3_kernel<64> in DESIGN.md)
+    a.out_vs = cout * 2;
+    a.pstride = (cout / 4) * 2;
+    for (int cg = 0; cg < cout / 32; ++cg) {
+        a.cout_off = 32 * cg;
+        a.poff = 16 * cg;
+        a.wpk = (const char*)weight + (size_t)cg * (a.ns * kSkipFrags + a.nu * kUpFrags) * 1024;
+        kern<<<grid, 256, p.lds, stream>>>(a);
+        SK_CHECK_LAUNCH();
+    }
     return SK_OK;
 }
 

@@ -19,7 +19,7 @@ def _cf(x):
     return x.permute(0, 4, 1, 2, 3).contiguous()
 
 
-# (B, out spatial, c_skip, c_up)
+# (B, out spatial, c_skip, c_up[, cout = 32])
 SHAPES = [
     (1, (8, 12, 20), 32, 32),      # Zl = 10: 3 rows per workgroup, exact
     (2, (12, 14, 20), 32, 32),     # Yl = 7: ragged last workgroup, batch 2
@@ -30,22 +30,24 @@ SHAPES = [
     (1, (8, 8, 20), 64, 32),       # two skip chunks
     (1, (8, 8, 12), 32, 64),       # two upsampled chunks
     (1, (44, 30, 20), 32, 32),     # several steps per x-chunk, ring reuse
+    (1, (14, 22, 10), 64, 64, 64),  # the level-1 decoder conv: cout 64 = two launches; x extent not a multiple of 4
+    (2, (6, 12, 20), 32, 32),      # x extent 6: a ragged second step
 ]
 
 
-def _make(B, osp, c_skip, c_up, integer, seed):
+def _make(B, osp, c_skip, c_up, integer, seed, cout=32):
     gen = torch.Generator().manual_seed(seed)
     lo = tuple(s // 2 for s in osp)
     if integer:
         skip = torch.randint(-3, 4, (B, c_skip) + osp, generator=gen).half()
         up = torch.randint(-3, 4, (B, c_up) + lo, generator=gen).half()
-        w = torch.randint(-2, 3, (32, c_skip + c_up, 3, 3, 3), generator=gen).float()
-        b = torch.randint(-4, 5, (32,), generator=gen).float()
+        w = torch.randint(-2, 3, (cout, c_skip + c_up, 3, 3, 3), generator=gen).float()
+        b = torch.randint(-4, 5, (cout,), generator=gen).float()
     else:
         skip = torch.randn((B, c_skip) + osp, generator=gen).half()
         up = torch.randn((B, c_up) + lo, generator=gen).half()
-        w = torch.randn((32, c_skip + c_up, 3, 3, 3), generator=gen) / ((c_skip + c_up) * 27) ** 0.5
-        b = torch.randn(32, generator=gen) * 0.1
+        w = torch.randn((cout, c_skip + c_up, 3, 3, 3), generator=gen) / ((c_skip + c_up) * 27) ** 0.5
+        b = torch.randn(cout, generator=gen) * 0.1
     return skip, up, w, b
 
 
@@ -57,45 +59,50 @@ def _torch(skip, up, w, b):
 def test_upfold_geometry_support():
     from skoots_amd import _ffi
     assert _ffi.lib.sk_conv3d_upfold_num_blocks(300, 300, 20, 32) > 0      # production tile, level 0
-    assert _ffi.lib.sk_conv3d_upfold_num_blocks(300, 300, 20, 64) < 0       # cout 64: not built
+    assert _ffi.lib.sk_conv3d_upfold_num_blocks(150, 150, 10, 64) > 0       # ... level 1 (two launches of 32 channels)
+    assert _ffi.lib.sk_conv3d_upfold_num_blocks(300, 300, 20, 128) < 0      # cout 128: not built
     assert _ffi.lib.sk_conv3d_upfold_num_blocks(512, 512, 128, 32) < 0      # Zl = 64 > 32
     assert _ffi.lib.sk_conv3d_upfold_num_blocks(8, 6, 64, 32) < 0           # Zl = 32: the four sub-planes pass 192 positions
-    assert _ffi.lib.sk_conv3d_upfold_num_blocks(10, 12, 20, 32) < 0         # x extent not a multiple of 4
+    assert _ffi.lib.sk_conv3d_upfold_num_blocks(9, 12, 20, 32) < 0          # odd x extent
     assert _ffi.lib.sk_conv3d_upfold_num_blocks(8, 12, 19, 32) < 0
 
 
-@pytest.mark.parametrize("B,osp,c_skip,c_up", SHAPES)
-def test_upfold_exact_on_integers(B, osp, c_skip, c_up):
+@pytest.mark.parametrize("shape", SHAPES)
+def test_upfold_exact_on_integers(shape):
     """Integer operands: folded kernel == direct kernel == torch fp32, bit for bit, and equal GroupNorm sums."""
     from skoots_amd import unet as U
-    skip, up, w, b = _make(B, osp, c_skip, c_up, True, 7 + osp[1])
+    B, osp, c_skip, c_up = shape[:4]
+    cout = shape[4] if len(shape) > 4 else 32
+    skip, up, w, b = _make(B, osp, c_skip, c_up, True, 7 + osp[1], cout)
     want = _torch(skip, up, w, b)
     assert want.abs().max() < 2048      # representable in fp16 exactly
     s_d, u_d = _cl(skip).to(DEV), _cl(up).to(DEV)
-    got, partial = U.conv3d_upfold(s_d, u_d, U.pack_conv_weight_upfold(w, c_skip, DEV), b.to(DEV), 32)
+    got, partial = U.conv3d_upfold(s_d, u_d, U.pack_conv_weight_upfold(w, c_skip, DEV), b.to(DEV), cout)
     got = _cf(got.cpu().float())
     assert torch.equal(got, want)
     zeros = torch.zeros(4096, dtype=torch.uint8, device=DEV)
-    ref, rpartial = U.conv3d([(s_d, 0), (u_d, 1)], U.pack_conv_weight(w, DEV), b.to(DEV), 32, 3, osp, zeros)
+    ref, rpartial = U.conv3d([(s_d, 0), (u_d, 1)], U.pack_conv_weight(w, DEV), b.to(DEV), cout, 3, osp, zeros)
     assert torch.equal(_cf(ref.cpu().float()), want)
     ps, rs = partial.sum(dim=1).cpu(), rpartial.sum(dim=1).cpu()
     assert torch.equal(ps[..., 0], rs[..., 0])                   # integer sums below 2^24: order-free
     assert torch.allclose(ps[..., 1], rs[..., 1], rtol=1e-6)     # sums of squares pass 2^24: fp32 rounding by order
 
 
-@pytest.mark.parametrize("B,osp,c_skip,c_up", SHAPES[:5])
-def test_upfold_vs_torch_random(B, osp, c_skip, c_up):
+@pytest.mark.parametrize("shape", SHAPES[:5] + SHAPES[-2:])
+def test_upfold_vs_torch_random(shape):
     """Random operands against torch fp32 on the fp16-rounded inputs and the UNROUNDED weights: the kernel's weights are
     fp16 (a folded one is the fp16 of a sum of up to 8 taps), accumulation fp32, output fp16."""
     from skoots_amd import unet as U
-    skip, up, w, b = _make(B, osp, c_skip, c_up, False, 11 + osp[0])
+    B, osp, c_skip, c_up = shape[:4]
+    cout = shape[4] if len(shape) > 4 else 32
+    skip, up, w, b = _make(B, osp, c_skip, c_up, False, 11 + osp[0], cout)
     want = _torch(skip, up, w, b)
-    got, partial = U.conv3d_upfold(_cl(skip).to(DEV), _cl(up).to(DEV), U.pack_conv_weight_upfold(w, c_skip, DEV), b.to(DEV), 32)
+    got, partial = U.conv3d_upfold(_cl(skip).to(DEV), _cl(up).to(DEV), U.pack_conv_weight_upfold(w, c_skip, DEV), b.to(DEV), cout)
     got = _cf(got.cpu().float())
     err = (got - want).abs().max().item()
     assert err <= 3e-3 * max(1.0, want.abs().max().item()), err
     p = partial.sum(dim=1).cpu()
-    wq = got.reshape(B, 8, 4, -1)      # statistics are those of the stored fp16 values
+    wq = got.reshape(B, cout // 4, 4, -1)      # statistics are those of the stored fp16 values
     assert torch.allclose(p[..., 0], wq.sum(dim=(2, 3)), rtol=1e-3, atol=2e-2 * wq.shape[-1] ** 0.5)
     assert torch.allclose(p[..., 1], (wq ** 2).sum(dim=(2, 3)), rtol=2e-3)
 
