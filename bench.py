@@ -174,7 +174,7 @@ def conv_hbm_traffic():
     """HBM bytes per conv3 launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     in separate runs of the same launch shapes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).
     bench.py cannot collect PMC counters itself; returns (None, None) when no profile is committed."""
-    for name in ("r02_conv_hbm_traffic_pmc.json", "r01_conv_hbm_traffic_pmc.json"):
+    for name in ("r02_conv_hbm_traffic_pmc_v2.json", "r02_conv_hbm_traffic_pmc.json", "r01_conv_hbm_traffic_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             prof = json.load(open(path))
@@ -182,7 +182,7 @@ def conv_hbm_traffic():
             continue
         tot, n = 0.0, 0
         for k in prof["kernels"]:
-            if "conv3_kernel" in k["kernel"] or "conv3_m16_kernel" in k["kernel"]:
+            if any(n in k["kernel"] for n in ("conv3_kernel", "conv3_m16_kernel", "conv3_upf_kernel")):
                 tot += (k["fetch_MB_per_launch_x2_gfx950_correction"] + k["write_MB_per_launch"]) * k["launches"]
                 n += k["launches"]
         if n:
@@ -351,6 +351,7 @@ def eval_main(args, rank, world, local):
         voxels = X * Y * Z
         conv_ms, conv_flops, conv_launches = prof.totals()
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        executed = prof.executed_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         traffic, traffic_src = conv_hbm_traffic()
         per_layer = {}
         for e0, e1, fl, name in prof.named():
@@ -373,12 +374,17 @@ def eval_main(args, rank, world, local):
                        "tile_batch": args.tile_batch, "streams": args.streams,
                        "instances": int(res.get("n_instances", -1)), "blobs_injected": n_blobs,
                        "stage_ms": {k: round(v / args.steps * 1e3, 2) for k, v in sv.timings.items()}},
-            "roofline": {"bound": "mfma", "kernel": "conv3_m16_kernel / conv3_kernel (all 3x3x3 MFMA conv launches)",
+            "roofline": {"bound": "mfma", "kernel": "conv3_m16_kernel / conv3_kernel / conv3_upf_kernel (all 3x3x3 MFMA conv launches)",
                          "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic if args.precision == "fp16" else None,
+                         # the two decoder convs over [skip, upsample(x)] run with the upsample folded into the weights
+                         # (8 of 27 taps for the upsampled channels): the pipe executes fewer FLOPs than the algorithm counts
+                         "executed": round(executed, 2), "frac_executed": round(executed / MFMA_PEAK_TFLOPS, 4),
                          "traffic_unit": f"bytes per launch (PMC, profiles/{traffic_src})",
                          "launches": conv_launches, "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
-                         "flops_counted": "algorithmic 2*Cin*Cout*27 per output voxel (split mode issues 3x that on the MFMA pipe); "
+                         "flops_counted": "achieved: algorithmic 2*Cin*Cout*27 per output voxel, the conv as the reference states it "
+                                          "(split mode issues 3x that on the MFMA pipe); executed: what the launches issue (fp16 mode: "
+                                          "dec0.0 / dec1.0 fold the nearest-upsample into the weights, 35 of 54 tap-chunks); "
                                           "dec0.1's launches also contain the GroupNorm + SiLU of their input (fused, fp16 mode)",
                          "layers": layers},
         }

@@ -87,7 +87,9 @@ class ConvProfile:
     the stream the kernels are launched on; bench.py turns it into the roofline figure."""
 
     def __init__(self):
-        self.events = []  # (start, end, flops, layer name)
+        self.events = []  # (start, end, flops, layer name): flops = the ALGORITHMIC count 2*Cin*Cout*27 per output voxel
+        self.executed_flops = 0.0  # what the launches put on the matrix pipe (the folded decoder convs: 8 of 27 taps
+        #                            for the upsampled channels)
 
     def named(self):
         if self.events:
@@ -242,6 +244,8 @@ class HipUNet:
         if timed:
             e1.record(torch.cuda.current_stream(self.device))
             self.profile.events.append((e0, e1, layer.flops_per_out_voxel * B * ox * oy * oz, layer.name))
+            per_voxel = 2.0 * layer.cout * (arr[0].c * 27 + arr[1].c * 8) if fold else layer.flops_per_out_voxel
+            self.profile.executed_flops += per_voxel * B * ox * oy * oz
         aff = self._norm_act(layer, out, partial, nblk, apply=activate)
         return out if activate else (out, aff)
 
