@@ -552,7 +552,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=["eval", "train"], default="eval",
                     help="eval: BASELINE configs[2]/[3] (the headline metric); train: configs[4], one training step")
-    ap.add_argument("--tile-batch", type=int, default=32, help="tiles per network launch (<= 32)")
+    ap.add_argument("--tile-batch", type=int, default=64, help="tiles per network launch (<= 64)")
     ap.add_argument("--shape", type=str, default="", help="override X,Y,Z (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inject", action="store_true")

@@ -21,7 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef t16 half4v __attribute__((ext_vector_type(4)));
 
-constexpr int kStemMaxB = 32;   // tiles per launch (origins travel by value in the kernel arguments)
+constexpr int kStemMaxB = 64;   // tiles per launch (the pipeline runs 64: +1 % end to end over 32) (origins travel by value in the kernel arguments)
 
 struct StemArgs {
     const t16* image;   // (X, Y, Z) fp16 volume

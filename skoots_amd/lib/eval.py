@@ -199,7 +199,7 @@ def tile_grid(shape: Sequence[int], tile=TILE, overlap=TILE_OVERLAP):
 
 
 def eval_volume(image: Tensor, model, scale, mean=None, std=None, n: int = FOLLOW_N,
-                tile=TILE, tile_overlap=TILE_OVERLAP, tile_batch: int = 32,
+                tile=TILE, tile_overlap=TILE_OVERLAP, tile_batch: int = 64,
                 inject: Optional[Callable] = None, keep_planar_vectors: bool = False,
                 timings: Optional[Dict[str, float]] = None) -> Dict[str, Tensor]:
     """In-memory variant of :func:`eval` on one GPU: (1, X, Y, Z) or (X, Y, Z) image on the

@@ -308,7 +308,7 @@ class ShardedVolume:
         self.timings[name] = self.timings.get(name, 0.0) + time.perf_counter() - t0
 
     def run(self, image: Tensor, model, scale, mean: float, std: float, n: int = 10,
-            decay: float = 1.0, tile=(300, 300, 20), tile_overlap=(50, 50, 5), tile_batch: int = 32,
+            decay: float = 1.0, tile=(300, 300, 20), tile_overlap=(50, 50, 5), tile_batch: int = 64,
             inject: Optional[Callable] = None, keep_planar_vectors: bool = False,
             conv_profile=None, streams: int = 1, stage_profile=None) -> Dict[str, object]:
         """``image``: this rank's window of the fp16 volume, shape (X, Y, window planes)."""
