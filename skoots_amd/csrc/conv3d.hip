@@ -634,7 +634,12 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
 // (Keeping chunk 0's rows resident in a two-chunk layer, selected at run time per phase, spills: 1.8x slower;
 // requesting a whole row of streamed fragments two bodies ahead instead of one measured 4 % slower.)
 // Measured A/B on one device: -4..5 % time on enc0.1 / dec0.1.
-template <int COUT, int XS, int RES = 0, bool SPLIT = false>
+// WL: further tap rows (RES .. RES + WL - 1) whose fragments sit in LDS behind the ring, one copy per workgroup -- the four
+// waves of a COUT-32 workgroup stream the SAME fragments, each through the CU's vector-memory path, which these kernels
+// load as heavily as the matrix pipe.  Two rows fit next to the six-plane ring of the production
+// tile (80 256 B: still two workgroups per CU): 12 of the 36 weight loads per wave and step become LDS reads,
+// enc0.1 0.677 -> 0.655 ms, dec0.1 0.867 -> 0.848 ms per 8 tiles (tools/layer_ab.py).
+template <int COUT, int XS, int RES = 0, bool SPLIT = false, int WL = 0>
 __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     constexpr int NT = COUT / 32;
     constexpr int P = NT;            // column tiles per wave
@@ -881,6 +886,11 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     }
     if (tid < R * 4)
         *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
+    if constexpr (RES > 0 && WL > 0) {   // rows RES .. RES + WL - 1 of chunk 0: one copy per workgroup
+        for (int i = tid; i < WL * 6 * 64; i += 256)
+            *reinterpret_cast<uint4*>(lds + R * plane_bytes + i * 16) =
+                *reinterpret_cast<const uint4*>(a.wpk + RES * 6 * 1024 + i * 16);
+    }
     issue_dma(0, ch0, false, 0);
     if constexpr (RES == 0) {
 #pragma unroll
@@ -1000,12 +1010,29 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                 if constexpr (RES > 0) {
                     if (dydz < RES) {
                         compute(dydz, 0, wres[2 * dydz]);
-                        if (dydz == RES - 1) {  // first streamed row's ks = 0 fragments, one body ahead
+                        if (dydz == RES - 1 && WL == 0) {  // first streamed row's ks = 0 fragments, one body ahead
 #pragma unroll
                             for (int d = 0; d < 3; ++d)
                                 a0[d] = wload(wrow + ((6 + d) * NT) * 1024);
                         }
                         compute(dydz, 1, wres[2 * dydz + 1]);
+                        continue;
+                    }
+                    if (dydz < RES + WL) {   // rows whose fragments sit in LDS behind the ring
+                        const char* wl = lds + R * plane_bytes + (dydz - RES) * 6144 + lane * 16;
+                        half8 l0[3], l1[3];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            l0[d] = *reinterpret_cast<const half8*>(wl + d * 1024);
+                            l1[d] = *reinterpret_cast<const half8*>(wl + (3 + d) * 1024);
+                        }
+                        compute(dydz, 0, l0);
+                        if (dydz == RES + WL - 1) {
+#pragma unroll
+                            for (int d = 0; d < 3; ++d)
+                                a0[d] = wload(wrow + ((6 + d) * NT) * 1024);
+                        }
+                        compute(dydz, 1, l1);
                         continue;
                     }
                 }
@@ -1669,14 +1696,16 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
     return 0;
 }
 
-template <int XS, int RES = 0, bool SPLIT = false>
+template <int XS, int RES = 0, bool SPLIT = false, int WL = 0>
 int launch_conv3_m16(const Conv3Args& a, const Plan& p, hipStream_t stream) {
-    auto kern = conv3_m16_kernel<32, XS, RES, SPLIT>;
-    if (p.lds > 48 * 1024)
+    auto kern = conv3_m16_kernel<32, XS, RES, SPLIT, WL>;
+    size_t lds = p.lds;
+    if (RES > 0 && WL > 0) lds = p.lds - 4 * kPadBytes + WL * 6144;   // this kernel has no transpose pads
+    if (lds > 48 * 1024)
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)p.lds));
+                                         (int)lds));
     unsigned grid = (unsigned)(p.npatch * p.nxc * a.B);
-    kern<<<grid, 256, p.lds, stream>>>(a);
+    kern<<<grid, 256, lds, stream>>>(a);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }
@@ -1888,7 +1917,10 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
         }
         if (cout == 32) {   // 16x16x32 kernel
             if (p.xs == 3) return launch_conv3_m16<3>(a, p, stream);
-            if (a.nchunks == 1 && !a.ablate) return launch_conv3_m16<4, 3>(a, p, stream);
+            if (a.nchunks == 1 && !a.ablate) {   // single chunk: 3 tap rows in registers, 2 more in LDS where they fit
+                if (p.lds - 4 * kPadBytes + 2 * 6144 <= 80 * 1024) return launch_conv3_m16<4, 3, false, 2>(a, p, stream);
+                return launch_conv3_m16<4, 3>(a, p, stream);
+            }
             return launch_conv3_m16<4>(a, p, stream);
         }
         if (cout == 64) return p.xs == 3 ? launch_conv3<64, 3>(a, p, stream) : launch_conv3<64, 4>(a, p, stream);
