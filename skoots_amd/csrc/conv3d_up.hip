@@ -76,7 +76,10 @@ struct UpfArgs {
 #define SK_T_DUMP(a, w, lane)
 #endif
 
-template <int XS>
+// WLDS (one skip chunk only): tap rows 0 and 1 of the skip chunk's weights sit in LDS behind the ring, one copy per
+// workgroup, instead of being streamed by each of the four waves (conv3_m16_kernel's WL): 12 of the 54 + 32 weight loads
+// per wave and step become LDS reads and the hand-off to the skip phase requests no weights at all.
+template <int XS, bool WLDS>
 __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
     constexpr int R = XS + 2;          // fine planes of a step
     constexpr int RL = XS / 2 + 2;     // low-resolution planes of a step
@@ -240,7 +243,9 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) dst[e] = wload(wch + (unsigned)((tytz * 8 + e) * 1024));
     };
+    const char* wlds = lds + R * plane_bytes + lane * 16;   // WLDS: fragments 0 .. 11 of the skip chunk
     auto prefetch_skip = [&](int cs) {   // the first fragments of a phase
+        if constexpr (WLDS) return;      // row 0 comes from LDS at the start of the phase
 #pragma unroll
         for (int e = 0; e < 6; ++e) wq[e] = wload(wbase_skip(cs) + e * 1024);
     };
@@ -252,6 +257,10 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
 
     if (tid < R * 4)
         *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
+    if constexpr (WLDS) {
+        for (int i = tid; i < 12 * 64; i += 256)
+            *reinterpret_cast<uint4*>(lds + R * plane_bytes + i * 16) = *reinterpret_cast<const uint4*>(a.wpk + i * 16);
+    }
     issue_fine(0, 0, false, 0);
     prefetch_skip(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -304,6 +313,10 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
                             if (o >= 0 && o < XS) acc[o][ks][j] = SK_MFMA_16x16x32_T16(wf[ks * 3 + d], src[i], acc[o][ks][j], 0, 0, 0);
                         }
             };
+            if constexpr (WLDS) {
+#pragma unroll
+                for (int e = 0; e < 6; ++e) wq[e] = *reinterpret_cast<const half8*>(wlds + e * 1024);
+            }
             load_body(0, 0, bb[0]);
 #pragma unroll
             for (int dydz = 0; dydz < 9; ++dydz) {
@@ -315,7 +328,12 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
                         load_body(dydz, 1, bb[1]);
                         if (dydz < 8) {
 #pragma unroll
-                            for (int e = 0; e < 6; ++e) wnext[e] = wload(wch + (unsigned)(((dydz + 1) * 6 + e) * 1024));
+                            for (int e = 0; e < 6; ++e) {
+                                if (WLDS && dydz + 1 < 2)
+                                    wnext[e] = *reinterpret_cast<const half8*>(wlds + ((dydz + 1) * 6 + e) * 1024);
+                                else
+                                    wnext[e] = wload(wch + (unsigned)(((dydz + 1) * 6 + e) * 1024));
+                            }
                         }
                     } else if (dydz < 8) {
                         load_body(dydz + 1, 0, bb[0]);
@@ -621,9 +639,11 @@ int sk_conv3d_upfold(const void* skip, int c_skip, const void* up, int c_up, con
 #ifdef SK_TIMING
     if (const char* e = getenv("SK_CONV_DBG")) a.dbg = (long long*)strtoull(e, nullptr, 0);
 #endif
-    auto kern = conv3_upf_kernel<4>;
-    if (p.lds > 48 * 1024)
-        SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    const bool wlds = a.ns == 1 && p.lds + 12288 <= 80 * 1024;   // two tap rows of the single skip chunk in LDS
+    auto kern = wlds ? conv3_upf_kernel<4, true> : conv3_upf_kernel<4, false>;
+    const size_t lds = p.lds + (wlds ? 12288 : 0);
+    if (lds > 48 * 1024)
+        SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)(p.npatch * p.nxc * B);
     // 32 output channels per launch (COUT 64: two launches over the same inputs -- twice the staging, but on the
     // 16x16x32 matrix instruction and at 70 instead of 108 tap-chunks; measured against conv3_kernel<64> in DESIGN.md)
@@ -633,7 +653,7 @@ int sk_conv3d_upfold(const void* skip, int c_skip, const void* up, int c_up, con
         a.cout_off = 32 * cg;
         a.poff = 16 * cg;
         a.wpk = (const char*)weight + (size_t)cg * (a.ns * kSkipFrags + a.nu * kUpFrags) * 1024;
-        kern<<<grid, 256, p.lds, stream>>>(a);
+        kern<<<grid, 256, lds, stream>>>(a);
         SK_CHECK_LAUNCH();
     }
     return SK_OK;
