@@ -174,7 +174,7 @@ def conv_hbm_traffic():
     """HBM bytes per conv3 launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     in separate runs of the same launch shapes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).
     bench.py cannot collect PMC counters itself; returns (None, None) when no profile is committed."""
-    for name in ("r02_conv_hbm_traffic_pmc_v2.json", "r02_conv_hbm_traffic_pmc.json", "r01_conv_hbm_traffic_pmc.json"):
+    for name in ("r02_conv_hbm_traffic_pmc_v3.json", "r02_conv_hbm_traffic_pmc_v2.json", "r02_conv_hbm_traffic_pmc.json", "r01_conv_hbm_traffic_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             prof = json.load(open(path))
