@@ -32,6 +32,8 @@ SHAPES = [
     (1, (44, 30, 20), 32, 32),     # several steps per x-chunk, ring reuse
     (1, (14, 22, 10), 64, 64, 64),  # the level-1 decoder conv: cout 64 = two launches; x extent not a multiple of 4
     (2, (6, 12, 20), 32, 32),      # x extent 6: a ragged second step
+    (2, (8, 300, 20), 32, 32),     # the production (y, z) plane: 50 workgroups per x-chunk, weight rows in LDS
+    (1, (8, 150, 10), 64, 64, 64),  # ... and the level-1 plane
 ]
 
 
