@@ -22,11 +22,13 @@
 // columns of an MFMA read 16 CONSECUTIVE positions (+ a wave-uniform offset): the conflict-free swizzle of
 // conv3_m16_kernel carries over unchanged.  z faces: a lane whose tap would wrap into the neighbouring row reads the
 // plane's zero position (conv3d.hip's linear mode).  The low-resolution source is staged as it is (4 planes of
-// (K + 2) rows), in the same LDS ring slots as the fine planes.
+// (K + 2) rows) in the ring slots of the fine planes the step is done with; fine planes XS, XS + 1 survive the upsampled
+// phases and are planes 0, 1 of the next step (one skip chunk).
 //
-// COUT 32 on v_mfma_f32_16x16x32_f16; everything else (x-marching ring, LDS-DMA through buffer descriptors, alternating
-// chunk order with two reused planes, B fragments of two tap rows double-buffered in registers, permlane epilogue,
-// GroupNorm partials on v_dot2c) as in conv3_m16_kernel, whose comments explain those parts.
+// 32 output channels per launch on v_mfma_f32_16x16x32_f16 (COUT 64: two launches); B fragments in half-row bodies one
+// body ahead, weight rows one (skip chunks; rows 0, 1 from LDS when there is one skip chunk) or two (upsampled chunks)
+// rows ahead; everything else (x-marching ring, LDS-DMA through buffer descriptors, permlane epilogue, GroupNorm partials on
+// v_dot2c) as in conv3_m16_kernel, whose comments explain those parts.
 #include <stdlib.h>
 
 #include <vector>
@@ -203,13 +205,12 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
             }
         }
     };
-    auto issue_low = [&](int step, int chu, bool reuse, int rotl_n) {
+    auto issue_low = [&](int step, int chu, bool /*reuse: never -- the skip phases overwrite these slots*/, int rotl_n) {
         const int xl0 = ((xa + step * XS) >> 1) - 1;
         const int xlo = max(xl0, 0);
         const long long wbytes = min((long long)(RL + 1) * a.up_plane, a.up_batch - (long long)xlo * a.up_plane);
         const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(a.up + (long long)b * a.up_batch + (long long)xlo * a.up_plane, (unsigned)wbytes);
         const unsigned vstride = (unsigned)(a.upC * 2);
-        (void)reuse;
         for (int i = 0; i < RL; ++i) {
             const int xl = xl0 + i;
             const bool xok = xl >= 0 && xl < Xl;
