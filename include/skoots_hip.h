@@ -223,6 +223,12 @@ int sk_conv3d_upfold(const void* skip, int c_skip, const void* up, int c_up, con
 int sk_conv3d_upfold_num_blocks(int ox, int oy, int oz, int cout);
 /* HOST: torch-layout weight (cout, c_skip + c_up, 3, 3, 3) fp32 -> fragments of sk_conv3d_upfold.  Bytes needed / written. */
 int64_t sk_conv3d_pack_weight_upfold_host(const float* w_host, int cout, int c_skip, int c_up, void* dst_host);
+/* The same on split tensors (precision "split": every voxel line [hi (C) | lo (C)] fp16, value = hi + lo; out the same with
+ * cout): three MFMA phases per logical chunk as sk_conv3d_split; the folded weights are summed in double and split afterwards. */
+int sk_conv3d_upfold_split(const void* skip, int c_skip, const void* up, int c_up, const void* weight,
+                           const float* bias, void* out, int B, int ox, int oy, int oz, int cout,
+                           float* gn_partial, void* stream);
+int64_t sk_conv3d_pack_weight_upfold_split_host(const float* w_host, int cout, int c_skip, int c_up, void* dst_host);
 
 /* Rows of gn_partial per batch item that sk_conv3d writes for this output shape. */
 int sk_conv3d_num_blocks(int B, int ox, int oy, int oz, int cout, int ksize);

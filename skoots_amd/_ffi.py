@@ -69,6 +69,8 @@ _SIGS = {
     "sk_conv3d_num_blocks": (i32, [i32, i32, i32, i32, i32, i32]),
     "sk_conv3d_pack_weight_host": (i64, [fp, i32, i32, i32, vp]),
     "sk_conv3d_upfold": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "sk_conv3d_upfold_split": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "sk_conv3d_pack_weight_upfold_split_host": (i64, [fp, i32, i32, i32, vp]),
     "sk_conv3d_upfold_num_blocks": (i32, [i32, i32, i32, i32]),
     "sk_conv3d_pack_weight_upfold_host": (i64, [fp, i32, i32, i32, vp]),
     "sk_conv3d_stem": (i32, [vp, i32, i32, i32, ip, i32, i32, i32, i32, f32, f32, vp, vp, i32, vp, vp, sz, vp]),

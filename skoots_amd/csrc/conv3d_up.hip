@@ -81,7 +81,11 @@ struct UpfArgs {
 // WLDS (one skip chunk only): tap rows 0 and 1 of the skip chunk's weights sit in LDS behind the ring, one copy per
 // workgroup, instead of being streamed by each of the four waves (conv3_m16_kernel's WL): 12 of the 54 + 32 weight loads
 // per wave and step become LDS reads and the hand-off to the skip phase requests no weights at all.
-template <int XS, bool WLDS>
+// SPLIT (precision "split", sk_conv3d_upfold_split): every tensor holds fp16 hi + lo pairs, [hi (C) | lo (C)] per voxel
+// line, and every weight is a hi + lo pair; a logical chunk runs as three phases -- (x_hi, w_lo), (x_hi again: no LDS-DMA,
+// w_hi), (x_lo, w_hi) -- as in conv3_m16_kernel's split mode, and the fp32 accumulator is stored as hi = fp16(v),
+// lo = fp16(v - hi).  The folded weights are split AFTER the fold (the sum is formed in double on the host).
+template <int XS, bool WLDS, bool SPLIT>
 __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
     constexpr int R = XS + 2;          // fine planes of a step
     constexpr int RL = XS / 2 + 2;     // low-resolution planes of a step
@@ -177,6 +181,13 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
     const float* biasp = a.bias + a.cout_off + 4 * g;
 
     const int nsteps = (xb - xa + XS - 1) / XS;
+    // Virtual chunks: plain mode one per 32-channel chunk; split mode three -- part 0: hi halves x lo weights, part 1: the
+    // SAME staged planes x hi weights (no LDS-DMA), part 2: lo halves x hi weights
+    constexpr int kParts = SPLIT ? 3 : 1;
+    const int nvs = a.ns * kParts, nvu = a.nu * kParts;
+    auto v_chunk = [](int v) { return SPLIT ? v / 3 : v; };
+    auto v_part = [](int v) { return SPLIT ? v % 3 : 0; };
+    auto v_dma = [&](int v) { return v_part(v) != 1; };
 
     // Phase order of a step: the skip chunks, then the upsampled chunks.  Fine plane i of the step lives in ring slot
     // (rot + i) % R; the low-resolution planes of the step take the slots of fine planes 0 .. RL-1, which the step is
@@ -187,12 +198,13 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
         const int xlo = max(x0 - 1, 0);
         const long long wbytes = min((long long)(R + 1) * a.skip_plane, a.skip_batch - (long long)xlo * a.skip_plane);
         const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(a.skip + (long long)b * a.skip_batch + (long long)xlo * a.skip_plane, (unsigned)wbytes);
-        const unsigned vstride = (unsigned)(a.skipC * 2);
+        const unsigned vstride = (unsigned)(a.skipC * 2 * (SPLIT ? 2 : 1));
+        const int choff = v_chunk(chs) * 64 + (v_part(chs) == 2 ? a.skipC * 2 : 0);   // split: the lo halves follow the hi halves
         for (int i = reuse ? 2 : 0; i < R; ++i) {
             const int x = x0 - 1 + i;
             const bool xok = x >= 0 && x < a.Xt;
             char* lbase = lds + ((rot_n + i) % R) * plane_bytes;
-            const unsigned xoff = (unsigned)((x - xlo) * (int)a.skip_plane + chs * 64 + d_cs);
+            const unsigned xoff = (unsigned)((x - xlo) * (int)a.skip_plane + choff + d_cs);
 #pragma unroll
             for (int k = 0; k < kMaxDma; ++k) {
                 const int t = w + 4 * k;
@@ -210,12 +222,13 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
         const int xlo = max(xl0, 0);
         const long long wbytes = min((long long)(RL + 1) * a.up_plane, a.up_batch - (long long)xlo * a.up_plane);
         const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(a.up + (long long)b * a.up_batch + (long long)xlo * a.up_plane, (unsigned)wbytes);
-        const unsigned vstride = (unsigned)(a.upC * 2);
+        const unsigned vstride = (unsigned)(a.upC * 2 * (SPLIT ? 2 : 1));
+        const int choff = v_chunk(chu) * 64 + (v_part(chu) == 2 ? a.upC * 2 : 0);
         for (int i = 0; i < RL; ++i) {
             const int xl = xl0 + i;
             const bool xok = xl >= 0 && xl < Xl;
             char* lbase = lds + ((rotl_n + i) % R) * plane_bytes;
-            const unsigned xoff = (unsigned)((xl - xlo) * (int)a.up_plane + chu * 64 + d_cs);
+            const unsigned xoff = (unsigned)((xl - xlo) * (int)a.up_plane + choff + d_cs);
 #pragma unroll
             for (int k = 0; k < kMaxDmaL; ++k) {
                 const int t = w + 4 * k;
@@ -226,14 +239,21 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
             }
         }
     };
-    const __amdgpu_buffer_rsrc_t wrsrc = sk::make_rsrc(a.wpk, (unsigned)((a.ns * kSkipFrags + a.nu * kUpFrags) * 1024));
+    const __amdgpu_buffer_rsrc_t wrsrc = sk::make_rsrc(a.wpk, (unsigned)((a.ns * kSkipFrags + a.nu * kUpFrags) * (SPLIT ? 2 : 1) * 1024));
     const unsigned wlane = lane * 16;
     auto wload = [&](unsigned off) {
         return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, __builtin_amdgcn_readfirstlane(off), 0));
     };
     // first fragment of a chunk for this wave
-    auto wbase_skip = [&](int cs) { return (unsigned)(cs * kSkipFrags * 1024); };
-    auto wbase_up = [&](int cu) { return (unsigned)((a.ns * kSkipFrags + cu * kUpFrags + w * 32) * 1024); };
+    // split: per chunk the lo-weight fragment set, then the hi-weight set; part 0 multiplies by lo, parts 1 and 2 by hi
+    auto wbase_skip = [&](int v) {
+        return (unsigned)((SPLIT ? (2 * v_chunk(v) + (v_part(v) != 0)) : v) * kSkipFrags * 1024);
+    };
+    auto wbase_up = [&](int v) {
+        const int frag0 = SPLIT ? 2 * a.ns * kSkipFrags + (2 * v_chunk(v) + (v_part(v) != 0)) * kUpFrags
+                                : a.ns * kSkipFrags + v * kUpFrags;
+        return (unsigned)((frag0 + w * 32) * 1024);
+    };
 
     // Weight fragments that cross a phase boundary (requested before the closing barrier of the phase before): ONE
     // register set for both kinds of chunk -- a value carried around the phase loop stays allocated through every phase.
@@ -267,7 +287,7 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const bool ring = a.ns == 1;   // the same skip chunk every step: its two trailing planes are reused
+    const bool ring = !SPLIT && a.ns == 1;   // the same skip chunk every step: its two trailing planes are reused
     int rot = 0;
     SK_T_DECL
     for (int step = 0; step < nsteps; ++step) {
@@ -281,7 +301,7 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
         int c16v = c16;
         asm volatile("" : "+v"(c16v));
 
-        for (int cs = 0; cs < a.ns; ++cs) {
+        for (int cs = 0; cs < nvs; ++cs) {
             const unsigned wch = wbase_skip(cs);
             // ---------------- skip chunk: 27 taps on the de-interleaved fine planes -----------------
             int pslot[R];
@@ -344,13 +364,17 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
                 }
             }
             SK_T(0)   // skip MFMA loop
-            if (cs + 1 < a.ns) {
+            if (cs + 1 < nvs) {
                 // hand the planes to the next skip chunk: barrier (all waves done reading) -> LDS-DMA + first weights of the
-                // next phase -> landed -> barrier
-                __syncthreads();
-                issue_fine(step, cs + 1, false, rot);
-                prefetch_skip(cs + 1);
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                // next phase -> landed -> barrier; split part 1 multiplies the planes that are staged: weights only
+                if (v_dma(cs + 1)) {
+                    __syncthreads();
+                    issue_fine(step, cs + 1, false, rot);
+                    prefetch_skip(cs + 1);
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                } else {
+                    prefetch_skip(cs + 1);
+                }
             }
         }
         // ... and to the first upsampled chunk (outside the loop: the weight rows requested here must not look live
@@ -365,7 +389,7 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
         asm volatile("s_barrier" ::: "memory");
         SK_T(4)   // barrier
 
-        for (int cu = 0; cu < a.nu; ++cu) {
+        for (int cu = 0; cu < nvu; ++cu) {
             const unsigned wch = wbase_up(cu);
             // ---------------- upsampled chunk: 2 x 2 x 2 folded taps on the low-resolution planes -----------------
             int pslot[RL];
@@ -412,7 +436,7 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
                             }
                 }
             }
-            const bool last = cu + 1 == a.nu;
+            const bool last = cu + 1 == nvu;
             const bool have_next = !last || step + 1 < nsteps;
             const int rot_n = (last && ring) ? (rot + XS) % R : rot;
             SK_T(5)   // upsampled MFMA loop
@@ -420,7 +444,7 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
             SK_T(6)   // barrier
             if (have_next) {
                 if (!last) {
-                    issue_low(step, cu + 1, false, rot);
+                    if (v_dma(cu + 1)) issue_low(step, cu + 1, false, rot);
                     prefetch_up(cu + 1);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 } else {
@@ -437,38 +461,53 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
                 for (int o = 0; o < XS; ++o) {
                     const int x = x0 + o;
     #pragma unroll
+                    for (int part = 0; part < (SPLIT ? 2 : 1); ++part) {   // SPLIT: the hi halves, then the lo halves
+    #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         unsigned d[2][2];
     #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const f32x4 r = acc[o][i][j];
-                            const half4 hv = {(t16)r[0], (t16)r[1], (t16)r[2], (t16)r[3]};
+                            half4 hv = {(t16)r[0], (t16)r[1], (t16)r[2], (t16)r[3]};
+                            if (part == 1)   // lo = fp16(v - hi): exact difference, rounded once
+                                hv = half4{(t16)(r[0] - (float)hv[0]), (t16)(r[1] - (float)hv[1]),
+                                           (t16)(r[2] - (float)hv[2]), (t16)(r[3] - (float)hv[3])};
                             const uint2 u = __builtin_bit_cast(uint2, hv);
                             d[j][0] = u.x;
                             d[j][1] = u.y;
                             const bool in = vvalid(j) && x < xb;
-                            const t16x2 z2 = {(t16)0.0f, (t16)0.0f}, one2 = {(t16)1.0f, (t16)1.0f};
-                            const t16x2 lo2 = in ? t16x2{hv[0], hv[1]} : z2, hi2 = in ? t16x2{hv[2], hv[3]} : z2;
-                            gsum[i] = SK_DOT2_T16(lo2, one2, gsum[i]);
-                            gsum[i] = SK_DOT2_T16(hi2, one2, gsum[i]);
-                            gsq[i] = SK_DOT2_T16(lo2, lo2, gsq[i]);
-                            gsq[i] = SK_DOT2_T16(hi2, hi2, gsq[i]);
+                            if (SPLIT) {
+                                if (part == 0 && in) {   // split: statistics of the fp32 accumulators
+                                    gsum[i] += (r[0] + r[1]) + (r[2] + r[3]);
+                                    gsq[i] += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+                                }
+                            } else {
+                                const t16x2 z2 = {(t16)0.0f, (t16)0.0f}, one2 = {(t16)1.0f, (t16)1.0f};
+                                const t16x2 lo2 = in ? t16x2{hv[0], hv[1]} : z2, hi2 = in ? t16x2{hv[2], hv[3]} : z2;
+                                gsum[i] = SK_DOT2_T16(lo2, one2, gsum[i]);
+                                gsum[i] = SK_DOT2_T16(hi2, one2, gsum[i]);
+                                gsq[i] = SK_DOT2_T16(lo2, lo2, gsq[i]);
+                                gsq[i] = SK_DOT2_T16(hi2, hi2, gsq[i]);
+                            }
                         }
                         const auto s0 = __builtin_amdgcn_permlane16_swap(d[0][0], d[1][0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(d[0][1], d[1][1], false, false);
                         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                         const u32x4 lv = {s0[0], s1[0], s0[1], s1[1]};
                         const bool sok = x < xb && ovox >= 0;
-                        const unsigned off = (unsigned)(o * (int)out_plane + ovox * a.out_vs + a.cout_off * 2 + 32 * i + 16 * (g >> 1));
+                        // split: the voxel line is [hi (cout) | lo (cout)]: out_vs = 4 cout bytes, the lo halves cout * 2 bytes on
+                        const unsigned off = (unsigned)(o * (int)out_plane + ovox * a.out_vs + part * (a.out_vs / 2) + a.cout_off * 2 +
+                                                        32 * i + 16 * (g >> 1));
                         // always issued (the counted wait below relies on it); a masked lane's offset is out of range: dropped
                         __builtin_amdgcn_raw_buffer_store_b128(lv, rout, sok ? off : sk::kOob, 0, 0);
+                    }
                     }
                 }
                 SK_T(8)   // epilogue
                 if (have_next) {
                     // vmcnt retires in order: everything older than the epilogue's XS * 2 stores -- the LDS-DMA and the
                     // weight fragments -- has landed (conv3_m16_kernel)
-                    constexpr int kStores = XS * 2;
+                    constexpr int kStores = XS * 2 * (SPLIT ? 2 : 1);
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
                 }
             }
@@ -550,16 +589,23 @@ int sk_conv3d_upfold_num_blocks(int ox, int oy, int oz, int cout) {
     return p.npatch * p.nxc;
 }
 
-int64_t sk_conv3d_pack_weight_upfold_host(const float* w, int cout, int c_skip, int c_up, void* dst) {
+static int64_t pack_upfold(const float* w, int cout, int c_skip, int c_up, void* dst, bool split) {
     if ((cout != 32 && cout != 64) || c_skip <= 0 || c_up <= 0 || c_skip % 32 || c_up % 32) {
         sk::set_error("sk_conv3d_pack_weight_upfold_host: unsupported shape cout=%d c_skip=%d c_up=%d", cout, c_skip, c_up);
         return SK_ERR_ARG;
     }
     const int ns = c_skip / 32, nu = c_up / 32, cin = c_skip + c_up;
-    const int64_t nfrag = ((int64_t)ns * kSkipFrags + (int64_t)nu * kUpFrags) * (cout / 32);
+    const int nsets = split ? 2 : 1;   // split: per chunk the lo-weight fragments, then the hi-weight fragments
+    const int64_t nfrag = ((int64_t)ns * kSkipFrags + (int64_t)nu * kUpFrags) * nsets * (cout / 32);
     if (!dst) return nfrag * 1024;
     t16* out = (t16*)dst;
     auto W = [&](int co, int ci, int kx, int ky, int kz) { return w[((((int64_t)co * cin + ci) * 3 + kx) * 3 + ky) * 3 + kz]; };
+    // plain: fp16(v); split set 0: lo = fp16(v - fp16(v)), set 1: hi = fp16(v)
+    auto part = [&](double v, int set) {
+        const t16 hi = (t16)(float)v;
+        if (!split || set == 1) return hi;
+        return (t16)(float)(v - (double)(float)hi);
+    };
     int64_t f = 0;
     // the folded weight of parity p, tap t along an axis sums the kernel taps k (0..2) that read the same low-resolution
     // voxel: p=0: t=0 {0}, t=1 {1,2}; p=1: t=0 {0,1}, t=1 {2}
@@ -568,37 +614,47 @@ int64_t sk_conv3d_pack_weight_upfold_host(const float* w, int cout, int c_skip, 
     for (int cg = 0; cg < cout / 32; ++cg) {   // one fragment set per 32 output channels (= per launch of the kernel)
         // skip chunks: conv3_m16_kernel's order [chunk][dy*3+dz][cout half][dx]; lane l holds W[16 i + (l&15)][c0 + 8 (l>>4) + e]
         for (int ch = 0; ch < ns; ++ch)
-            for (int dydz = 0; dydz < 9; ++dydz)
-                for (int i = 0; i < 2; ++i)
-                    for (int dx = 0; dx < 3; ++dx, ++f)
-                        for (int l = 0; l < 64; ++l)
-                            for (int e = 0; e < 8; ++e)
-                                out[f * 512 + l * 8 + e] =
-                                    (t16)W(32 * cg + 16 * i + (l & 15), ch * 32 + 8 * (l >> 4) + e, dx, dydz / 3, dydz % 3);
-        // upsampled chunks: [chunk][class 2 py + pz][ty*2+tz][cout half][px][tx]
-        for (int ch = 0; ch < nu; ++ch)
-            for (int cls = 0; cls < 4; ++cls)
-                for (int tytz = 0; tytz < 4; ++tytz)
+            for (int set = 0; set < nsets; ++set)
+                for (int dydz = 0; dydz < 9; ++dydz)
                     for (int i = 0; i < 2; ++i)
-                        for (int px = 0; px < 2; ++px)
-                            for (int tx = 0; tx < 2; ++tx, ++f) {
-                                const int py = cls >> 1, pz = cls & 1, ty = tytz >> 1, tz = tytz & 1;
-                                for (int l = 0; l < 64; ++l)
-                                    for (int e = 0; e < 8; ++e) {
-                                        const int co = 32 * cg + 16 * i + (l & 15), ci = c_skip + ch * 32 + 8 * (l >> 4) + e;
-                                        float s = 0.0f;
-                                        for (int kx = lo(px, tx); kx <= hi(px, tx); ++kx)
-                                            for (int ky = lo(py, ty); ky <= hi(py, ty); ++ky)
-                                                for (int kz = lo(pz, tz); kz <= hi(pz, tz); ++kz) s += W(co, ci, kx, ky, kz);
-                                        out[f * 512 + l * 8 + e] = (t16)s;
-                                    }
-                            }
+                        for (int dx = 0; dx < 3; ++dx, ++f)
+                            for (int l = 0; l < 64; ++l)
+                                for (int e = 0; e < 8; ++e)
+                                    out[f * 512 + l * 8 + e] =
+                                        part(W(32 * cg + 16 * i + (l & 15), ch * 32 + 8 * (l >> 4) + e, dx, dydz / 3, dydz % 3), set);
+        // upsampled chunks: [chunk][class 2 py + pz][ty*2+tz][cout half][px][tx]; the fold is summed in double, then split
+        for (int ch = 0; ch < nu; ++ch)
+            for (int set = 0; set < nsets; ++set)
+                for (int cls = 0; cls < 4; ++cls)
+                    for (int tytz = 0; tytz < 4; ++tytz)
+                        for (int i = 0; i < 2; ++i)
+                            for (int px = 0; px < 2; ++px)
+                                for (int tx = 0; tx < 2; ++tx, ++f) {
+                                    const int py = cls >> 1, pz = cls & 1, ty = tytz >> 1, tz = tytz & 1;
+                                    for (int l = 0; l < 64; ++l)
+                                        for (int e = 0; e < 8; ++e) {
+                                            const int co = 32 * cg + 16 * i + (l & 15), ci = c_skip + ch * 32 + 8 * (l >> 4) + e;
+                                            double sacc = 0.0;
+                                            for (int kx = lo(px, tx); kx <= hi(px, tx); ++kx)
+                                                for (int ky = lo(py, ty); ky <= hi(py, ty); ++ky)
+                                                    for (int kz = lo(pz, tz); kz <= hi(pz, tz); ++kz) sacc += (double)W(co, ci, kx, ky, kz);
+                                            out[f * 512 + l * 8 + e] = part(split ? sacc : (double)(float)sacc, set);
+                                        }
+                                }
     }
     return nfrag * 1024;
 }
 
-int sk_conv3d_upfold(const void* skip, int c_skip, const void* up, int c_up, const void* weight, const float* bias,
-                     void* out, int B, int ox, int oy, int oz, int cout, float* gn_partial, void* stream_) {
+int64_t sk_conv3d_pack_weight_upfold_host(const float* w, int cout, int c_skip, int c_up, void* dst) {
+    return pack_upfold(w, cout, c_skip, c_up, dst, false);
+}
+
+int64_t sk_conv3d_pack_weight_upfold_split_host(const float* w, int cout, int c_skip, int c_up, void* dst) {
+    return pack_upfold(w, cout, c_skip, c_up, dst, true);
+}
+
+static int upfold_impl(const void* skip, int c_skip, const void* up, int c_up, const void* weight, const float* bias,
+                       void* out, int B, int ox, int oy, int oz, int cout, float* gn_partial, void* stream_, const bool split) {
     hipStream_t stream = (hipStream_t)stream_;
     SK_CHECK_ARG(skip && up && weight && bias && out, "sk_conv3d_upfold: NULL pointer");
     SK_CHECK_ARG(cout == 32 || cout == 64, "sk_conv3d_upfold: cout must be 32 or 64 (got %d)", cout);
@@ -613,9 +669,10 @@ int sk_conv3d_upfold(const void* skip, int c_skip, const void* up, int c_up, con
     a.up = (const char*)up;
     a.skipC = c_skip;
     a.upC = c_up;
-    a.skip_plane = (long long)oy * oz * c_skip * 2;
+    const int lanes = split ? 2 : 1;   // fp16 values per logical channel in a voxel line: [hi | lo]
+    a.skip_plane = (long long)oy * oz * c_skip * 2 * lanes;
     a.skip_batch = a.skip_plane * ox;
-    a.up_plane = (long long)(oy / 2) * (oz / 2) * c_up * 2;
+    a.up_plane = (long long)(oy / 2) * (oz / 2) * c_up * 2 * lanes;
     a.up_batch = a.up_plane * (ox / 2);
     a.ns = c_skip / 32;
     a.nu = c_up / 32;
@@ -640,24 +697,35 @@ int sk_conv3d_upfold(const void* skip, int c_skip, const void* up, int c_up, con
 #ifdef SK_TIMING
     if (const char* e = getenv("SK_CONV_DBG")) a.dbg = (long long*)strtoull(e, nullptr, 0);
 #endif
-    const bool wlds = a.ns == 1 && p.lds + 12288 <= 80 * 1024;   // two tap rows of the single skip chunk in LDS
-    auto kern = wlds ? conv3_upf_kernel<4, true> : conv3_upf_kernel<4, false>;
+    const bool wlds = !split && a.ns == 1 && p.lds + 12288 <= 80 * 1024;   // two tap rows of the single skip chunk in LDS
+    auto kern = split ? conv3_upf_kernel<4, false, true> : (wlds ? conv3_upf_kernel<4, true, false> : conv3_upf_kernel<4, false, false>);
     const size_t lds = p.lds + (wlds ? 12288 : 0);
     if (lds > 48 * 1024)
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)(p.npatch * p.nxc * B);
     // 32 output channels per launch (COUT 64: two launches over the same inputs -- twice the staging, but on the
     // 16x16x32 matrix instruction and at 70 instead of 108 tap-chunks; measured against conv3_kernel<64> in DESIGN.md)
-    a.out_vs = cout * 2;
+    a.out_vs = cout * 2 * lanes;
     a.pstride = (cout / 4) * 2;
     for (int cg = 0; cg < cout / 32; ++cg) {
         a.cout_off = 32 * cg;
         a.poff = 16 * cg;
-        a.wpk = (const char*)weight + (size_t)cg * (a.ns * kSkipFrags + a.nu * kUpFrags) * 1024;
+        a.wpk = (const char*)weight + (size_t)cg * (a.ns * kSkipFrags + a.nu * kUpFrags) * lanes * 1024;
         kern<<<grid, 256, lds, stream>>>(a);
         SK_CHECK_LAUNCH();
     }
     return SK_OK;
+}
+
+
+int sk_conv3d_upfold(const void* skip, int c_skip, const void* up, int c_up, const void* weight, const float* bias,
+                     void* out, int B, int ox, int oy, int oz, int cout, float* gn_partial, void* stream) {
+    return upfold_impl(skip, c_skip, up, c_up, weight, bias, out, B, ox, oy, oz, cout, gn_partial, stream, false);
+}
+
+int sk_conv3d_upfold_split(const void* skip, int c_skip, const void* up, int c_up, const void* weight, const float* bias,
+                           void* out, int B, int ox, int oy, int oz, int cout, float* gn_partial, void* stream) {
+    return upfold_impl(skip, c_skip, up, c_up, weight, bias, out, B, ox, oy, oz, cout, gn_partial, stream, true);
 }
 
 }  // extern "C"

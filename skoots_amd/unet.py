@@ -65,13 +65,13 @@ class _ConvLayer:
     def weight(self) -> Tensor:
         return self.packed(False)
 
-    def packed_upfold(self, c_skip: int) -> Tensor:
-        """Fragments of ``sk_conv3d_upfold`` (decoder conv, the nearest-upsample of the last ``cin - c_skip`` input
-        channels folded into their weights); packed on first use."""
-        key = ("upfold", c_skip)
+    def packed_upfold(self, c_skip: int, split: bool = False) -> Tensor:
+        """Fragments of ``sk_conv3d_upfold`` / ``sk_conv3d_upfold_split`` (decoder conv, the nearest-upsample of the last
+        ``cin - c_skip`` input channels folded into their weights); packed on first use."""
+        key = ("upfold", c_skip, split)
         t = self._packed.get(key)
         if t is None:
-            fn = _ffi.lib.sk_conv3d_pack_weight_upfold_host
+            fn = _ffi.lib.sk_conv3d_pack_weight_upfold_split_host if split else _ffi.lib.sk_conv3d_pack_weight_upfold_host
             fpt = self._w_cpu.numpy().ctypes.data_as(C.POINTER(C.c_float))
             nbytes = fn(fpt, self.cout, c_skip, self.cin - c_skip, None)
             if nbytes < 0:
@@ -219,7 +219,7 @@ class HipUNet:
         assert cin == layer.cin, (layer.name, cin, layer.cin)
         # decoder conv over cat([skip, upsample(x)]): the folded kernel where it covers the shape (fp16 mode, both
         # sources activated); it has its own workgroup count, hence its own number of partial-sum rows
-        fold = (self.fold_upsample and not split and layer.ksize == 3 and len(srcs) == 2 and bool(srcs[1][1])
+        fold = (self.fold_upsample and layer.ksize == 3 and len(srcs) == 2 and bool(srcs[1][1])
                 and not srcs[0][1] and arr[0].affine is None and arr[1].affine is None)
         nblk = _ffi.lib.sk_conv3d_upfold_num_blocks(ox, oy, oz, layer.cout) if fold else -1
         fold = nblk > 0
@@ -233,9 +233,10 @@ class HipUNet:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
         if fold:
-            _ffi.check(_ffi.lib.sk_conv3d_upfold(arr[0].data, arr[0].c, arr[1].data, arr[1].c,
-                                                 _ffi.ptr(layer.packed_upfold(arr[0].c)), _ffi.ptr(layer.bias), _ffi.ptr(out),
-                                                 B, ox, oy, oz, layer.cout, _ffi.ptr(partial), _ffi.stream_ptr(self.device)))
+            ufn = _ffi.lib.sk_conv3d_upfold_split if split else _ffi.lib.sk_conv3d_upfold
+            _ffi.check(ufn(arr[0].data, arr[0].c, arr[1].data, arr[1].c,
+                           _ffi.ptr(layer.packed_upfold(arr[0].c, split)), _ffi.ptr(layer.bias), _ffi.ptr(out),
+                           B, ox, oy, oz, layer.cout, _ffi.ptr(partial), _ffi.stream_ptr(self.device)))
         else:
             fn = _ffi.lib.sk_conv3d_split if split else _ffi.lib.sk_conv3d
             _ffi.check(fn(arr, len(srcs), _ffi.ptr(layer.packed(split)), _ffi.ptr(layer.bias),
@@ -244,7 +245,7 @@ class HipUNet:
         if timed:
             e1.record(torch.cuda.current_stream(self.device))
             self.profile.events.append((e0, e1, layer.flops_per_out_voxel * B * ox * oy * oz, layer.name))
-            per_voxel = 2.0 * layer.cout * (arr[0].c * 27 + arr[1].c * 8) if fold else layer.flops_per_out_voxel
+            per_voxel = 2.0 * layer.cout * (arr[0].c * 27 + arr[1].c * 8) if fold else layer.flops_per_out_voxel   # x3 in split mode: bench.py
             self.profile.executed_flops += per_voxel * B * ox * oy * oz
         aff = self._norm_act(layer, out, partial, nblk, apply=activate)
         return out if activate else (out, aff)
@@ -588,11 +589,12 @@ def conv3d(srcs: List[Tuple[Tensor, int]], packed_weight: Tensor, bias: Tensor, 
     return out, partial
 
 
-def pack_conv_weight_upfold(weight: Tensor, c_skip: int, device) -> Tensor:
-    """Torch-layout (cout, c_skip + c_up, 3, 3, 3) fp32 weight -> the fragments of ``sk_conv3d_upfold`` on ``device``."""
+def pack_conv_weight_upfold(weight: Tensor, c_skip: int, device, split: bool = False) -> Tensor:
+    """Torch-layout (cout, c_skip + c_up, 3, 3, 3) fp32 weight -> the fragments of ``sk_conv3d_upfold`` (``split``:
+    ``sk_conv3d_upfold_split``) on ``device``."""
     w = weight.detach().float().cpu().contiguous()
     cout, cin = int(w.shape[0]), int(w.shape[1])
-    fn = _ffi.lib.sk_conv3d_pack_weight_upfold_host
+    fn = _ffi.lib.sk_conv3d_pack_weight_upfold_split_host if split else _ffi.lib.sk_conv3d_pack_weight_upfold_host
     fpt = w.numpy().ctypes.data_as(C.POINTER(C.c_float))
     nbytes = fn(fpt, cout, c_skip, cin - c_skip, None)
     if nbytes < 0:
@@ -602,9 +604,11 @@ def pack_conv_weight_upfold(weight: Tensor, c_skip: int, device) -> Tensor:
     return torch.from_numpy(buf).to(device)
 
 
-def conv3d_upfold(skip: Tensor, up: Tensor, packed_weight: Tensor, bias: Tensor, cout: int, want_stats: bool = True):
+def conv3d_upfold(skip: Tensor, up: Tensor, packed_weight: Tensor, bias: Tensor, cout: int, want_stats: bool = True,
+                  split: bool = False):
     """Raw decoder conv over cat([skip, nearest-upsample(up)]) with the upsample folded into the weights:
-    skip (B, x, y, z, c) fp16, up (B, x/2, y/2, z/2, c') fp16 -> ((B, x, y, z, cout) fp16, gn_partial or None)."""
+    skip (B, x, y, z, c) fp16, up (B, x/2, y/2, z/2, c') fp16 -> ((B, x, y, z, cout) fp16, gn_partial or None).
+    ``split``: the tensors are split pairs (..., 2c) (:func:`split_pair`), the weight packed with ``split=True``."""
     _ffi.require_gpu(skip, "skip")
     _ffi.require_gpu(up, "up")
     B, ox, oy, oz = (int(v) for v in skip.shape[:4])
@@ -613,11 +617,12 @@ def conv3d_upfold(skip: Tensor, up: Tensor, packed_weight: Tensor, bias: Tensor,
     nblk = _ffi.lib.sk_conv3d_upfold_num_blocks(ox, oy, oz, cout)
     if nblk <= 0:
         raise ValueError(f"sk_conv3d_upfold does not cover the output shape {(ox, oy, oz)} / cout {cout}")
-    out = torch.empty((B, ox, oy, oz, cout), dtype=torch.float16, device=skip.device)
+    lanes = 2 if split else 1
+    out = torch.empty((B, ox, oy, oz, cout * lanes), dtype=torch.float16, device=skip.device)
     partial = torch.zeros((B, nblk, cout // 4, 2), dtype=torch.float32, device=skip.device) if want_stats else None
-    _ffi.check(_ffi.lib.sk_conv3d_upfold(_ffi.ptr(skip), skip.shape[-1], _ffi.ptr(up), up.shape[-1], _ffi.ptr(packed_weight),
-                                         _ffi.ptr(bias), _ffi.ptr(out), B, ox, oy, oz, cout, _ffi.ptr(partial),
-                                         _ffi.stream_ptr(skip.device)))
+    fn = _ffi.lib.sk_conv3d_upfold_split if split else _ffi.lib.sk_conv3d_upfold
+    _ffi.check(fn(_ffi.ptr(skip), skip.shape[-1] // lanes, _ffi.ptr(up), up.shape[-1] // lanes, _ffi.ptr(packed_weight),
+                  _ffi.ptr(bias), _ffi.ptr(out), B, ox, oy, oz, cout, _ffi.ptr(partial), _ffi.stream_ptr(skip.device)))
     return out, partial
 
 

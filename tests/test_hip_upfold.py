@@ -123,3 +123,30 @@ def test_network_with_and_without_fold():
     model.fold_upsample = True
     assert (a.float() - b.float()).abs().max().item() <= 5e-3
     assert (a.float() - b.float()).pow(2).mean().sqrt().item() <= 5e-4
+
+
+@pytest.mark.parametrize("shape", [(1, (8, 12, 20), 32, 32, 32), (2, (12, 14, 20), 32, 32, 32), (1, (14, 22, 10), 64, 64, 64),
+                                   (1, (8, 8, 12), 32, 64, 32)])
+def test_upfold_split_vs_float64(shape):
+    """precision "split" (hi + lo fp16 pairs, three MFMA phases per logical chunk): against a float64 conv of the SAME
+    pair-representable operands -- the bound test_conv_split_vs_torch holds sk_conv3d_split to (2e-5 of the range)."""
+    from skoots_amd import unet as U
+    B, osp, c_skip, c_up, cout = shape
+    gen = torch.Generator().manual_seed(31 + osp[1])
+    lo = tuple(v // 2 for v in osp)
+    skip = U.join_pair(U.split_pair(_cl(torch.randn((B, c_skip) + osp, generator=gen))))      # what the pair holds exactly
+    up = U.join_pair(U.split_pair(_cl(torch.randn((B, c_up) + lo, generator=gen))))
+    w = torch.randn((cout, c_skip + c_up, 3, 3, 3), generator=gen) / ((c_skip + c_up) * 27) ** 0.5
+    w = U.join_pair(U.split_pair(w.unsqueeze(-1))).squeeze(-1)
+    b = torch.randn(cout, generator=gen) * 0.1
+    x = torch.cat([_cf(skip).double(), F.interpolate(_cf(up).double(), scale_factor=2, mode="nearest")], dim=1)
+    want = F.conv3d(x, w.double(), b.double(), padding=1)
+    got, partial = U.conv3d_upfold(U.split_pair(skip).to(DEV), U.split_pair(up).to(DEV),
+                                   U.pack_conv_weight_upfold(w, c_skip, DEV, split=True), b.to(DEV), cout, split=True)
+    got = _cf(U.join_pair(got.cpu())).double()
+    err = (got - want).abs().max().item()
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), err
+    p = partial.sum(dim=1).cpu().double()
+    wq = want.reshape(B, cout // 4, 4, -1)
+    assert torch.allclose(p[..., 0], wq.sum(dim=(2, 3)), rtol=1e-4, atol=1e-3 * wq.shape[-1] ** 0.5)
+    assert torch.allclose(p[..., 1], (wq ** 2).sum(dim=(2, 3)), rtol=1e-4)
