@@ -287,6 +287,7 @@ def eval_main(args, rank, world, local):
     X, Y, Z = shape
     sv = ShardedVolume(shape, rank, world, dev)
     model = unet.smoke_model(dev)
+    model.fold_upsample = not args.no_fold
     model.precision = args.precision
 
     # ---- synthetic inputs, resident in HBM before the timed region -------------------
@@ -371,7 +372,7 @@ def eval_main(args, rank, world, local):
             "config": {"workload": f"{X}x{Y}x{Z} fp16 volume, 300x300x20 tiles (margin 50,50,5), "
                                    f"U-Net dims [32,64,128,64,32] depths [2,2,2,2,2], N=10 follow, "
                                    f"Z-sharded x{world}", "precision": args.precision,
-                       "tile_batch": args.tile_batch, "streams": args.streams,
+                       "tile_batch": args.tile_batch, "streams": args.streams, "fold_upsample": not args.no_fold,
                        "instances": int(res.get("n_instances", -1)), "blobs_injected": n_blobs,
                        "stage_ms": {k: round(v / args.steps * 1e3, 2) for k, v in sv.timings.items()}},
             "roofline": {"bound": "mfma", "kernel": "conv3_m16_kernel / conv3_kernel / conv3_upf_kernel (all 3x3x3 MFMA conv launches)",
@@ -558,6 +559,7 @@ def main():
     ap.add_argument("--no-inject", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the live parity_vs_fp32_mode measurement")
     ap.add_argument("--streams", type=int, default=1, help="tile batches in flight (HIP streams)")
+    ap.add_argument("--no-fold", action="store_true", help="A/B: decoder convs on the direct kernels instead of sk_conv3d_upfold")
     ap.add_argument("--precision", choices=["fp16", "split", "fp32", "bf16", "mixed"], default=None,
                     help="eval: fp16 (default) | split (<= 1e-3 vs fp32) | fp32; train: bf16 (default) | mixed (fp16) | fp32")
     ap.add_argument("--launcher-dry-run", action="store_true", help=argparse.SUPPRESS)
