@@ -31,8 +31,6 @@
 // v_dot2c) as in conv3_m16_kernel, whose comments explain those parts.
 #include <stdlib.h>
 
-#include <vector>
-
 #include "common.h"
 
 namespace {
