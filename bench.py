@@ -19,7 +19,17 @@ reference's autocast does), "split" (fp16 hi + lo operand pairs: max-abs <= 1e-3
 north_star tolerance) or "fp32" (exact-fp32 MFMA).  Every line states its own measured tolerance
 (``parity_vs_fp32_mode``: the benched precision against the exact-fp32 mode on one production batch).
 
-``--config train``: BASELINE configs[4], one training step on a synthetic 256^3 crop (see train_main).
+``--config train``: BASELINE configs[4], one training step on a synthetic 256^3 crop (see train_measure).
+
+The default N = 1 line (what the driver runs) carries three measurements from ONE process: ``value`` = the fp16 eval
+path (BASELINE's dtype), ``also.split`` = the same volume at the precision that meets north_star's 1e-3 tolerance
+(value, ms_per_step, roofline, parity_vs_fp32_mode measured live) and ``also.train_bf16`` = configs[4] (ms_per_step,
+Mvoxels/s trained, roofline); ``--no-also`` prints the first alone.  ``box`` = a bare-MFMA-loop probe of this device:
+boxes differ by ~6 % under matrix load, figures from two boxes compare only beside it.
+
+``--streams 2`` keeps two tile batches in flight on two HIP streams (the HBM-bound kernels of one batch fill the gaps of
+the other's MFMA-bound convs).  Overlapping launches make per-launch durations meaningless, so ``roofline`` is then
+measured in the single-stream warm-up steps (``roofline.timed_over`` says which steps it covers).
 
 Synthetic data: uint8-range random image, random-init network of the named shape
 (DIMS [32,64,128,64,32], DEPTHS [2,2,2,2,2]).  A random-init net never crosses the 0.8
@@ -56,11 +66,15 @@ def workload_shape(n_gpus: int):
             8: (2048, 2048, 512)}.get(n_gpus, (1024, 1024, 256 * n_gpus))
 
 
-def device_blob_field(shape, z_window, device, seed=0, pitch=(64, 64, 16)):
+def device_blob_field(shape, z_window, device, seed=0, pitch=(64, 64, 16), dense=False):
     """Blob field of tests/workload.py generated directly on the device for the local
     z-window: one ellipsoid per (64,64,16) lattice cell (jittered centre and radii), prob
     0.95 inside, vectors pointing at the centre / SCALE, skeleton ball at the centre.
-    Returns (5, X, Y, zw) fp16 and the number of blobs in the whole volume."""
+    Returns (5, X, Y, zw) fp16 and the number of blobs in the whole volume.
+
+    ``dense``: the worst case of the follow kernel instead of the ~94 %-background field: EVERY voxel of a cell is
+    gated in and carries a non-zero vector -- half the pull towards the cell's centre plus a swirl around it, never
+    exactly zero -- so every voxel makes all nine dependent hops of N = 10, each to a different voxel."""
     X, Y, Z = shape
     z0, z1 = z_window
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -89,6 +103,11 @@ def device_blob_field(shape, z_window, device, seed=0, pitch=(64, 64, 16)):
         inside = (dx / rx[I]) ** 2 + (dy / ry[I]) ** 2 + (dz / rz[I]) ** 2 <= 1.0
         core = (dx * dx + dy * dy + dz * dz <= 2.5) & inside
         o = out[:, xa:xb]
+        if dense:
+            inside = torch.ones_like(inside)
+            eps = 0.26   # a quarter voxel: the vector is never zero, the follow never reaches its fixed-point exit
+            vx, vy, vz = 0.5 * dx - 0.5 * dy + eps, 0.5 * dy + 0.5 * dx + eps, 0.5 * dz + eps
+            dx, dy, dz = vx, vy, vz.expand_as(vx)
         o[0] = torch.where(inside, (dx / SCALE[0]).clamp(-1, 1), 0).half()
         o[1] = torch.where(inside, (dy / SCALE[1]).clamp(-1, 1), 0).half()
         o[2] = torch.where(inside, (dz / SCALE[2]).clamp(-1, 1), 0).half()
@@ -170,24 +189,105 @@ def cpu_baseline(budget_s: float = 8.0):
                       f"configs[0] 128x128x32 (100 tiles, 62x overcompute) measured the same way"}
 
 
-def conv_hbm_traffic():
-    """HBM bytes per conv3 launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    in separate runs of the same launch shapes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).
-    bench.py cannot collect PMC counters itself; returns (None, None) when no profile is committed."""
-    for name in ("r02_conv_hbm_traffic_pmc_v3.json", "r02_conv_hbm_traffic_pmc_v2.json", "r02_conv_hbm_traffic_pmc.json", "r01_conv_hbm_traffic_pmc.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        try:
-            prof = json.load(open(path))
-        except OSError:
-            continue
-        tot, n = 0.0, 0
-        for k in prof["kernels"]:
-            if any(n in k["kernel"] for n in ("conv3_kernel", "conv3_m16_kernel", "conv3_upf_kernel")):
-                tot += (k["fetch_MB_per_launch_x2_gfx950_correction"] + k["write_MB_per_launch"]) * k["launches"]
-                n += k["launches"]
-        if n:
-            return round(tot / n * 1024 * 1024), name
-    return None, None
+def _newest_profile(stem):
+    """profiles/rNN_<stem>[_vK].json with the highest (round, version); None when none is committed."""
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", f"r??_{stem}*.json")):
+        m = re.match(rf"r(\d+)_{stem}(?:_v(\d+))?\.json$", os.path.basename(path))
+        if m:
+            key = (int(m.group(1)), int(m.group(2) or 1))
+            if best is None or key > best[0]:
+                best = (key, path)
+    return best[1] if best else None
+
+
+def conv_hbm_traffic(tile_batch):
+    """HBM bytes per conv3 launch of ``tile_batch`` tiles from the newest committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs of the same launch shapes, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md's gfx950 note; tools/pmc_collect.sh).  A profile taken at another batch size is scaled per
+    tile and the source says so.  bench.py cannot collect PMC counters itself; (None, None) when nothing is committed."""
+    import re
+    path = _newest_profile("conv_hbm_traffic_pmc")
+    if path is None:
+        return None, None
+    prof = json.load(open(path))
+    m = re.search(r"--batch (\d+)", prof.get("command", ""))
+    pbatch = int(prof.get("batch") or (m.group(1) if m else 8))
+    tot, n = 0.0, 0
+    for k in prof["kernels"]:
+        if any(nm in k["kernel"] for nm in ("conv3_kernel", "conv3_m16_kernel", "conv3_upf_kernel", "conv3_px_kernel")):
+            tot += (k["fetch_MB_per_launch_x2_gfx950_correction"] + k["write_MB_per_launch"]) * k["launches"]
+            n += k["launches"]
+    if not n:
+        return None, None
+    src = os.path.basename(path) + ("" if pbatch == tile_batch else f", collected at {pbatch} tiles per launch and scaled per tile")
+    return round(tot / n * 1024 * 1024 / pbatch * tile_batch), src
+
+
+def stage_hbm_traffic():
+    """{kernel-name substring: bytes per launch} of the stage 2-3 kernels at 1024x1024x256 from the newest committed
+    PMC passes over tools/bench_stages.py (tools/pmc_stages.sh); {} when nothing is committed."""
+    path = _newest_profile("stage23_hbm_traffic_pmc")
+    if path is None:
+        return {}, None
+    prof = json.load(open(path))
+    return prof.get("stages", {}), os.path.basename(path)
+
+
+def stage_rooflines(sprof):
+    """HBM-bound stages.  ``achieved`` = ALGORITHMIC bytes / HIP-event kernel time; ``traffic`` = HBM-side
+    bytes per step of the stage's kernels from the committed PMC passes (same volume, same blob field), and when it is
+    there ``frac`` is the MEASURED byte rate against the 8 TB/s peak (``frac_algorithmic`` keeps the other one): the
+    algorithmic count overstates a sparse field -- a background voxel of the follow kernel moves ~16 B, not 64."""
+    out = {}
+    measured, src = stage_hbm_traffic()
+    names = {"gate_dilate_scatter": "roofline_gate", "ccl": "roofline_ccl", "follow_assign": "roofline_assign"}
+    per_voxel = {"gate_dilate_scatter": 17, "ccl": 9, "follow_assign": 64}
+    for kname, (kms, kbytes, kn) in sprof.totals().items():
+        gbs = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        e = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": kn,
+             "avg_launch_ms": round(kms / max(kn, 1), 4), "algorithmic_bytes_per_voxel": per_voxel[kname]}
+        m = measured.get(kname)
+        nsteps = kbytes / m["algorithmic_bytes_per_step"] if m else 0.0
+        if m and kms > 0 and nsteps >= 0.99 and abs(nsteps - round(nsteps)) < 0.01:   # the profiled volume is this volume
+            steps = round(nsteps)
+            e["traffic"] = int(m["bytes_per_step"])
+            mg = m["bytes_per_step"] * steps / (kms * 1e-3) / 1e9
+            e["frac_algorithmic"] = e["frac"]
+            e["achieved_measured"] = round(mg, 1)
+            e["frac"] = round(mg / HBM_PEAK_GBS, 4)
+            e["traffic_unit"] = f"HBM-side bytes per step (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{src}); frac = measured bytes / time / peak"
+        out[names[kname]] = e
+    return out
+
+
+def box_probe(dev):
+    """Rate of a bare MFMA register loop on this device (sk_mfma_probe), printed next to the line: MI355X boxes hold
+    different clocks under matrix load (the same code read 548-580 Mvox/s across boxes in round 2), so a figure from
+    another box is comparable only beside this one.  ``band``: this device against the 1 900 TFLOP/s the loop sustained
+    on the boxes of rounds 1-2 (tools/mfma_shape_probe.hip)."""
+    import ctypes as C
+    from skoots_amd import _ffi
+    scratch = torch.empty(512 * 256, dtype=torch.float32, device=dev)
+    fl = C.c_double(0.0)
+    st = _ffi.stream_ptr(dev)
+    best = 0.0
+    for rep in range(4):   # first launch warms the clocks
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(dev))
+        _ffi.check(_ffi.lib.sk_mfma_probe(_ffi.ptr(scratch), scratch.numel() * 4, 20000, C.byref(fl), st))
+        e1.record(torch.cuda.current_stream(dev))
+        e1.synchronize()
+        if rep:
+            best = max(best, fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    nominal = 1900.0
+    r = best / nominal
+    return {"mfma_probe_tflops": round(best, 1), "probe": "bare v_mfma_f32_16x16x32_f16 loop, 2 waves per SIMD, every CU (sk_mfma_probe)",
+            "vs_nominal_1900": round(r, 3), "band": "slow" if r < 0.97 else ("fast" if r > 1.03 else "typical"),
+            "device": torch.cuda.get_device_name(dev)}
 
 
 def log(msg):
@@ -263,6 +363,9 @@ def parity_vs_fp32_mode(model, image, origins, eff, mean, std, out_box, precisio
 
 
 def eval_main(args, rank, world, local):
+    """The headline line.  At N = 1 the same process then times, on the same resident volume, the precision that
+    meets north_star's 1e-3 tolerance (``also.split``) and one training leg (``also.train_bf16``, configs[4]) --
+    the driver's command prints one line and that line carries all three (``--no-also`` skips them)."""
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")
@@ -280,7 +383,7 @@ def eval_main(args, rank, world, local):
             dist.init_process_group(backend)
 
     from skoots_amd import unet
-    from skoots_amd.parallel import ShardedVolume
+    from skoots_amd.parallel import ShardedVolume, tile_plan
     from skoots_amd.profile import KernelProfile
 
     shape = tuple(int(v) for v in args.shape.split(",")) if args.shape else workload_shape(world)
@@ -288,7 +391,6 @@ def eval_main(args, rank, world, local):
     sv = ShardedVolume(shape, rank, world, dev)
     model = unet.smoke_model(dev)
     model.fold_upsample = not args.no_fold
-    model.precision = args.precision
 
     # ---- synthetic inputs, resident in HBM before the timed region -------------------
     zlo, zhi = sv.window  # local z-window (slab + halo)
@@ -307,121 +409,156 @@ def eval_main(args, rank, world, local):
         x, y, z = origin
         return inject_vol[:, x:x + eff[0], y:y + eff[1], z:z + eff[2]]  # strided view: no copy
 
-    def step(prof=None, sprof=None):
-        return sv.run(image, model, SCALE, mean, std, tile_batch=args.tile_batch, inject=inject,
-                      conv_profile=prof, streams=args.streams, stage_profile=sprof)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    log(f"inputs resident: volume {shape}, window {sv.window}, {n_blobs} blobs; warm-up x{args.warmup}")
-    for _ in range(args.warmup):
-        res = step()
-        log(f"warm-up step done: {sv.timings}")
-    sv.timings.clear()
-    sv.comm._acct.clear()
-    barrier()
-    prof, sprof = unet.ConvProfile(), KernelProfile()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step(prof, sprof)
-    barrier()
-    dt = time.perf_counter() - t0
-    log(f"timed {args.steps} steps in {dt:.3f} s")
-    comm_stats = sv.comm.stats()
-    tiles = sv.tiles_this_rank
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        # per-rank tile counts and communication time (max over ranks: the slowest rank sets the step time)
-        tl = torch.tensor([tiles], dtype=torch.int64, device=dev)
-        gathered = [torch.zeros_like(tl) for _ in range(world)]
-        dist.all_gather(gathered, tl)
-        tiles = [int(v.item()) for v in gathered]
-        keys = sorted(comm_stats)
-        ms = torch.tensor([comm_stats[k]["ms"] for k in keys], dtype=torch.float64, device=dev)
-        dist.all_reduce(ms, op=dist.ReduceOp.MAX)
-        for k, v in zip(keys, ms.tolist()):
-            comm_stats[k]["ms_max_over_ranks"] = round(v, 3)
+    probe = box_probe(dev) if rank == 0 else None
 
-    if rank == 0:
-        ms = dt / args.steps * 1e3
-        voxels = X * Y * Z
-        conv_ms, conv_flops, conv_launches = prof.totals()
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        executed = prof.executed_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        traffic, traffic_src = conv_hbm_traffic()
-        per_layer = {}
-        for e0, e1, fl, name in prof.named():
-            d = per_layer.setdefault(name, [0.0, 0.0, 0])
-            d[0] += e0.elapsed_time(e1)
-            d[1] += fl
-            d[2] += 1
-        layers = {k: {"tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1), "avg_launch_ms": round(v[0] / v[2], 4)}
-                  for k, v in per_layer.items() if v[0] > 0}
-        line = {
-            "metric": "Mvoxels/s end-to-end (3D U-Net fwd + instance assign)",
-            "value": round(voxels / (dt / args.steps) / 1e6, 3), "unit": "Mvoxels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp16": "f16", "split": "f16 hi+lo pairs (3 MFMA products, f32 accumulate)", "fp32": "f32"}[args.precision],
-            "data": "synthetic",
-            "config": {"workload": f"{X}x{Y}x{Z} fp16 volume, 300x300x20 tiles (margin 50,50,5), "
-                                   f"U-Net dims [32,64,128,64,32] depths [2,2,2,2,2], N=10 follow, "
-                                   f"Z-sharded x{world}", "precision": args.precision,
-                       "tile_batch": args.tile_batch, "streams": args.streams, "fold_upsample": not args.no_fold,
-                       "instances": int(res.get("n_instances", -1)), "blobs_injected": n_blobs,
-                       "stage_ms": {k: round(v / args.steps * 1e3, 2) for k, v in sv.timings.items()}},
-            "roofline": {"bound": "mfma", "kernel": "conv3_m16_kernel / conv3_kernel / conv3_upf_kernel (all 3x3x3 MFMA conv launches)",
-                         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic if args.precision == "fp16" else None,
-                         # the two decoder convs over [skip, upsample(x)] run with the upsample folded into the weights
-                         # (8 of 27 taps for the upsampled channels): the pipe executes fewer FLOPs than the algorithm counts
-                         "executed": round(executed, 2), "frac_executed": round(executed / MFMA_PEAK_TFLOPS, 4),
-                         "traffic_unit": f"bytes per launch (PMC, profiles/{traffic_src})",
-                         "launches": conv_launches, "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
-                         "flops_counted": "achieved: algorithmic 2*Cin*Cout*27 per output voxel, the conv as the reference states it "
-                                          "(split mode issues 3x that on the MFMA pipe); executed: what the launches issue (fp16 mode: "
-                                          "dec0.0 / dec1.0 fold the nearest-upsample into the weights, 35 of 54 tap-chunks); "
-                                          "dec0.1's launches also contain the GroupNorm + SiLU of their input (fused, fp16 mode)",
-                         "layers": layers},
-        }
-        if args.precision == "fp32":  # the MFMA conv profile only instruments the fp16 / split kernels
-            line["roofline"] = None
-        # HBM-bound stages: algorithmic bytes / HIP-event kernel time vs the 8 TB/s peak
-        names = {"gate_dilate_scatter": "roofline_gate", "ccl": "roofline_ccl", "follow_assign": "roofline_assign"}
-        for kname, (kms, kbytes, kn) in sprof.totals().items():
-            gbs = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-            line[names[kname]] = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                                  "launches": kn, "avg_launch_ms": round(kms / max(kn, 1), 4),
-                                  "algorithmic_bytes_per_voxel": {"gate_dilate_scatter": 17, "ccl": 9, "follow_assign": 64}[kname]}
+    def measure(precision, steps, warmup, streams):
+        """W untimed + K timed steps of the whole path at ``precision``; returns rank 0's line (None elsewhere)."""
+        model.precision = precision
+
+        def step(prof=None, sprof=None, nstreams=1):
+            return sv.run(image, model, SCALE, mean, std, tile_batch=args.tile_batch, inject=inject,
+                          conv_profile=prof, streams=nstreams, stage_profile=sprof)
+
+        log(f"[{precision}] volume {shape}, window {sv.window}, {n_blobs} blobs; warm-up x{warmup}")
+        # The warm-up steps run on ONE stream with the per-launch HIP events on: every conv launch then has the device
+        # to itself and its duration is a kernel duration -- the `roofline` figures come from these steps when the timed
+        # steps keep two tile batches in flight (overlapping launches make per-launch durations meaningless).
+        prof, sprof = unet.ConvProfile(), KernelProfile()
+        res = None
+        cold = 1 if warmup > 1 else 0   # the first step of a process allocates its buffers: not profiled when there are others
+        for i in range(warmup):
+            on = streams > 1 and i >= cold
+            res = step(prof if on else None, sprof if on else None)
+            log(f"warm-up step done: {sv.timings}")
+        roof_steps, roof_src = warmup - cold, "single-stream warm-up steps"
+        sv.timings.clear()
+        sv.comm._acct.clear()
+        barrier()
+        if streams == 1 or warmup == 0:
+            prof, sprof = unet.ConvProfile(), KernelProfile()
+            roof_steps, roof_src = steps, "timed steps"
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step(prof, sprof, streams) if streams == 1 or warmup == 0 else step(None, None, streams)
+        barrier()
+        dt = time.perf_counter() - t0
+        log(f"[{precision}] timed {steps} steps in {dt:.3f} s")
+        comm_stats = sv.comm.stats()
+        tiles = sv.tiles_this_rank
         if world > 1:
-            line["multi_gpu"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
-                                 "tiles_per_rank": tiles, "slab_planes": [b - a for a, b in sv.slabs],
-                                 "comm_rank0_per_step": {k: {"bytes": v["bytes"] // args.steps,
-                                                             "ms": round(v["ms"] / args.steps, 3),
-                                                             "ms_max_over_ranks": round(v.get("ms_max_over_ranks", v["ms"]) / args.steps, 3),
-                                                             "calls": v["calls"] // args.steps}
-                                                         for k, v in comm_stats.items()}}
-    if not args.no_parity:
-        # every rank runs it (same launches everywhere keeps the ranks in step); rank 0 reports
-        from skoots_amd.parallel import tile_plan
-        plan, eff = tile_plan(shape, (300, 300, 20), (50, 50, 5), world)
-        mine = plan[rank][:8]
-        reach, ov = (3, 3, 1), (50, 50, 5)
-        box = ([max(0, o - r) for o, r in zip(ov, reach)], [min(s, s - o + r) for s, o, r in zip(eff, ov, reach)])
-        par = parity_vs_fp32_mode(model, image, [(x, y, z - zlo) for (x, y, z) in mine], eff, mean, std, box,
-                                  args.precision)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            # per-rank tile counts and communication time (max over ranks: the slowest rank sets the step time)
+            tl = torch.tensor([tiles], dtype=torch.int64, device=dev)
+            gathered = [torch.zeros_like(tl) for _ in range(world)]
+            dist.all_gather(gathered, tl)
+            tiles = [int(v.item()) for v in gathered]
+            keys = sorted(comm_stats)
+            cms = torch.tensor([comm_stats[k]["ms"] for k in keys], dtype=torch.float64, device=dev)
+            dist.all_reduce(cms, op=dist.ReduceOp.MAX)
+            for k, v in zip(keys, cms.tolist()):
+                comm_stats[k]["ms_max_over_ranks"] = round(v, 3)
+        line = None
         if rank == 0:
-            line["parity_vs_fp32_mode"] = par
+            ms = dt / steps * 1e3
+            voxels = X * Y * Z
+            conv_ms, conv_flops, conv_launches = prof.totals()
+            achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+            executed = prof.executed_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+            traffic, traffic_src = conv_hbm_traffic(args.tile_batch)
+            per_layer = {}
+            for e0, e1, fl, name in prof.named():
+                d = per_layer.setdefault(name, [0.0, 0.0, 0])
+                d[0] += e0.elapsed_time(e1)
+                d[1] += fl
+                d[2] += 1
+            layers = {k: {"tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1), "avg_launch_ms": round(v[0] / v[2], 4)}
+                      for k, v in per_layer.items() if v[0] > 0}
+            line = {
+                "metric": "Mvoxels/s end-to-end (3D U-Net fwd + instance assign)",
+                "value": round(voxels / (dt / steps) / 1e6, 3), "unit": "Mvoxels/s",
+                "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": {"fp16": "f16", "split": "f16 hi+lo pairs (3 MFMA products, f32 accumulate)", "fp32": "f32"}[precision],
+                "data": "synthetic",
+                "config": {"workload": f"{X}x{Y}x{Z} fp16 volume, 300x300x20 tiles (margin 50,50,5), "
+                                       f"U-Net dims [32,64,128,64,32] depths [2,2,2,2,2], N=10 follow, "
+                                       f"Z-sharded x{world}", "precision": precision,
+                           "tile_batch": args.tile_batch, "streams": streams, "fold_upsample": not args.no_fold,
+                           "instances": int(res.get("n_instances", -1)), "blobs_injected": n_blobs,
+                           "stage_ms": {k: round(v / steps * 1e3, 2) for k, v in sv.timings.items()}},
+                "roofline": {"bound": "mfma", "kernel": "conv3_m16_kernel / conv3_kernel / conv3_upf_kernel (all 3x3x3 MFMA conv launches)",
+                             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic if precision == "fp16" else None,
+                             # the two decoder convs over [skip, upsample(x)] run with the upsample folded into the weights
+                             # (8 of 27 taps for the upsampled channels): the pipe executes fewer FLOPs than the algorithm counts
+                             "executed": round(executed, 2), "frac_executed": round(executed / MFMA_PEAK_TFLOPS, 4),
+                             "traffic_unit": f"bytes per launch of {args.tile_batch} tiles (PMC, profiles/{traffic_src})",
+                             "launches": conv_launches, "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
+                             "timed_over": f"{roof_steps} {roof_src} (HIP events around every conv launch, one stream)",
+                             "flops_counted": "achieved: algorithmic 2*Cin*Cout*27 per output voxel, the conv as the reference states it "
+                                              "(split mode issues 3x that on the MFMA pipe); executed: what the launches issue (fp16 mode: "
+                                              "dec0.0 / dec1.0 fold the nearest-upsample into the weights, 35 of 54 tap-chunks); "
+                                              "dec0.1's launches also contain the GroupNorm + SiLU of their input (fused, fp16 mode)",
+                             "layers": layers},
+            }
+            if precision == "fp32":  # the MFMA conv profile only instruments the fp16 / split kernels
+                line["roofline"] = None
+            line.update(stage_rooflines(sprof))
+            if world > 1:
+                line["multi_gpu"] = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                                     "tiles_per_rank": tiles, "slab_planes": [b - a for a, b in sv.slabs],
+                                     "comm_rank0_per_step": {k: {"bytes": v["bytes"] // steps,
+                                                                 "ms": round(v["ms"] / steps, 3),
+                                                                 "ms_max_over_ranks": round(v.get("ms_max_over_ranks", v["ms"]) / steps, 3),
+                                                                 "calls": v["calls"] // steps}
+                                                             for k, v in comm_stats.items()}}
+        if not args.no_parity:
+            # every rank runs it (same launches everywhere keeps the ranks in step); rank 0 reports
+            plan, eff = tile_plan(shape, (300, 300, 20), (50, 50, 5), world)
+            mine = plan[rank][:8]
+            reach, ov = (3, 3, 1), (50, 50, 5)
+            box = ([max(0, o - r) for o, r in zip(ov, reach)], [min(s, s - o + r) for s, o, r in zip(eff, ov, reach)])
+            par = parity_vs_fp32_mode(model, image, [(x, y, z - zlo) for (x, y, z) in mine], eff, mean, std, box, precision)
+            if rank == 0:
+                line["parity_vs_fp32_mode"] = par
+        return line
+
+    line = measure(args.precision, args.steps, args.warmup, args.streams)
+    also = {}
+    if world == 1 and not args.no_also and args.precision == "fp16":
+        # the precision that meets north_star's tolerance, same volume, same process
+        sp = measure("split", args.also_steps, 1, args.streams)
+        also["split"] = {k: sp[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "parity_vs_fp32_mode")
+                         if k in sp}
+        also["split"]["roofline"] = {k: sp["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "executed",
+                                                                      "frac_executed", "launches", "avg_launch_ms", "timed_over")}
+        also["split"]["roofline"]["note"] = ("achieved = ALGORITHMIC FLOPs (2*Cin*Cout*27) / conv time; the split mode issues three fp16 "
+                                             "MFMA products per algorithmic product, `executed` counts them")
+        also["split"]["stage_ms"] = sp["config"]["stage_ms"]
     if rank == 0:
+        line["box"] = probe
         if not args.no_cpu_baseline and world == 1:
             log("timing the CPU restatement (bounded sample)")
             line["cpu_baseline"] = cpu_baseline(args.cpu_budget)
+    if world == 1 and not args.no_also and args.precision == "fp16":
+        del sv, model, image, inject_vol
+        torch.cuda.empty_cache()
+        targs = argparse.Namespace(**vars(args))
+        targs.precision, targs.steps, targs.warmup, targs.no_cpu_baseline = "bf16", args.also_train_steps, 2, True
+        targs.shape = args.also_train_shape
+        tr = train_measure(targs, rank, world, dev)
+        also["train_bf16"] = {k: tr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline")}
+        also["train_bf16"]["config"] = tr["config"]
+    if rank == 0:
+        if also:
+            line["also"] = also
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -459,9 +596,6 @@ def train_cpu_baseline(crop=(64, 64, 64), budget_s: float = 8.0):
 
 
 def train_main(args, rank, world, local):
-    """One training step of BASELINE configs[4] (skoots/train/engine.py:456-499: forward, three Tversky terms incl.
-    the embedding loss, backward, AdamW) on a synthetic 256^3 crop, batch 1 per GPU, random-init U-Net; N > 1 =
-    data-parallel replicas with one all-reduce of the flat gradient buffer per step (engine.py:113-115)."""
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")
@@ -472,6 +606,19 @@ def train_main(args, rank, world, local):
         if ndev < world:
             raise SystemExit(f"WORLD_SIZE={world} but only {ndev} device(s) visible")
         dist.init_process_group("nccl", device_id=dev)
+    line = train_measure(args, rank, world, dev)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_measure(args, rank, world, dev):
+    """One training step of BASELINE configs[4] (skoots/train/engine.py:456-499: forward, three Tversky terms incl.
+    the embedding loss, backward, AdamW) on a synthetic 256^3 crop, batch 1 per GPU, random-init U-Net; N > 1 =
+    data-parallel replicas with one all-reduce of the flat gradient buffer per step (engine.py:113-115).
+    Returns rank 0's line (None on the other ranks)."""
     from skoots_amd.profile import KernelProfile
     from skoots_amd.train import TrainStep, TrainUNet
     from skoots_amd.unet import random_state_dict
@@ -512,6 +659,7 @@ def train_main(args, rank, world, local):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    line = None
     if rank == 0:
         ms = dt / args.steps * 1e3
         line = {"metric": "training Mvoxels/s (U-Net fwd + Tversky/embedding loss + bwd + AdamW)",
@@ -540,10 +688,7 @@ def train_main(args, rank, world, local):
         if not args.no_cpu_baseline and world == 1:
             log("timing the CPU restatement of the training step (bounded sample)")
             line["cpu_baseline"] = train_cpu_baseline(budget_s=args.cpu_budget)
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return line
 
 
 def main():
@@ -562,6 +707,11 @@ def main():
     ap.add_argument("--no-fold", action="store_true", help="A/B: decoder convs on the direct kernels instead of sk_conv3d_upfold")
     ap.add_argument("--precision", choices=["fp16", "split", "fp32", "bf16", "mixed"], default=None,
                     help="eval: fp16 (default) | split (<= 1e-3 vs fp32) | fp32; train: bf16 (default) | mixed (fp16) | fp32")
+    ap.add_argument("--no-also", action="store_true",
+                    help="N = 1 fp16 eval line only: skip the `also` legs (split precision on the same volume, one bf16 training leg)")
+    ap.add_argument("--also-steps", type=int, default=3, help="timed steps of the split-precision leg")
+    ap.add_argument("--also-train-steps", type=int, default=5, help="timed steps of the training leg")
+    ap.add_argument("--also-train-shape", type=str, default="", help="X,Y,Z of the training leg's crop (default 256,256,256)")
     ap.add_argument("--launcher-dry-run", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds of stage-1 CPU work in the cpu_baseline sample")
     args = ap.parse_args()

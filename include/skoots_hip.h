@@ -485,6 +485,21 @@ int sk_mask_iou(const int32_t* gt, const int32_t* pred, int64_t n, const int32_t
                 const int32_t* lut_pred, int max_pred, int M, float* iou, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * Diagnostics (no reference counterpart; not on the hot path)
+ * ------------------------------------------------------------------------ */
+
+/* Box probe: one launch of a bare v_mfma_f32_16x16x32_f16 register loop (512 workgroups of 4 waves, `iters` x 8
+ * MFMAs per wave, non-trivial operands).  The caller times it with events on `stream`; *flops (host, may be NULL)
+ * receives the FLOPs of the launch.  bench.py prints the rate next to its line: devices hold different clocks under
+ * matrix load, so figures from two boxes are comparable only beside it.  scratch: >= 512 KiB of device memory. */
+int sk_mfma_probe(void* scratch, size_t scratch_bytes, int iters, double* flops, void* stream);
+
+/* Phase-timing builds (-DSK_TIMING, tools/conv_phase_timing.py) dump per-wave cycle sums of the conv kernels into
+ * this device buffer, [4096 workgroups][4 waves][16 slots] int64 (bytes must cover all of it); NULL detaches it.
+ * The release library stores the pointer and never writes through it. */
+int sk_debug_set_timing_buffer(void* device_ptr, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,13 @@ namespace sk {
 
 void set_error(const char* fmt, ...);
 
+// -DSK_TIMING builds only: where the conv kernels dump their per-wave phase cycle sums (sk_debug_set_timing_buffer).
+// One record layout for every kernel: [4096 workgroups][4 waves][kTimingSlots] int64; a launch whose buffer is absent or
+// smaller than that does not dump.
+constexpr int kTimingSlots = 16;
+constexpr int kTimingBlocks = 4096;
+long long* timing_buffer();
+
 #define SK_CHECK_ARG(cond, ...)            \
     do {                                   \
         if (!(cond)) {                     \

@@ -91,10 +91,10 @@ struct Conv3Args {
 // it loses what the conv's stores leave in the Infinity Cache; net zero, not used)
 // Phase timing (tools/conv_phase_timing.py, -DSK_TIMING build only): per wave, cycles between the marks of a phase
 #ifdef SK_TIMING
-#define SK_T_DECL long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tprev_ = __builtin_readcyclecounter();
+#define SK_T_DECL long long tacc_[sk::kTimingSlots] = {0}; long long tprev_ = __builtin_readcyclecounter();
 #define SK_T(i) { const long long t_ = __builtin_readcyclecounter(); tacc_[i] += t_ - tprev_; tprev_ = t_; }
-#define SK_T_DUMP(a, w, lane) if ((a).dbg && blockIdx.x < 4096 && (lane) == 0) { \
-        for (int i_ = 0; i_ < 8; ++i_) (a).dbg[((long long)blockIdx.x * 4 + (w)) * 8 + i_] = tacc_[i_]; }
+#define SK_T_DUMP(a, w, lane) if ((a).dbg && blockIdx.x < sk::kTimingBlocks && (w) < 4 && (lane) == 0) { \
+        for (int i_ = 0; i_ < sk::kTimingSlots; ++i_) (a).dbg[((long long)blockIdx.x * 4 + (w)) * sk::kTimingSlots + i_] = tacc_[i_]; }
 #else
 #define SK_T_DECL
 #define SK_T(i)
@@ -1904,7 +1904,7 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
         a.alt = (!split && a.nchunks == 2) ? 1 : 0;
         a.dbg = nullptr;
 #ifdef SK_TIMING
-        if (const char* e = getenv("SK_CONV_DBG")) a.dbg = (long long*)strtoull(e, nullptr, 0);
+        a.dbg = sk::timing_buffer();
 #endif
         a.ablate = 0;
 #ifdef SK_TUNING

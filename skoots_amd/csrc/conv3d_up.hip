@@ -66,10 +66,10 @@ struct UpfArgs {
 
 // Phase timing (-DSK_TIMING build only): per wave, cycles between the marks of a phase
 #ifdef SK_TIMING
-#define SK_T_DECL long long tacc_[16] = {0}; long long tprev_ = __builtin_readcyclecounter();
+#define SK_T_DECL long long tacc_[sk::kTimingSlots] = {0}; long long tprev_ = __builtin_readcyclecounter();
 #define SK_T(i) { const long long t_ = __builtin_readcyclecounter(); tacc_[i] += t_ - tprev_; tprev_ = t_; }
-#define SK_T_DUMP(a, w, lane) if ((a).dbg && blockIdx.x < 4096 && (lane) == 0) { \
-        for (int i_ = 0; i_ < 16; ++i_) (a).dbg[((long long)blockIdx.x * 4 + (w)) * 16 + i_] = tacc_[i_]; }
+#define SK_T_DUMP(a, w, lane) if ((a).dbg && blockIdx.x < sk::kTimingBlocks && (w) < 4 && (lane) == 0) { \
+        for (int i_ = 0; i_ < sk::kTimingSlots; ++i_) (a).dbg[((long long)blockIdx.x * 4 + (w)) * sk::kTimingSlots + i_] = tacc_[i_]; }
 #else
 #define SK_T_DECL
 #define SK_T(i)
@@ -693,7 +693,7 @@ static int upfold_impl(const void* skip, int c_skip, const void* up, int c_up, c
     a.nposl = p.nposl;
     a.dbg = nullptr;
 #ifdef SK_TIMING
-    if (const char* e = getenv("SK_CONV_DBG")) a.dbg = (long long*)strtoull(e, nullptr, 0);
+    a.dbg = sk::timing_buffer();
 #endif
     const bool wlds = !split && a.ns == 1 && p.lds + 12288 <= 80 * 1024;   // two tap rows of the single skip chunk in LDS
     auto kern = split ? conv3_upf_kernel<4, false, true> : (wlds ? conv3_upf_kernel<4, true, false> : conv3_upf_kernel<4, false, false>);

@@ -1,0 +1,42 @@
+// Box probe: a bare v_mfma_f32_16x16x32_f16 register loop on non-trivial operands, every CU busy at two waves per SIMD.
+// bench.py times one launch with HIP events and prints the rate beside its numbers: MI355X devices hold different
+// clocks under matrix load (MI355X_MICROARCH.md, DVFS give-back item 5: 12 % apart for a loop without memory traffic),
+// so end-to-end figures from two boxes are only comparable next to this figure.  Not on the hot path; no reference
+// counterpart.
+#include "common.h"
+
+namespace {
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256, 2) mfma_probe_kernel(float* out, int iters) {
+    half8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {   // values in (-1, 1) that differ per lane and element (zero operands clock higher)
+        a[i] = (_Float16)((float)((threadIdx.x * 37 + i * 11) % 201 - 100) * 0.0099f);
+        b[i] = (_Float16)((float)((threadIdx.x * 53 + i * 29) % 199 - 99) * 0.0101f);
+    }
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+}  // namespace
+
+extern "C" int sk_mfma_probe(void* scratch, size_t scratch_bytes, int iters, double* flops, void* stream) {
+    constexpr int kBlocks = 512;   // 256 CUs x 2 workgroups of 4 waves
+    SK_CHECK_ARG(scratch != nullptr && scratch_bytes >= (size_t)kBlocks * 256 * sizeof(float),
+                 "sk_mfma_probe: scratch must hold %d floats", kBlocks * 256);
+    SK_CHECK_ARG(iters > 0, "sk_mfma_probe: iters must be positive");
+    mfma_probe_kernel<<<kBlocks, 256, 0, (hipStream_t)stream>>>((float*)scratch, iters);
+    SK_CHECK_LAUNCH();
+    if (flops) *flops = (double)kBlocks * 4 * iters * 8 * (2.0 * 16 * 16 * 32);
+    return SK_OK;
+}

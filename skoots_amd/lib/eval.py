@@ -199,7 +199,7 @@ def tile_grid(shape: Sequence[int], tile=TILE, overlap=TILE_OVERLAP):
 
 
 def eval_volume(image: Tensor, model, scale, mean=None, std=None, n: int = FOLLOW_N,
-                tile=TILE, tile_overlap=TILE_OVERLAP, tile_batch: int = 64,
+                tile=TILE, tile_overlap=TILE_OVERLAP, tile_batch: Optional[int] = None,
                 inject: Optional[Callable] = None, keep_planar_vectors: bool = False,
                 timings: Optional[Dict[str, float]] = None) -> Dict[str, Tensor]:
     """In-memory variant of :func:`eval` on one GPU: (1, X, Y, Z) or (X, Y, Z) image on the
@@ -208,6 +208,8 @@ def eval_volume(image: Tensor, model, scale, mean=None, std=None, n: int = FOLLO
     ``model`` is a :class:`skoots_amd.unet.HipUNet`; ``inject(out5, origin, eff) -> out5``
     may replace a tile's network output (parity tests and bench.py's assignment workload
     use it).  The multi-GPU form is :class:`skoots_amd.parallel.ShardedVolume`.
+    ``tile_batch``: tiles per network launch; None = as many as the tile count and the free device memory allow,
+    at most 64 (:func:`skoots_amd.parallel.pick_tile_batch`; a tile's output does not depend on its batch).
     """
     from ..parallel import ShardedVolume
     img = image.squeeze(0) if image.ndim == 4 else image
@@ -258,8 +260,12 @@ def _cfg_get(cfg, section: str, key: str, default=None):
 
 
 @torch.inference_mode()
-def eval(image_path: str, checkpoint_path: str, used_cached_data: bool = False) -> None:
+def eval(image_path: str, checkpoint_path: str, used_cached_data: bool = False, precision: str = "fp16") -> None:
     """Evaluates SKOOTS on an arbitrary image (drop-in for ``skoots.lib.eval.eval``).
+
+    ``precision`` (not in the reference's signature; keyword with the reference's behaviour as default): "fp16" = what the
+    reference's fp16 autocast does (eval.py:142); "split" = fp16 hi + lo operand pairs, network outputs within 1e-3 of an
+    fp32 forward at about a third of the speed; "fp32" = exact-fp32 matrix instructions (:class:`skoots_amd.unet.HipUNet`).
 
     Writes next to the image, with the reference's names: ``<base>_skoots_skeleton`` (1,X,Y,Z) u1
     and ``<base>_skoots_vectors`` (3,X,Y,Z) f2 as ``.zarr`` directory stores (zarr v2 layout, uncompressed,
@@ -295,7 +301,7 @@ def eval(image_path: str, checkpoint_path: str, used_cached_data: bool = False) 
     scale = [int(v) for v in _cfg_get(cfg, "SKOOTS", "VECTOR_SCALING")]  # eval.py:99
 
     logging.info("Constructing SKOOTS model")
-    model = unet.cfg_to_model(cfg, device, checkpoint["model_state_dict"])
+    model = unet.cfg_to_model(cfg, device, checkpoint["model_state_dict"], precision=precision)
     from . import zarr_store
     skel_path, vec_path = base + "_skoots_skeleton.zarr", base + "_skoots_vectors.zarr"  # eval.py:102-103
 

@@ -128,9 +128,13 @@ class Comm:
     HIP events for RCCL, wall clock for the host-staged gloo rehearsal) -- ``stats()`` is what
     bench.py prints for N > 1, so that a scaling curve can be read per exchange step."""
 
-    def __init__(self, rank: int, world: int):
+    def __init__(self, rank: int, world: int, force_device: bool = False):
+        """``force_device``: run the collectives through ``torch.distributed`` even with ONE rank (they are identities
+        there and normally skipped) -- on a one-GPU box this is how the RCCL code path gets executed at all
+        (tests/test_hip_sharded.py: library load, ``device_id`` binding, ``all_gather_into_tensor``, all-reduce)."""
         self.rank, self.world = rank, world
-        self.staged = world > 1 and dist.get_backend() == "gloo"
+        self.force = bool(force_device) and dist.is_available() and dist.is_initialized()
+        self.staged = (world > 1 or self.force) and dist.get_backend() == "gloo"
         self._acct: Dict[str, Dict[str, object]] = {}
 
     def _out(self, t: Tensor) -> Tensor:
@@ -138,6 +142,11 @@ class Comm:
 
     # -- accounting ----------------------------------------------------------------------
     class _Span:
+        """Brackets ONE SYNCHRONOUS collective.  RCCL runs it on PyTorch's internal communication stream; the event
+        pair on the calling stream brackets it only because a synchronous op makes the calling stream wait for it.
+        With ``async_op=True`` the pair would time nothing: every collective in this module is synchronous, and
+        :meth:`Comm.exchange` waits for its requests inside the span."""
+
         def __init__(self, comm: "Comm", what: str, nbytes: int, device):
             self.c, self.what, self.nbytes, self.device = comm, what, int(nbytes), device
 
@@ -176,7 +185,7 @@ class Comm:
 
     # -- collectives ---------------------------------------------------------------------
     def all_gather(self, t: Tensor, what: str = "all_gather") -> List[Tensor]:
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return [t]
         src = self._out(t.contiguous())
         with self.span(what, src.numel() * src.element_size() * (self.world - 1), t.device):
@@ -189,7 +198,7 @@ class Comm:
             return [o.to(t.device) for o in outs]
 
     def all_reduce_min(self, t: Tensor, what: str = "all_reduce") -> Tensor:
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return t
         src = self._out(t)
         with self.span(what, 2 * src.numel() * src.element_size() * (self.world - 1) // self.world, t.device):
@@ -280,10 +289,52 @@ def exchange_blocks(arrays: Sequence[Tensor], blocks, windows, rank: int, comm: 
             at += v.numel()
 
 
+MAX_TILE_BATCH = 64   # tiles per network launch the kernels' launch plans are built for
+
+
+def tile_batch_bytes(eff: Sequence[int], split: bool = False) -> int:
+    """Activation bytes ONE tile adds to a network context (skoots_amd.unet.HipUNet buffers): three 32-channel
+    full-resolution tensors, the half- and quarter-resolution ones, the stem workspace and the 5-channel output."""
+    v = int(eff[0]) * int(eff[1]) * int(eff[2])
+    lanes = 2 if split else 1
+    l0 = 3 * 32 * 2 * v * lanes                                  # L0a, L0b, skip0
+    l1 = (3 * 64 + 32) * 2 * (v // 8) * lanes                    # L1a, L1b, skip1, L1r
+    l2 = (2 * 128 + 64) * 2 * (v // 64) * lanes                  # L2a, L2b, L2r
+    return l0 + l1 + l2 + 5 * 2 * v + 4 * v                      # + out5 + the stem's normalised workspace
+
+
+def pick_tile_batch(n_tiles: int, eff: Sequence[int], device, contexts: int = 1, split: bool = False,
+                    requested: Optional[int] = None) -> int:
+    """Tiles per network launch: ``requested`` (default MAX_TILE_BATCH) clamped to the tile count and to what fits in
+    60 % of the device memory that is free right now (``contexts`` activation sets: one per stream).  A tile's output
+    bits do not depend on its batch (tests/test_hip_geometry.py), so the clamp changes speed only; a device too full
+    for even one tile raises here, with the numbers, instead of failing inside a layer's allocation."""
+    want = MAX_TILE_BATCH if requested is None else int(requested)
+    if want < 1:
+        raise ValueError("tile_batch must be >= 1")
+    want = min(want, MAX_TILE_BATCH, max(1, int(n_tiles)))
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return want
+    free, _ = torch.cuda.mem_get_info(dev)
+    free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)   # torch's cached blocks are reusable
+    per = tile_batch_bytes(eff, split) * max(1, contexts)
+    fit = int(0.6 * free // per)
+    if fit < 1:
+        raise RuntimeError(f"not enough free device memory for one tile of {tuple(eff)}: {free / 2**30:.1f} GiB free, "
+                           f"{per / 2**30:.2f} GiB of activations per tile")
+    return min(want, fit)
+
+
 class ShardedVolume:
     """One rank's share of a volume: runs stages 1-3 + renumber, collectives included."""
 
-    def __init__(self, shape: Sequence[int], rank: int, world: int, device, halo: int = HALO):
+    def __init__(self, shape: Sequence[int], rank: int, world: int, device, halo: int = HALO,
+                 force_distributed: bool = False):
+        """``force_distributed``: take the multi-rank code paths (slab labelling with its metadata / label gathers,
+        distributed renumber) even with one rank, with the collectives really issued (``Comm(force_device=True)``):
+        the single-rank result must equal the plain pipeline's -- the one-GPU box's rehearsal of the RCCL path."""
+        self.force_distributed = bool(force_distributed)
         self.shape = tuple(int(v) for v in shape)
         self.rank, self.world = rank, world
         self.device = torch.device(device)
@@ -293,7 +344,7 @@ class ShardedVolume:
         self.windows = [window_of(s, self.shape[2], world, halo) for s in self.slabs]
         self.slab, self.window = self.slabs[rank], self.windows[rank]
         self.timings: Dict[str, float] = {}
-        self.comm = Comm(rank, world)      # persistent: its per-exchange accounting accumulates over run() calls
+        self.comm = Comm(rank, world, force_device=self.force_distributed)   # persistent: its accounting accumulates over run() calls
         self.tiles_this_rank = 0
 
     def _side_stream(self, i: int):
@@ -308,7 +359,7 @@ class ShardedVolume:
         self.timings[name] = self.timings.get(name, 0.0) + time.perf_counter() - t0
 
     def run(self, image: Tensor, model, scale, mean: float, std: float, n: int = 10,
-            decay: float = 1.0, tile=(300, 300, 20), tile_overlap=(50, 50, 5), tile_batch: int = 64,
+            decay: float = 1.0, tile=(300, 300, 20), tile_overlap=(50, 50, 5), tile_batch: Optional[int] = None,
             inject: Optional[Callable] = None, keep_planar_vectors: bool = False,
             conv_profile=None, streams: int = 1, stage_profile=None) -> Dict[str, object]:
         """``image``: this rank's window of the fp16 volume, shape (X, Y, window planes)."""
@@ -337,6 +388,12 @@ class ShardedVolume:
         out_box = ([max(0, o - r) for o, r in zip(tile_overlap, reach)],
                    [min(s_, s_ - o + r) for s_, o, r in zip(eff, tile_overlap, reach)])
         n_streams = max(1, int(streams)) if model is not None else 1
+        if model is not None:   # None / too large a request: clamped to the tile count and the free device memory
+            tile_batch = pick_tile_batch(len(origins), eff, dev, contexts=n_streams,
+                                         split=getattr(model, "precision", "fp16") == "split", requested=tile_batch)
+        elif tile_batch is None:
+            tile_batch = MAX_TILE_BATCH
+        self.tile_batch_used = tile_batch
         ctxs = [model] + [model.clone_context() for _ in range(n_streams - 1)] if model is not None else [None]
         for c in ctxs:
             if c is not None:
@@ -377,7 +434,7 @@ class ShardedVolume:
 
         # ---- stage 2 --------------------------------------------------------------------
         t0 = time.perf_counter()
-        if self.world == 1:
+        if self.world == 1 and not self.force_distributed:
             labels = label_skeleton(state.skeleton, reference_ids=False, profile=stage_profile)
             n_labels_hint = None
         else:
@@ -399,7 +456,7 @@ class ShardedVolume:
 
         # ---- renumber -------------------------------------------------------------------
         t0 = time.perf_counter()
-        if self.world == 1:
+        if self.world == 1 and not self.force_distributed:
             k = state.renumber()
         else:
             k = distributed_renumber(inst, self.shape, self.slab, int(n_labels_hint), comm)

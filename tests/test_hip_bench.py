@@ -24,7 +24,8 @@ def _run(*argv):
 
 @pytest.mark.parametrize("precision", ["fp16", "split"])
 def test_eval_line_contract(precision):
-    d = _run("--steps", "1", "--warmup", "1", "--shape", "512,512,64", "--precision", precision, "--cpu-budget", "1")
+    d = _run("--steps", "1", "--warmup", "1", "--shape", "512,512,64", "--precision", precision, "--cpu-budget", "1",
+             "--also-steps", "1", "--also-train-steps", "2", "--also-train-shape", "64,64,64")
     assert d["metric"].startswith("Mvoxels/s end-to-end") and d["unit"] == "Mvoxels/s" and d["n_gpus"] == 1
     assert d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 512 * 512 * 64 / d["ms_per_step"] / 1e3) < 0.01 * d["value"]
@@ -40,6 +41,28 @@ def test_eval_line_contract(precision):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mvoxels/s" and "936" in c["sample"]
     assert d["config"]["instances"] > 0   # the injected blob field went through stages 2-3
+    assert d["box"]["mfma_probe_tflops"] > 500 and d["box"]["band"] in ("slow", "typical", "fast")
+    if precision == "split":
+        assert "also" not in d
+        return
+    # the default (fp16) line also carries the tolerance-meeting precision and the training step, same process
+    sp, tr = d["also"]["split"], d["also"]["train_bf16"]
+    assert sp["value"] > 0 and sp["unit"] == "Mvoxels/s" and sp["steps"] == 1 and sp["ms_per_step"] > d["ms_per_step"]
+    assert abs(sp["value"] - 512 * 512 * 64 / sp["ms_per_step"] / 1e3) < 0.01 * sp["value"]
+    assert sp["parity_vs_fp32_mode"]["max_abs"] <= 1e-3 and sp["parity_vs_fp32_mode"]["north_star_tolerance"] == 1e-3
+    assert sp["roofline"]["bound"] == "mfma" and 0.005 < sp["roofline"]["frac"] < 1.0 and sp["roofline"]["launches"] > 0
+    assert tr["dtype"] == "bf16" and tr["steps"] == 2 and tr["ms_per_step"] > 0 and tr["value"] > 0
+    assert tr["roofline"]["bound"] == "mfma" and tr["roofline"]["achieved"] > 0
+    assert tr["config"]["precision"] == "bf16" and all(0 < v < 3 for v in tr["config"]["losses"][:3])
+
+
+def test_eval_line_two_streams_keeps_a_roofline():
+    """--streams 2: the timed steps overlap two tile batches; the per-launch roofline then comes from the single-stream
+    warm-up steps and says so."""
+    d = _run("--steps", "1", "--warmup", "2", "--shape", "512,512,64", "--streams", "2", "--no-also", "--no-cpu-baseline")
+    r = d["roofline"]
+    assert d["config"]["streams"] == 2 and "warm-up" in r["timed_over"] and r["launches"] > 0 and 0.02 < r["frac"] < 1.0
+    assert d["roofline_assign"]["launches"] >= 1 and d["config"]["instances"] > 0
 
 
 def test_train_line_contract():

@@ -89,3 +89,69 @@ def test_sharded_equals_single(world, sparse, pair_cap):
         # seed 11 puts skeleton cores across the z = 90 slab boundary: with a zero pair capacity the second gather runs
         assert comm_stats["label_meta"]["calls"] == (2 if pair_cap is not None else 1), comm_stats["label_meta"]
     assert np.array_equal(got, want)
+
+
+def _nccl_single_rank(port, q):
+    """One rank, backend nccl (= RCCL): the device-tensor branches of Comm and the multi-rank stage 2 / renumber code."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from skoots_amd.parallel import Comm, ShardedVolume
+        comm = Comm(0, 1, force_device=True)
+        assert comm.force and not comm.staged and dist.get_backend() == "nccl"
+        t = torch.arange(1000, dtype=torch.int32, device=dev)
+        parts = comm.all_gather(t, what="probe_gather")          # all_gather_into_tensor on a device tensor
+        r = comm.all_reduce_min(t.to(torch.int64) + 5, what="probe_reduce")
+        ok_comm = (len(parts) == 1 and parts[0].is_cuda and torch.equal(parts[0], t)
+                   and torch.equal(r, t.to(torch.int64) + 5))
+        st = comm.stats()
+        out_vol, _ = _field()
+        out_dev = out_vol.to(dev)
+        image = torch.zeros(SHAPE, dtype=torch.float16, device=dev)
+
+        def inject(_, origin, eff):
+            x, y, z = origin
+            return out_dev[:, x:x + eff[0], y:y + eff[1], z:z + eff[2]].contiguous()
+
+        sv = ShardedVolume(SHAPE, 0, 1, dev, force_distributed=True)
+        res = sv.run(image, None, (60, 60, 12), 0.0, 1.0, inject=inject)
+        q.put((ok_comm, st, res["instance_mask"].cpu().numpy(), res["n_instances"], sv.comm.stats()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_path_executes_with_one_rank():
+    """The box has one device and RCCL refuses two ranks on it, so the N > 1 tests above rehearse over gloo.  This one
+    initialises the nccl backend itself (world size 1, ``device_id`` bound) and drives the NON-staged branches:
+    ``all_gather_into_tensor`` / ``all_reduce`` on device tensors with HIP-event accounting, then the whole pipeline
+    through the multi-rank stage-2 and renumber code (``force_distributed``) -- result bit-identical to the plain
+    single-GPU pipeline.  Point-to-point is left out: a self-send is not an RCCL pattern."""
+    from skoots_amd.lib import eval as E
+    out_vol, k = _field()
+    dev = "cuda:0"
+    out_dev = out_vol.to(dev)
+
+    def inject(_, origin, eff):
+        x, y, z = origin
+        return out_dev[:, x:x + eff[0], y:y + eff[1], z:z + eff[2]].contiguous()
+
+    single = E.eval_volume(torch.zeros(SHAPE, dtype=torch.float16, device=dev), None, (60, 60, 12),
+                           mean=0.0, std=1.0, inject=inject)
+    want = single["instance_mask"].cpu().numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_single_rank, args=(_free_port(), q))
+    p.start()
+    ok_comm, st, got, n_inst, stats = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert ok_comm
+    assert st["probe_gather"]["calls"] == 1 and st["probe_gather"]["ms"] > 0     # HIP events on the calling stream
+    assert st["probe_reduce"]["calls"] == 1 and st["probe_reduce"]["ms"] > 0
+    assert n_inst == single["n_instances"] and np.array_equal(got, want)
+    assert {"label_meta", "label_gather", "renumber_allreduce"} <= set(stats)
+    assert all(v["ms"] > 0 for v in stats.values())

@@ -201,3 +201,26 @@ def test_precision_names_are_validated():
     assert PRECISIONS == ("fp16", "split", "fp32")
     with pytest.raises(ValueError, match="precision"):
         HipUNet({}, "cuda:0", precision="bf16")
+
+
+def test_tile_batch_is_clamped_to_the_tile_count_and_validated():
+    """pick_tile_batch (the library default of eval_volume / ShardedVolume.run): never more tiles per launch than there
+    are tiles or than the kernels' launch plans take; on a device it is also bounded by the free memory (GPU test)."""
+    from skoots_amd import parallel as P
+    assert P.pick_tile_batch(5, (300, 300, 20), "cpu") == 5
+    assert P.pick_tile_batch(625, (300, 300, 20), "cpu") == P.MAX_TILE_BATCH == 64
+    assert P.pick_tile_batch(625, (300, 300, 20), "cpu", requested=8) == 8
+    assert P.pick_tile_batch(625, (300, 300, 20), "cpu", requested=500) == 64
+    with pytest.raises(ValueError):
+        P.pick_tile_batch(10, (300, 300, 20), "cpu", requested=0)
+    per = P.tile_batch_bytes((300, 300, 20))
+    assert 0.40e9 < per < 0.60e9              # ~0.5 GB of activations per production tile (64 tiles: ~31 GB)
+    assert P.tile_batch_bytes((300, 300, 20), split=True) > 1.8 * per
+
+
+def test_eval_signature_is_the_references_plus_precision():
+    import inspect
+    from skoots_amd.lib import eval as E
+    sig = inspect.signature(E.eval)
+    assert list(sig.parameters)[:3] == ["image_path", "checkpoint_path", "used_cached_data"]   # skoots/lib/eval.py:33-37
+    assert sig.parameters["used_cached_data"].default is False and sig.parameters["precision"].default == "fp16"

@@ -115,3 +115,30 @@ def test_flood_equals_true_ccl_when_no_quirk():
     # same partition: label pairs are in bijection
     pairs = np.unique(np.stack([got.ravel().astype(np.int64), ref.ravel().astype(np.int64)]), axis=1)
     assert len(np.unique(pairs[0])) == pairs.shape[1] == len(np.unique(pairs[1]))
+
+
+def test_16bit_storage_emulation_of_the_training_step_is_the_plain_step_at_fp32():
+    """oracle.train_step_16bit_storage (the checker of the HIP bf16 step) with dtype float32 rounds nothing: it must
+    reproduce oracle.train_step -- the same graph, hand-written GroupNorm included -- and with bfloat16 it must stay
+    within bf16's error of it."""
+    import copy
+
+    import torch
+    from oracle import train_step as O
+    from oracle import unet_spec
+    ref = unet_spec.build().train()
+    twins = [copy.deepcopy(ref) for _ in range(2)]
+    g = torch.Generator().manual_seed(40)
+    B, X, Y, Z = 1, 16, 12, 8
+    images = torch.randn((B, 1, X, Y, Z), generator=g)
+    masks = (torch.rand((B, 1, X, Y, Z), generator=g) > 0.5).float()
+    skele = (torch.rand((B, 1, X, Y, Z), generator=g) > 0.9).float()
+    baked = torch.rand((B, 3, X, Y, Z), generator=g) * 16
+    sigma, scale = torch.tensor([20.0, 20.0, 20.0]), torch.tensor((60, 60, 12))
+    want = O.train_step(ref, O.make_optimizer(ref), images, masks, skele, baked, sigma, scale)
+    grads = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    for twin, dtype, tol_l, tol_g in ((twins[0], torch.float32, 1e-6, 1e-4), (twins[1], torch.bfloat16, 5e-3, 0.15)):
+        got = O.train_step_16bit_storage(twin, O.make_optimizer(twin), images, masks, skele, baked, sigma, scale, dtype=dtype)
+        assert (got - want).abs().max().item() <= tol_l
+        for k, p in twin.named_parameters():
+            assert (p.grad - grads[k]).abs().max() <= tol_g * grads[k].abs().max(), (dtype, k)

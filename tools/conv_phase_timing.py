@@ -26,8 +26,8 @@ def main():
     from skoots_amd import _ffi, unet
     dev = torch.device("cuda", 0)
     B = 8
-    dbg = torch.zeros((4096, 4, 8), dtype=torch.int64, device=dev)
-    os.environ["SK_CONV_DBG"] = hex(dbg.data_ptr())
+    dbg = torch.zeros((4096, 4, 16), dtype=torch.int64, device=dev)   # [workgroup][wave][slot]: the library's one record layout
+    _ffi.check(_ffi.lib.sk_debug_set_timing_buffer(_ffi.ptr(dbg), dbg.numel() * 8))
     zeros = torch.zeros(4096, dtype=torch.uint8, device=dev)
     out = {}
     for name, ext, srcdef, cout, act in LAYERS:
@@ -56,6 +56,7 @@ def main():
         tot = m.sum().item()
         out[name] = {"cycles_per_wave": round(tot), **{n: round(v / tot, 4) for n, v in zip(NAMES[:7], m.tolist())}}
         print(name, json.dumps(out[name]), flush=True)
+    _ffi.check(_ffi.lib.sk_debug_set_timing_buffer(None, 0))   # detach before `dbg` can be freed
     print(json.dumps(out))
 
 

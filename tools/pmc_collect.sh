@@ -1,16 +1,18 @@
 #!/bin/bash
-# PMC passes over the conv stack at the production launch geometry (8 tiles of 300x300x20), on the GPU box:
+# PMC passes over the conv stack at the production launch geometry (BATCH tiles of 300x300x20, default 64 = what
+# bench.py launches), on the GPU box:
 #   pass 1  FETCH_SIZE      pass 2  WRITE_SIZE      (separate passes, as MI355X_MICROARCH.md prescribes)
 #   pass 3  SQ counters     (MFMA busy, wave wait / issue split, LDS activity)
 # Each pass is `rocprofv3 --kernel-trace --pmc ...` only (no other trace domains).  Writes
 #   gpurun_out/<tag>_conv_hbm_traffic_pmc.json   and   gpurun_out/<tag>_conv_sq_counters.json
 # which are then copied into profiles/ (bench.py's roofline.traffic reads the newest committed traffic file).
 #
-#   gpurun -- 'bash tools/pmc_collect.sh r02'
+#   gpurun -- 'bash tools/pmc_collect.sh r03'          BATCH=8 bash tools/pmc_collect.sh r03_b8
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
+BATCH=${BATCH:-64}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-CMD="python3 $ROOT/tools/bench_conv.py --tile 300,300,20 --batch 8 --iters 1 --warmup 1"
+CMD="python3 $ROOT/tools/bench_conv.py --tile 300,300,20 --batch $BATCH --iters 1 --warmup 1"
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_f /tmp/pmc_w /tmp/pmc_s

@@ -32,7 +32,8 @@ def short(name):
 def traffic(fdir, wdir, cmd):
     fetch = per_kernel(fdir, {"FETCH_SIZE"})
     write = per_kernel(wdir, {"WRITE_SIZE"})
-    out = {"command": cmd,
+    m = re.search(r"--batch (\d+)", cmd)
+    out = {"command": cmd, "batch": int(m.group(1)) if m else None,
            "note": "per-launch averages; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced "
                    "reads; Infinity-Cache hits are counted); WRITE_SIZE as is",
            "kernels": []}
@@ -69,8 +70,55 @@ def sq(sdir, cmd):
     return out
 
 
+STAGE_KERNELS = {"gate_dilate_scatter": ("gate_dilate_scatter_kernel",),
+                 "ccl": ("ccl_",),
+                 "follow_assign": ("follow_assign_kernel",),
+                 "renumber": ("first_seen_kernel", "mark_kernel", "chunk_popc_kernel", "chunk_scan_kernel", "word_prefix_kernel",
+                              "build_lut_kernel", "apply_lut_kernel")}
+
+
+def stages(fdir, wdir, fdir_dense, wdir_dense, sparse_json, dense_json, cmd):
+    """HBM-side bytes per STEP of every stage-2/3 kernel group (a step = one pass of tools/bench_stages.py over the
+    1024x1024x256 volume): sum over the group's launches of FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE."""
+    out = {"command": cmd,
+           "note": "bytes per step = sum over the stage's kernel launches of one pass; FETCH_SIZE (KiB) doubled per "
+                   "MI355X_MICROARCH.md (gfx950 counts wide coalesced reads at half; Infinity-Cache hits are counted), WRITE_SIZE "
+                   "(KiB) as is.  The 4-byte-per-lane accesses of the labelling kernels are outside the guide's calibration "
+                   "(16 B per lane): read their absolute figures with that caveat, ratios between variants are unaffected",
+           "stages": {}, "stages_dense_field": {}}
+    for key, fd, wd, tj in (("stages", fdir, wdir, sparse_json), ("stages_dense_field", fdir_dense, wdir_dense, dense_json)):
+        timing = json.load(open(tj))
+        fetch = per_kernel(fd, {"FETCH_SIZE"})
+        write = per_kernel(wd, {"WRITE_SIZE"})
+        out[key + "_field"] = {k: timing[k] for k in ("shape", "dense", "instances", "foreground_frac", "skeleton_frac")}
+        for stage, pats in STAGE_KERNELS.items():
+            fb = wb = 0.0
+            kern = {}
+            for k, (c, n) in fetch.items():
+                if any(p_ in k for p_ in pats):
+                    # the profiled command runs warm-up + 1 step: launches / 2 per step
+                    w = write.get(k, ({"WRITE_SIZE": 0.0}, n))[0]["WRITE_SIZE"]
+                    per_step = n / 2.0
+                    kern[short(k)] = {"launches_per_step": per_step, "fetch_MB_x2": round(2 * c["FETCH_SIZE"] / 1024 * per_step, 2),
+                                      "write_MB": round(w / 1024 * per_step, 2)}
+                    fb += 2 * c["FETCH_SIZE"] * 1024 * per_step
+                    wb += w * 1024 * per_step
+            t = timing["kernels"].get(stage, {})
+            e = {"bytes_per_step": int(fb + wb), "fetch_bytes_per_step": int(fb), "write_bytes_per_step": int(wb), "kernels": kern}
+            if t:
+                e["algorithmic_bytes_per_step"] = t["algorithmic_bytes_per_step"]
+                e["ms_per_step_unprofiled"] = t["ms_per_step"]
+                e["measured_GBps"] = round((fb + wb) / (t["ms_per_step"] * 1e-3) / 1e9, 1)
+                e["algorithmic_GBps"] = t["algorithmic_GBps"]
+                e["traffic_over_algorithmic"] = round((fb + wb) / max(t["algorithmic_bytes_per_step"], 1), 3)
+            out[key][stage] = e
+    return out
+
+
 def main():
-    if sys.argv[1] == "traffic":
+    if sys.argv[1] == "stages":
+        json.dump(stages(*sys.argv[2:9]), sys.stdout, indent=1)
+    elif sys.argv[1] == "traffic":
         json.dump(traffic(sys.argv[2], sys.argv[3], sys.argv[4]), sys.stdout, indent=1)
     elif sys.argv[1] == "sq":
         json.dump(sq(sys.argv[2], sys.argv[3]), sys.stdout, indent=1)

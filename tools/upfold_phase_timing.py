@@ -16,11 +16,11 @@ NAMES = ["skip_mfma", "barrier", "dma_low_issue", "landing_wait", "barrier", "up
 
 
 def main():
-    from skoots_amd import unet
+    from skoots_amd import _ffi, unet
     dev = torch.device("cuda", 0)
     B, ext = 8, (300, 300, 20)
     dbg = torch.zeros((4096, 4, 16), dtype=torch.int64, device=dev)
-    os.environ["SK_CONV_DBG"] = hex(dbg.data_ptr())
+    _ffi.check(_ffi.lib.sk_debug_set_timing_buffer(_ffi.ptr(dbg), dbg.numel() * 8))
     g = torch.Generator(device=dev).manual_seed(1)
     skip = torch.randn((B,) + ext + (32,), generator=g, device=dev).half()
     up = torch.randn((B,) + tuple(e // 2 for e in ext) + (32,), generator=g, device=dev).half()
@@ -31,6 +31,7 @@ def main():
         dbg.zero_()
         unet.conv3d_upfold(skip, up, wp, bias, 32)
         torch.cuda.synchronize()
+    _ffi.check(_ffi.lib.sk_debug_set_timing_buffer(None, 0))   # detach before `dbg` can be freed
     d = dbg.double()
     used = d.sum(dim=(1, 2)) > 0
     m = d[used].mean(dim=(0, 1))
