@@ -103,6 +103,11 @@ class TrainUNet:
         self.fast_stem = True          # stem as an fp16-operand fast block
         self.fast_heads = True         # heads straight on the fp16 activation
         self.f16_grad_handoff = True   # single-reader fp16 data gradients handed on without an fp32 copy
+        # tests only: a list here makes backward() record, per fast block, copies of exactly the 16-bit tensors its kernels
+        # read and wrote (sources, raw output, incoming gradient, dy, data gradients, scales) next to the parameter
+        # gradients they produced, so that every kernel of the step can be replayed in torch ON THE SAME OPERANDS
+        # (tests/test_hip_train.py: test_bf16_step_kernels_replayed_in_situ)
+        self.audit: Optional[list] = None
 
         def stack(name, n):
             return [_Layer(f"{name}.{i}", 3, True) for i in range(n)]
@@ -432,6 +437,17 @@ class TrainUNet:
                     _ffi.check(self._L.sk_train_conv_wgrad(self._srcs(srcs), len(srcs), _ffi.ptr(dy), B, ox, oy, oz, cout,
                                                             layer.ksize, _ffi.ptr(layer.g_weight), _ffi.ptr(layer.g_bias),
                                                             _ffi.ptr(ws), st))
+            rec = None
+            if self.audit is not None and fast:
+                rec = {"name": layer.name, "ksize": layer.ksize,
+                       "srcs": [((self._h(t) if layer.cin != 1 else t).clone(), up) for t, up in srcs],
+                       "y16": y.clone(), "affine": affine.clone(), "stats": stats.clone(),
+                       "dz": (dz.clone(), None) if dz_scale is None else (dz.clone(), dz_scale.clone()),
+                       "dy16": dy16.clone(), "scale": scale.clone(), "g_weight": layer.g_weight.clone(),
+                       "g_bias": layer.g_bias.clone(), "g_gamma": layer.g_gamma.clone(), "g_beta": layer.g_beta.clone(),
+                       "weight": layer.weight.clone(), "bias": layer.bias.clone(), "gamma": layer.gamma.clone(),
+                       "beta": layer.beta.clone(), "dx16": {}}
+                self.audit.append(rec)
             lo = 0
             for t, up in srcs:
                 c = t.shape[-1]
@@ -473,6 +489,8 @@ class TrainUNet:
                     # data gradient on the fast conv kernel: the layer's weight packed transposed + tap-flipped
                     dx16 = self._fast_conv([(dy16, 0)], self._pack(layer, True, lo, c), self._zero_bias, (ox, oy, oz), c,
                                            layer.ksize, None)
+                    if rec is not None:
+                        rec["dx16"][lo] = dx16.clone()
                     if up:
                         if key in grads:
                             raise RuntimeError("an upsampled tensor has one consumer in this graph")

@@ -12,9 +12,6 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
-# bf16 step against the bf16-storage emulation (see test_train_step_bf16_vs_bf16_storage_oracle): per parameter tensor,
-# max error / tensor max and rms error / tensor max
-BF16_EMU_MAX, BF16_EMU_RMS = 0.02, 0.005
 DEV = "cuda:0"
 
 
@@ -582,37 +579,86 @@ def test_train_step_bf16_vs_oracle():
     print(f"bf16: worst gradient error / max = {worst:.2e}, worst rms / max = {worst_rms:.2e}")
 
 
-def test_train_step_bf16_vs_bf16_storage_oracle():
-    """The bf16 step against oracle.train_step_16bit_storage: the same graph under torch autograd with the step's 16-bit
-    STORAGE restated (bf16 image operand / conv weights / raw conv outputs / activations / output- and data-gradients,
-    everything else fp32) -- so what is left between the two is summation order and the rounding flips it causes, not
-    the dtype.  The fp32-oracle bound of the test above mixes both (5.8 % of max measured: the emulation itself sits
-    5.6 % / 1.6 % rms from the fp32 oracle); this one is the check that would catch a wrong tap, a wrong chunk or a twin
-    resolved to the wrong build."""
-    from oracle import train_step as O
+def test_bf16_step_kernels_replayed_in_situ():
+    """Every fast block of a whole bf16 step, replayed in torch ON THE TENSORS THE KERNELS ACTUALLY READ.  Comparing two
+    bf16 realisations of the step end to end cannot be tight: with the step's 16-bit storage restated under torch
+    autograd (oracle.train_step_16bit_storage, itself 5.6 % of max / 1.6 % rms from the fp32 oracle) the HIP step still
+    sits 5.0 % / 1.5 % from it on this batch -- bf16 rounding flips are chaotic, so the fp32-oracle bound of
+    test_train_step_bf16_vs_oracle is as tight as an end-to-end bound gets.  What IS tight is each kernel on its own
+    operands: ``TrainUNet.audit`` records, per block, the 16-bit sources, raw output, incoming gradient, dy and data
+    gradients of the step, and here
+      forward conv        y16        == one bf16 rounding of conv(x16, bf16(w)) + b           (4.5e-3 of max)
+      GroupNorm backward  dy16, dgamma, dbeta  vs torch autograd through silu(group_norm(y16))  (6e-3 / 2e-3)
+      weight gradient     dW, dbias  vs autograd on (x16, dy16): only the summation order      (1e-3)
+      data gradient       dx16       == one bf16 rounding of autograd's dx                     (4.5e-3)
+    -- a wrong tap, a wrong chunk, a flipped transpose or a twin resolved to the wrong build is a >= 10 % error in one
+    of these, on the layer where it happens."""
     from oracle import unet_spec
     from skoots_amd.train import TrainStep, TrainUNet
     ref = unet_spec.build().train()
     B, X, Y, Z = 2, 16, 12, 8
-    sigma, scale = torch.tensor([20.0, 20.0, 20.0]), torch.tensor((60, 60, 12))
     model = TrainUNet(ref.state_dict(), DEV, precision="bf16")
+    model.audit = []
     step = TrainStep(model)
-    opt = O.make_optimizer(ref)
     images, masks, skele, baked = _synthetic_batch(B, X, Y, Z, 40)
-    want = O.train_step_16bit_storage(ref, opt, images, masks, skele, baked, sigma, scale, dtype=torch.bfloat16)
-    ref_grads = {k: p.grad.clone() for k, p in ref.named_parameters()}
-    got = step(images.to(DEV), masks.to(DEV), skele.to(DEV), baked.to(DEV), sigma.tolist())
-    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=2e-3)
-    worst, worst_rms, wk = 0.0, 0.0, ""
-    for k, g in model.grads().items():
-        r = ref_grads[k].double()
-        e = (g.cpu().double() - r)
-        m, q = (e.abs().max() / r.abs().max()).item(), (e.pow(2).mean().sqrt() / r.abs().max()).item()
-        if m > worst:
-            worst, wk = m, k
-        worst_rms = max(worst_rms, q)
-    print(f"bf16 vs bf16-storage oracle: worst gradient error / max = {worst:.2e} ({wk}), worst rms / max = {worst_rms:.2e}")
-    assert worst <= BF16_EMU_MAX and worst_rms <= BF16_EMU_RMS, (wk, worst, worst_rms)
+    step(images.to(DEV), masks.to(DEV), skele.to(DEV), baked.to(DEV), [20.0, 20.0, 20.0])
+    audit, model.audit = model.audit, None
+    names = [r["name"] for r in audit]
+    assert len(names) == 14 and {"enc0.0", "enc0.1", "down0", "mid.1", "red1", "dec1.0", "red0", "dec0.0", "dec0.1"} <= set(names)
+    bf = torch.bfloat16
+    worst = {}
+
+    def rel(got, want):
+        return ((got.double() - want.double()).abs().max() / want.double().abs().max().clamp_min(1e-30)).item()
+
+    for r in audit:
+        k, name = r["ksize"], r["name"]
+        w, bias, gamma, beta = (r[q].float().cpu() for q in ("weight", "bias", "gamma", "beta"))
+        stem = w.shape[1] == 1
+        srcs = [(_cf(t.float().cpu()), up) for t, up in r["srcs"]]
+        xs = [t.to(bf).float() if stem else t for t, _ in srcs]                     # the stem rounds its image operand
+        leaves = [t.clone().requires_grad_(True) for t in xs]
+        x = torch.cat([F.interpolate(t, scale_factor=2, mode="nearest") if up else t for t, (_, up) in zip(leaves, srcs)], dim=1)
+        wq = (w if stem else w.to(bf).float()).clone().requires_grad_(True)          # stem weights stay exact (hi + lo)
+        bl = bias.clone().requires_grad_(True)
+        conv = (lambda a_, w_, b_: F.conv3d(a_, w_, b_, padding=1)) if k == 3 else (lambda a_, w_, b_: F.conv3d(a_, w_, b_, stride=k))
+        y = conv(x, wq, bl)
+        y16 = _cf(r["y16"].float().cpu())
+        worst[name + " fwd"] = e = rel(y16, y)
+        assert e <= 4.5e-3, (name, "forward conv", e)
+        # GroupNorm + SiLU backward on the raw 16-bit output the kernel read
+        dz, dzs = r["dz"]
+        dz = _cf(dz.float().cpu()) * (1.0 if dzs is None else float(dzs[1]))
+        yl = y16.clone().requires_grad_(True)
+        gl, btl = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        F.silu(F.group_norm(yl, 8, gl, btl, eps=1e-5)).backward(dz)
+        sc = r["scale"].cpu()
+        dy16 = _cf(r["dy16"].float().cpu()) * float(sc[1])
+        worst[name + " gn_bwd"] = e = rel(dy16, yl.grad)
+        assert e <= 6e-3, (name, "GroupNorm backward dy", e)
+        assert rel(r["g_gamma"].cpu(), gl.grad) <= 2e-3 and rel(r["g_beta"].cpu(), btl.grad) <= 2e-3, (name, "dgamma / dbeta")
+        # weight / bias / data gradients from the dy the kernels actually read (the stem's weight gradient reads the
+        # unrounded fp32 image)
+        if stem:
+            xw = srcs[0][0].clone()
+            yw = conv(xw, wq, bl)
+            yw.backward(dy16)
+        else:
+            y.backward(dy16)
+        worst[name + " wgrad"] = e = rel(r["g_weight"].cpu(), wq.grad)
+        assert e <= 1e-3, (name, "weight gradient", e)
+        assert rel(r["g_bias"].cpu(), bl.grad) <= 1e-3, (name, "bias gradient")
+        if not stem and k in (1, 3):
+            xx = x.detach().clone().requires_grad_(True)
+            conv(xx, wq.detach(), None).backward(dy16)
+            for lo, dx16 in r["dx16"].items():
+                c = dx16.shape[-1]
+                got = _cf(dx16.float().cpu()) * float(sc[1])
+                worst[name + f" dgrad@{lo}"] = e = rel(got, xx.grad[:, lo:lo + c])
+                assert e <= 4.5e-3, (name, "data gradient", lo, e)
+            assert r["dx16"], name
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:6]
+    print("bf16 step replayed in situ, largest relative errors:", ", ".join(f"{k_} {v:.1e}" for k_, v in top))
 
 
 @pytest.mark.parametrize("precision", ["bf16", "mixed"])
