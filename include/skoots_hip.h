@@ -195,6 +195,15 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
               void* out, int B, int ox, int oy, int oz, int cout, int ksize,
               float* gn_partial, void* zero_page, void* stream);
 
+/* sk_conv3d with a STORE BOX (round 3): store_box = {lo_x, lo_y, lo_z, hi_x, hi_y, hi_z} (host, tile-local, half open)
+ * or NULL.  The convolution and its GroupNorm partial sums cover the whole tile as always; output voxels outside the
+ * box may be left unwritten -- for a tensor whose only reader looks at a box of it (the last block's conv: the heads
+ * evaluate the scatter's box, 28 % of a 300x300x20 tile).  Honoured by the single-chunk 32 -> 32 kernel
+ * (conv3_px_kernel); every other shape stores the whole tile, which satisfies the contract too. */
+int sk_conv3d_box(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,
+                  int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial,
+                  void* zero_page, const int* store_box, void* stream);
+
 /* 2x2x2 stride-2 down conv with the GroupNorm + SiLU of its INPUT folded in (the fused form of north_star's
  * "fused GroupNorm+SiLU" for the two skip tensors): in_raw (B, 2ox, 2oy, 2oz, cin) fp16 is the RAW output of the
  * producing conv, affine (B, 2, cin) its GroupNorm coefficients.  The kernel stages the input through LDS, activates

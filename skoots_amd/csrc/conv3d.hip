@@ -32,6 +32,7 @@
 //     sk_groupnorm_finalize (deterministic, no float atomics).
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -79,6 +80,7 @@ struct Conv3Args {
     const float* act[2];
     long long* dbg;     // -DSK_TIMING builds: per-wave phase cycle sums
     int alt;            // multi-chunk layers: visit the chunks in alternating order (see `reuse` in the kernels)
+    int has_box, box_lo[3], box_hi[3];   // sk_conv3d_box: only the output voxels inside [lo, hi) are STORED (conv3_px_kernel)
     int ablate;         // timing experiments only (-DSK_TUNING builds, SK_CONV_ABLATE): 1 skip DMA, 2 reuse first weights, 4 skip stores
     // per phase chunk: bit 0 = source, bit 1 = "same LDS image as the previous chunk: no DMA", bits 8.. = byte offset of
     // the chunk inside the source's voxel line
@@ -1203,6 +1205,455 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// conv3_px_kernel (round 3): the single-chunk COUT-32 layers (32 -> 32: enc0.1, dec0.1) marching along x by INPUT
+// plane -- different wave work per step, not different knobs.
+//
+// conv3_m16_kernel's step is serial inside a workgroup: MFMAs over a six-plane ring, barrier, the NEXT step's LDS-DMA
+// (11 pieces per wave), 24 weight-fragment loads streamed behind the MFMAs, epilogue (8 stores), landing wait, barrier --
+// 43 vector-memory instructions per wave and step, and DESIGN.md section 8 prices each at 100-350 cycles of wave time
+// (profiles/r03_conv_sq_counters.json: MFMA busy 0.555 against 0.70-0.75 for the COUT 64 / 128 kernels).  Here
+//   * a step consumes TWO input planes; input plane x contributes its 27 taps to the output planes x-1, x, x+1, so four
+//     rolling accumulator planes are live (64 registers, as before) and two output planes complete per step;
+//   * what a step reads from the ring is only its own two planes: the ring holds 4 plane slots (2 being read, 2 landing)
+//     instead of 6, and the LDS-DMA of the planes of step s+1 is issued at the START of step s -- a whole step of MFMAs
+//     (~3.5 k cycles) to land in, nothing serial about it;
+//   * the LDS the ring gives back holds the weights: RESW tap rows in registers, the other 9 - RESW rows in LDS (one copy
+//     per workgroup, loaded once per x-chunk) -- NO weight fragment is loaded in the loop: a wave issues 5-6 LDS-DMA
+//     pieces + 4 stores per 216 MFMAs where conv3_m16_kernel issues 43 vector-memory instructions per 432;
+//   * B fragments: one ds_read_b128 feeds the three x-taps of both cout halves (6 MFMAs), 0.17 reads per MFMA against
+//     0.25; the LDS-resident weight rows add 0.14.
+// The summation order of an output voxel (x-tap major) is a function of the voxel alone: batch- and chunk-invariant
+// like conv3_m16_kernel's, not bit-identical to it (asserted against torch to one fp16 ulp like every conv kernel,
+// bit-exact on integer operands).
+// Store box (Conv3Args.box, sk_conv3d_box): only the voxels inside it are stored -- the statistics still cover the
+// whole tile.  The last block's conv (dec0.1) is read by the heads on 28 % of the tile (the scatter's box).
+template <int RESW, int NPOSP>
+__global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
+    constexpr int NSLOT = 4;
+    constexpr int plane_bytes = NPOSP * kPosBytes;   // compile-time: a slot's offset is an immediate of its ds_read_b128
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // column tile of this wave (32 voxels of the 128-voxel patch)
+    const int c16 = lane & 15, g = lane >> 4;
+
+    int blk = blockIdx.x;   // XCD-aware order, see conv3_kernel
+    {
+        const int nwg = gridDim.x, xcd = blk & 7, qn = nwg >> 3, rn = nwg & 7;
+        blk = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blk >> 3);
+    }
+    const int patch = blk % a.npatch;
+    blk /= a.npatch;
+    const int xc = blk % a.nxc;
+    const int b = blk / a.nxc;
+    const int block_in_batch = xc * a.npatch + patch;
+    const int nblk = a.npatch * a.nxc;
+
+    // ---- patch geometry (conv3_m16_kernel's, one column tile per wave) ---------------------------
+    const int pitch = a.pitch;
+    int off, ybase, zbase, q_row, out_vox0, tile_nvox;
+    int svy, svz;             // (y, z) of the voxel this lane STORES: column c16 + 16 (g & 1) of the wave's tile
+    unsigned vflags = 0;      // bit j: voxel 16 j + c16 on the z = 0 face | << 8: on the z = Zt-1 face | << 16: inside the tile
+    auto zlo = [&](int j) { return (vflags >> j) & 1u; };
+    auto zhi = [&](int j) { return (vflags >> (8 + j)) & 1u; };
+    auto vvalid = [&](int j) { return (vflags >> (16 + j)) & 1u; };
+    // linear mode only (Zt <= 40, conv3_m16_kernel's comment): region position q <-> in-plane voxel v0 - Zt - 1 + q
+    const int needed = kPatch + 2 * a.Zt + 2;   // positions a plane really holds; NPOSP rounds it up to a DMA granule
+    {
+        const int v0 = patch * kPatch;
+        off = v0 - a.Zt - 1;
+        ybase = 0;
+        zbase = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int v = v0 + 32 * w + 16 * j + c16;
+            const int vy = v / a.Zt, vz = v - vy * a.Zt;
+            vflags |= (unsigned)(v < a.Yt * a.Zt) << (16 + j);
+            vflags |= (unsigned)(vz == 0) << j;
+            vflags |= (unsigned)(vz == a.Zt - 1) << (8 + j);
+            if (j == 0) q_row = v - off;
+        }
+        out_vox0 = v0 + 32 * w;
+        tile_nvox = a.Yt * a.Zt;
+        const int sv = out_vox0 + c16 + 16 * (g & 1);
+        svy = sv / a.Zt;
+        svz = sv - svy * a.Zt;
+    }
+    const bool sbox = !a.has_box || (svy >= a.box_lo[1] && svy < a.box_hi[1] && svz >= a.box_lo[2] && svz < a.box_hi[2]);
+
+    // ---- LDS-DMA bookkeeping: this lane's slots of a plane (conv3_m16_kernel's swizzle) -----------
+    constexpr int ndma = NPOSP / 16;
+    int d_vox[kMaxDma];
+    const int d_cs = ((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 16;
+#pragma unroll
+    for (int k = 0; k < kMaxDma; ++k) {
+        const int t = w + 4 * k;
+        const int q = (64 * t + lane) >> 2;
+        const int Pq = q + off;
+        const int y = ybase + (Pq >= 0 ? Pq / pitch : -1), z = zbase + (Pq >= 0 ? Pq % pitch : 0);
+        // positions >= needed are padding: kept zero (one of them is every tap's zero position)
+        const bool ok = (t < ndma) && q < needed && y >= 0 && y < a.Yt && z >= 0 && z < a.Zt;
+        d_vox[k] = ok ? y * a.Zt + z : -1;
+    }
+
+    const int xa = xc * a.XC;
+    const int xb = min(xa + a.XC, a.Xt);
+    const int n = xb - xa;                 // output planes xa .. xb-1 of this workgroup
+    const int nin = n + 2;                 // input planes t = 0 .. nin-1 <-> x = xa - 1 + t; plane t lives in slot t & 3
+    const int zero_addr = needed * kPosBytes;   // first padding position of a plane: the LDS-DMA rewrites it with zeros every time
+    constexpr int kOvs = 64;               // bytes per output voxel (32 channels)
+    const long long out_plane = (long long)a.Yt * a.Zt * kOvs;
+    char* outb = a.out + (long long)b * a.Xt * out_plane;
+    const SrcDev s0 = a.src[0];
+    const char* srcb = s0.data + (long long)b * s0.batch;
+
+    auto issue_plane = [&](int t) {
+        const int x = xa - 1 + t;
+        if (x < 0 || x >= a.Xt) return;   // outside the tile: the steps that would read it skip their MFMAs
+        const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(srcb + (long long)x * s0.plane, (unsigned)s0.plane);
+        char* lbase = lds + (t & (NSLOT - 1)) * plane_bytes;
+#pragma unroll
+        for (int k = 0; k < kMaxDma; ++k) {
+            const int tt = w + 4 * k;
+            if (tt < ndma) {
+                const unsigned voff = d_vox[k] >= 0 ? (unsigned)d_vox[k] * 64u + (unsigned)d_cs : sk::kOob;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lbase + tt * 1024), 16, voff, 0, 0, 0);
+            }
+        }
+    };
+    // GroupNorm affine + SiLU of a RAW source in LDS, by the lane that staged the piece (conv3_m16_kernel's `activate`)
+    const float* af = a.act[0];
+    auto activate_plane = [&](int t) {
+        const int x = xa - 1 + t;
+        if (x < 0 || x >= a.Xt) return;
+        const int c0 = (d_cs / 16) * 8;
+        float ga[8], gb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ga[j] = af[((long long)b * 2) * 32 + c0 + j];
+            gb[j] = af[((long long)b * 2 + 1) * 32 + c0 + j];
+        }
+        char* lbase = lds + (t & (NSLOT - 1)) * plane_bytes;
+        half8 v[kMaxDma];
+#pragma unroll
+        for (int k = 0; k < kMaxDma; ++k)
+            if (w + 4 * k < ndma) v[k] = *reinterpret_cast<const half8*>(lbase + (w + 4 * k) * 1024 + lane * 16);
+#pragma unroll
+        for (int k = 0; k < kMaxDma; ++k) {
+            const int tt = w + 4 * k;
+            if (tt < ndma) {
+                const bool real = d_vox[k] >= 0;
+                half8 r;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {   // gn_silu_kernel's arithmetic, op for op
+                    const float y = fmaf(ga[e], (float)v[k][e], gb[e]);
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+                    r[e] = real ? (t16)(y * sg) : v[k][e];
+                }
+                *reinterpret_cast<half8*>(lbase + tt * 1024 + lane * 16) = r;
+            }
+        }
+    };
+
+    // ---- weights: rows 0 .. RESW-1 in registers, rows RESW .. 8 in LDS behind the ring -------------------
+    // fragment of (row dydz, cout half i, x tap d): ((dydz * 2 + i) * 3 + d) KiB into the packed weight
+    const __amdgpu_buffer_rsrc_t wrsrc = sk::make_rsrc(a.wpk, 54u * 1024u);
+    half8 wres[2 * RESW][3];
+#pragma unroll
+    for (int r = 0; r < 2 * RESW; ++r)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            wres[r][d] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, (r * 3 + d) * 1024, 0));
+    char* wlds = lds + NSLOT * plane_bytes;
+    for (int i = tid; i < (9 - RESW) * 6 * 64; i += 256)
+        *reinterpret_cast<uint4*>(wlds + i * 16) = *reinterpret_cast<const uint4*>(a.wpk + RESW * 6 * 1024 + i * 16);
+
+    int issued = 0;
+    auto issue_upto = [&](int lim) {   // planes [issued, min(nin, lim))
+        const int hi = min(nin, lim);
+        const int lo = issued;
+        for (int t = lo; t < hi; ++t) issue_plane(t);
+        issued = max(issued, hi);
+        return lo;
+    };
+    issue_upto(NSLOT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (af) {
+        for (int t = 0; t < issued; ++t) activate_plane(t);
+    }
+    __syncthreads();
+
+    // ---- accumulators ----------------------------------------------------------------------------------------
+    // element r of [i][j]: cout 16 i + 4 g + r, voxel 16 j + c16 of the wave's column tile
+    f32x4 P0[2][2], P1[2][2], Q0[2][2], Q1[2][2];
+    const f32x4 bias0 = *reinterpret_cast<const f32x4*>(a.bias + 4 * g), bias1 = *reinterpret_cast<const f32x4*>(a.bias + 4 * g + 16);
+    auto reset = [&](f32x4 (&o)[2][2]) {
+        o[0][0] = o[0][1] = bias0;
+        o[1][0] = o[1][1] = bias1;
+    };
+    reset(P0);
+    reset(P1);
+    reset(Q0);
+    reset(Q1);
+    float gsum[2] = {0.0f, 0.0f}, gsq[2] = {0.0f, 0.0f};
+
+    auto baddr = [&](int dydz, int j) -> int {
+        const int dz = dydz % 3 - 1;
+        const int q = q_row + (dydz / 3 - 1) * pitch + dz;
+        int addr = (q * 4 + (g ^ (((q >> 2) & 1) << 1))) * 16 + 1024 * j;
+        if (dz < 0) addr = zlo(j) ? zero_addr : addr;
+        if (dz > 0) addr = zhi(j) ? zero_addr : addr;
+        return addr;
+    };
+    auto wfrag = [&](int dydz, int i, half8 (&dst)[3]) {
+        if (dydz < RESW) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) dst[d] = wres[2 * dydz + i][d];
+        } else {
+            const char* p = wlds + ((dydz - RESW) * 6 + i * 3) * 1024 + lane * 16;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) dst[d] = *reinterpret_cast<const half8*>(p + d * 1024);
+        }
+    };
+
+    // A step over the input planes A (slot sA) and B = A + 1 (slot sB).  oA1 / oA / oB / oB1: the accumulators of the
+    // output planes A-1, A, B, B+1.  Tap d of a weight row multiplies x_in = x_out + d - 1.
+    auto pair_step = [&](auto SA, auto SB, f32x4 (&oA1)[2][2], f32x4 (&oA)[2][2], f32x4 (&oB)[2][2], f32x4 (&oB1)[2][2]) {
+        // compile-time slots: the 18 tap addresses of the patch (plane-relative, loop-invariant) serve both planes of
+        // every step through the immediate offset of ds_read_b128
+        const char* pa = lds + decltype(SA)::value * plane_bytes;
+        const char* pb = lds + decltype(SB)::value * plane_bytes;
+        half8 bq[2][2][2];   // [buffer][plane][j]: the B fragments of a tap row, one row ahead
+        half8 wq[2][3];      // [buffer][d]: the weight fragments of a half row, one half row ahead
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ad = baddr(0, j);
+            bq[0][0][j] = *reinterpret_cast<const half8*>(pa + ad);
+            bq[0][1][j] = *reinterpret_cast<const half8*>(pb + ad);
+        }
+        wfrag(0, 0, wq[0]);
+#pragma unroll
+        for (int dydz = 0; dydz < 9; ++dydz) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int h = dydz * 2 + i;   // half-row index: its weights sit in wq[h & 1], its B fragments in bq[dydz & 1]
+                int nreads = 0;
+                if (i == 0) {
+                    wfrag(dydz, 1, wq[(h + 1) & 1]);
+                    nreads = dydz < RESW ? 0 : 3;
+                } else if (dydz < 8) {
+                    wfrag(dydz + 1, 0, wq[(h + 1) & 1]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ad = baddr(dydz + 1, j);
+                        bq[(dydz + 1) & 1][0][j] = *reinterpret_cast<const half8*>(pa + ad);
+                        bq[(dydz + 1) & 1][1][j] = *reinterpret_cast<const half8*>(pb + ad);
+                    }
+                    nreads = 4 + (dydz + 1 < RESW ? 0 : 3);
+                }
+                // the next half row's LDS reads one per MFMA gap at the head of this half row's 12 MFMAs (the builtin wants
+                // literal counts: the four cases of `nreads`, three of them dead after unrolling)
+#define SK_PX_PAIR(n) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                if (nreads == 3) {
+                    SK_PX_PAIR(0) SK_PX_PAIR(1) SK_PX_PAIR(2)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+                } else if (nreads == 4) {
+                    SK_PX_PAIR(0) SK_PX_PAIR(1) SK_PX_PAIR(2) SK_PX_PAIR(3)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                } else if (nreads == 7) {
+                    SK_PX_PAIR(0) SK_PX_PAIR(1) SK_PX_PAIR(2) SK_PX_PAIR(3) SK_PX_PAIR(4) SK_PX_PAIR(5) SK_PX_PAIR(6)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+                }
+#undef SK_PX_PAIR
+                const half8(&W)[3] = wq[h & 1];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const half8 fa = bq[dydz & 1][0][j], fb = bq[dydz & 1][1][j];
+                    oB[i][j] = SK_MFMA_16x16x32_T16(W[0], fa, oB[i][j], 0, 0, 0);
+                    oB1[i][j] = SK_MFMA_16x16x32_T16(W[0], fb, oB1[i][j], 0, 0, 0);
+                    oA[i][j] = SK_MFMA_16x16x32_T16(W[1], fa, oA[i][j], 0, 0, 0);
+                    oA1[i][j] = SK_MFMA_16x16x32_T16(W[2], fa, oA1[i][j], 0, 0, 0);
+                    oB[i][j] = SK_MFMA_16x16x32_T16(W[1], fb, oB[i][j], 0, 0, 0);
+                    oA[i][j] = SK_MFMA_16x16x32_T16(W[2], fb, oA[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // one input plane, a subset of its three x taps (the planes at the ends of an x-chunk)
+    auto single_step = [&](auto D0, auto D1, auto D2, int s, f32x4 (&o0)[2][2], f32x4 (&o1)[2][2], f32x4 (&o2)[2][2]) {
+        const char* pa = lds + s * plane_bytes;
+#pragma unroll
+        for (int dydz = 0; dydz < 9; ++dydz) {
+            half8 fa[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fa[j] = *reinterpret_cast<const half8*>(pa + baddr(dydz, j));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                half8 W[3];
+                wfrag(dydz, i, W);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (decltype(D0)::value) o0[i][j] = SK_MFMA_16x16x32_T16(W[0], fa[j], o0[i][j], 0, 0, 0);
+                    if constexpr (decltype(D1)::value) o1[i][j] = SK_MFMA_16x16x32_T16(W[1], fa[j], o1[i][j], 0, 0, 0);
+                    if constexpr (decltype(D2)::value) o2[i][j] = SK_MFMA_16x16x32_T16(W[2], fa[j], o2[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // raw fp16 store of one finished output plane + its GroupNorm partial sums (conv3_m16_kernel's epilogue); returns the
+    // number of store instructions issued (0 or 2: the counted landing wait needs it)
+    auto finish_plane = [&](f32x4 (&o)[2][2], int x) -> int {
+        const bool xbox = !a.has_box || (x >= a.box_lo[0] && x < a.box_hi[0]);   // wave-uniform
+        const __amdgpu_buffer_rsrc_t rout = sk::make_rsrc(outb + (long long)x * out_plane, (unsigned)out_plane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned d[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 r = o[i][j];
+                const half4 hv = {(t16)r[0], (t16)r[1], (t16)r[2], (t16)r[3]};
+                const uint2 u = __builtin_bit_cast(uint2, hv);
+                d[j][0] = u.x;
+                d[j][1] = u.y;
+                const bool in = vvalid(j);
+                const t16x2 z2 = {(t16)0.0f, (t16)0.0f}, one2 = {(t16)1.0f, (t16)1.0f};
+                const t16x2 lo2 = in ? t16x2{hv[0], hv[1]} : z2, hi2 = in ? t16x2{hv[2], hv[3]} : z2;
+                gsum[i] = SK_DOT2_T16(lo2, one2, gsum[i]);
+                gsum[i] = SK_DOT2_T16(hi2, one2, gsum[i]);
+                gsq[i] = SK_DOT2_T16(lo2, lo2, gsq[i]);
+                gsq[i] = SK_DOT2_T16(hi2, hi2, gsq[i]);
+            }
+            if (xbox) {
+                const auto s0_ = __builtin_amdgcn_permlane16_swap(d[0][0], d[1][0], false, false);
+                const auto s1_ = __builtin_amdgcn_permlane16_swap(d[0][1], d[1][1], false, false);
+                // this lane now owns channels 16 i + 8 (g >> 1) .. +7 of voxel c16 + 16 (g & 1)
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 lv = {s0_[0], s1_[0], s0_[1], s1_[1]};
+                const int vv = c16 + 16 * (g & 1);
+                const bool sok = sbox && out_vox0 + vv < tile_nvox;
+                const unsigned so = (unsigned)((out_vox0 + vv) * kOvs + 32 * i + 16 * (g >> 1));
+                __builtin_amdgcn_raw_buffer_store_b128(lv, rout, sok ? so : sk::kOob, 0, 0);
+            }
+        }
+        return xbox ? 2 : 0;
+    };
+    // end of a step: this wave's LDS-DMA of the step (issued before its MFMAs, older than its `ns` stores) has landed ->
+    // activate what it staged -> barrier: every wave is done with the step's planes and sees the landed ones
+    auto end_step = [&](int ns, int t_lo, int t_hi) {
+        if (ns == 4)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (ns == 2)
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (af) {
+            for (int t = t_lo; t < t_hi; ++t) activate_plane(t);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    typedef std::integral_constant<bool, true> T_;
+    typedef std::integral_constant<bool, false> F_;
+
+    // ---- the march -----------------------------------------------------------------------------------------------
+    // P0 / P1: the two oldest live output planes (P0 = plane xa - 1 at first: never stored), Q0 / Q1 the next two
+    int t = 0;
+    {   // plane xa - 1 reaches only output plane xa (tap d = 0)
+        const int lo = issue_upto(t + NSLOT);
+        if (xa > 0) single_step(T_{}, F_{}, F_{}, 0, P1, P1, P1);
+        end_step(0, lo, issued);
+        t = 1;
+    }
+    const int npairs = n >> 1;
+    typedef std::integral_constant<int, 0> S0_;
+    typedef std::integral_constant<int, 1> S1_;
+    typedef std::integral_constant<int, 2> S2_;
+    typedef std::integral_constant<int, 3> S3_;
+    // Pair steps alternate between two fixed role assignments: input planes t = 1 + 2 pi live in slots (1, 2) for even pi
+    // and (3, 0) for odd pi, and the accumulator pairs P / Q swap roles -- two straight-line bodies, every register fixed.
+    auto even_step = [&]() {
+        const int lo = issue_upto(t + NSLOT);
+        const int xA = xa - 1 + t;   // input plane A = the output plane of the second-oldest accumulator
+        pair_step(S1_{}, S2_{}, P0, P1, Q0, Q1);
+        int ns = 0;
+        if (xA - 1 >= xa) ns += finish_plane(P0, xA - 1);
+        ns += finish_plane(P1, xA);
+        reset(P0);
+        reset(P1);
+        end_step(ns, lo, issued);
+        t += 2;
+    };
+    auto odd_step = [&]() {
+        const int lo = issue_upto(t + NSLOT);
+        const int xA = xa - 1 + t;
+        pair_step(S3_{}, S0_{}, Q0, Q1, P0, P1);
+        int ns = finish_plane(Q0, xA - 1);
+        ns += finish_plane(Q1, xA);
+        reset(Q0);
+        reset(Q1);
+        end_step(ns, lo, issued);
+        t += 2;
+    };
+    for (int pi = 0; pi + 1 < npairs; pi += 2) {
+        even_step();
+        odd_step();
+    }
+    if (npairs & 1) even_step();
+    if (npairs & 1) {   // the two oldest live planes are Q0 / Q1: rename (once per workgroup)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                P0[i][j] = Q0[i][j];
+                P1[i][j] = Q1[i][j];
+            }
+    }
+    if (n & 1) {   // plane xb - 1 alone: taps d = 2 -> P0 (xb - 2), d = 1 -> P1 (xb - 1)
+        const int lo = issue_upto(t + NSLOT);
+        single_step(F_{}, T_{}, T_{}, t & 3, P0, P1, P0);
+        int ns = 0;
+        if (xb - 2 >= xa) ns += finish_plane(P0, xb - 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) P0[i][j] = P1[i][j];
+        end_step(ns, lo, issued);
+        t += 1;
+    }
+    // plane xb reaches only output plane xb - 1 (tap d = 2)
+    if (xb < a.Xt) single_step(F_{}, F_{}, T_{}, t & 3, P0, P0, P0);
+    finish_plane(P0, xb - 1);
+
+    // ---- block-level reduction of the GroupNorm partials (conv3_m16_kernel's) --------------------------------
+    if (a.partial) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float s = gsum[i], ss = gsq[i];
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) {
+                s += __shfl_xor(s, m);
+                ss += __shfl_xor(ss, m);
+            }
+            if (c16 == 0) {
+                red[(w * 8 + 4 * i + g) * 2 + 0] = s;
+                red[(w * 8 + 4 * i + g) * 2 + 1] = ss;
+            }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            float tsum = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tsum += red[q * 16 + tid];
+            a.partial[((long long)b * nblk + block_in_batch) * 16 + tid] = tsum;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Gather GEMM for the layers with no spatial reuse of activations: 2x2x2 stride-2
 // down-sampling convs (8 taps, each input voxel feeds one output voxel) and 1x1x1
 // channel reducers.  B fragments come straight from global memory (16 B per lane),
@@ -1710,6 +2161,25 @@ int launch_conv3_m16(const Conv3Args& a, const Plan& p, hipStream_t stream) {
     return SK_OK;
 }
 
+// conv3_px_kernel is built for the plane geometry of the production tile: linear mode with 176 positions per plane
+// (Zt 16 .. 22: 128 + 2 Zt + 2 positions, at least one padding position left for the taps' zero position).  RESW tap rows
+// in registers, the other rows in LDS: 4 plane slots (44 KiB) + 6 rows (36 KiB) = 80 KiB, two workgroups per CU.
+constexpr int kPxResidentRows = 3;
+constexpr int kPxPositions = 176;
+constexpr size_t kPxLds = (size_t)4 * kPxPositions * kPosBytes + (size_t)(9 - kPxResidentRows) * 6144;
+bool conv3_px_covers(const Plan& p, int Zt) { return p.mode == 0 && p.nposp == kPxPositions && kPatch + 2 * Zt + 2 < kPxPositions; }
+
+int launch_conv3_px(const Conv3Args& a, const Plan& p, hipStream_t stream) {
+    auto kern = conv3_px_kernel<kPxResidentRows, kPxPositions>;
+    const size_t lds = kPxLds;
+    static_assert(kPxLds <= 80 * 1024, "two workgroups per CU");
+    SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    unsigned grid = (unsigned)(p.npatch * p.nxc * a.B);
+    kern<<<grid, 256, lds, stream>>>(a);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
 template <int COUT, int XS, int RES = 0, bool SPLIT = false>
 int launch_conv3(const Conv3Args& a, const Plan& p, hipStream_t stream) {
     auto kern = conv3_kernel<COUT, XS, RES, SPLIT>;
@@ -1824,7 +2294,7 @@ static int launch_down2(const void* in, const float* affine, int writeback, cons
 
 static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,
                        int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial,
-                       void* zeros, void* stream_, const bool split) {
+                       void* zeros, void* stream_, const bool split, const int* store_box = nullptr) {
     hipStream_t stream = (hipStream_t)stream_;
     const int lanes = split ? 2 : 1;   // fp16 values per logical channel in a voxel line: [hi | lo]
     SK_CHECK_ARG(srcs && weight && bias && out, "sk_conv3d: NULL pointer");
@@ -1915,6 +2385,21 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
             if (cout == 64) return p.xs == 3 ? launch_conv3<64, 3, 0, true>(a, p, stream) : launch_conv3<64, 4, 0, true>(a, p, stream);
             return launch_conv3<128, 2, 0, true>(a, p, stream);
         }
+        a.has_box = 0;
+        if (store_box) {
+            for (int k = 0; k < 3; ++k) {
+                a.box_lo[k] = store_box[k];
+                a.box_hi[k] = store_box[3 + k];
+                SK_CHECK_ARG(a.box_lo[k] >= 0 && a.box_lo[k] <= a.box_hi[k], "sk_conv3d_box: bad box on axis %d", k);
+            }
+            a.has_box = 1;
+        }
+        bool use_px = cout == 32 && a.nchunks == 1 && n_src == 1 && !srcs[0].upsample && conv3_px_covers(p, oz) && !a.ablate;
+#ifdef SK_TUNING
+        if (getenv("SK_CONV_NO_PX")) use_px = false;   // A/B: the single-chunk COUT-32 layers on conv3_m16_kernel
+#endif
+        if (use_px) return launch_conv3_px(a, p, stream);
+        a.has_box = 0;   // the other kernels store the whole tile (a superset of any box)
         if (cout == 32) {   // 16x16x32 kernel
             if (p.xs == 3) return launch_conv3_m16<3>(a, p, stream);
             if (a.nchunks == 1 && !a.ablate) {   // single chunk: 3 tap rows in registers, 2 more in LDS where they fit
@@ -1978,6 +2463,13 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
               int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial,
               void* zeros, void* stream) {
     return conv3d_impl(srcs, n_src, weight, bias, out, B, ox, oy, oz, cout, ksize, gn_partial, zeros, stream, false);
+}
+
+int sk_conv3d_box(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,
+                  int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial,
+                  void* zeros, const int* store_box, void* stream) {
+    SK_CHECK_ARG(ksize == 3 || store_box == nullptr, "sk_conv3d_box: a store box needs ksize 3");
+    return conv3d_impl(srcs, n_src, weight, bias, out, B, ox, oy, oz, cout, ksize, gn_partial, zeros, stream, false, store_box);
 }
 
 int sk_conv3d_down_act(void* in_raw, const float* affine, const void* weight, const float* bias, void* out, int B,

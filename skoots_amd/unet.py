@@ -149,6 +149,7 @@ class HipUNet:
         self.profile: Optional[ConvProfile] = None
         self.defer_activation = True  # single-consumer tensors stay RAW and are activated on load (tools/ A/B switch)
         self.fold_upsample = True     # decoder convs: nearest-upsample folded into the weights (sk_conv3d_upfold; tools/ A/B switch)
+        self.box_store = True         # with an out_box the last conv stores only the box the heads read (sk_conv3d_box; tools/ A/B switch)
 
     @property
     def split(self) -> bool:
@@ -199,9 +200,11 @@ class HipUNet:
         return aff
 
     def _conv(self, layer: _ConvLayer, srcs: List[Tuple], out_shape: Tuple[int, int, int],
-              tag: str, activate: bool = True):
+              tag: str, activate: bool = True, store_box=None):
         """srcs: [(tensor, upsample flag[, affine])].  Returns the activated output, or
-        (raw output, affine) when ``activate`` is False."""
+        (raw output, affine) when ``activate`` is False.  ``store_box`` = (lo, hi): the only reader of the output looks at
+        this box of it (the heads, with an ``out_box``): the conv may leave the rest unwritten (sk_conv3d_box; its
+        GroupNorm statistics cover the whole tile regardless)."""
         B = srcs[0][0].shape[0]
         ox, oy, oz = out_shape
         split = self.split
@@ -237,6 +240,11 @@ class HipUNet:
             _ffi.check(ufn(arr[0].data, arr[0].c, arr[1].data, arr[1].c,
                            _ffi.ptr(layer.packed_upfold(arr[0].c, split)), _ffi.ptr(layer.bias), _ffi.ptr(out),
                            B, ox, oy, oz, layer.cout, _ffi.ptr(partial), _ffi.stream_ptr(self.device)))
+        elif store_box is not None and not split and layer.ksize == 3 and not activate:
+            box = (C.c_int32 * 6)(*[int(v) for v in store_box[0]], *[int(v) for v in store_box[1]])
+            _ffi.check(_ffi.lib.sk_conv3d_box(arr, len(srcs), _ffi.ptr(layer.packed(False)), _ffi.ptr(layer.bias),
+                                              _ffi.ptr(out), B, ox, oy, oz, layer.cout, layer.ksize,
+                                              _ffi.ptr(partial), _ffi.ptr(self.zeros), box, _ffi.stream_ptr(self.device)))
         else:
             fn = _ffi.lib.sk_conv3d_split if split else _ffi.lib.sk_conv3d
             _ffi.check(fn(arr, len(srcs), _ffi.ptr(layer.packed(split)), _ffi.ptr(layer.bias),
@@ -335,10 +343,10 @@ class HipUNet:
             if keep_features:
                 feats[name] = (t[0] if isinstance(t, tuple) else t).clone()
 
-        def block(layer, srcs, shape, tag, want_raw):
+        def block(layer, srcs, shape, tag, want_raw, store_box=None):
             """srcs: [((tensor, affine | None), upsample)]; returns (tensor, affine | None)."""
             flat = [(t, up, aff) for (t, aff), up in srcs]
-            out = self._conv(layer, flat, shape, tag, activate=not want_raw)
+            out = self._conv(layer, flat, shape, tag, activate=not want_raw, store_box=store_box)
             return out if want_raw else (out, None)
 
         a = (self._stem(self.enc0[0], image, origins, L0, float(mean), float(std),
@@ -385,7 +393,9 @@ class HipUNet:
             last = i == len(self.dec0) - 1
             raw = (self.defer_activation and last) or (not last and lds_act(self.dec0[i + 1]))  # last: consumed by the heads
             src = [(s0, 0), (r0, 1)] if i == 0 else [(a, 0)]
-            a = block(layer, src, L0, tags[i % 2], raw)
+            # the last conv's raw output is read by the heads alone, and with an out_box only inside it
+            sbox = out_box if (last and raw and out_box is not None and not keep_features and self.box_store) else None
+            a = block(layer, src, L0, tags[i % 2], raw, store_box=sbox)
             keep(layer.name, a)
         a, aff = a
         out5 = self._buf("out5", (B, 5, xt, yt, zt))

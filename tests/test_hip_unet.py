@@ -51,6 +51,15 @@ CONV_CASES = [
     (1, (5, 9, 5), [(64, 0)], 128, 2),
     (1, (9, 10, 5), [(128, 0)], 64, 1),          # pointwise reducers
     (1, (12, 10, 10), [(64, 0)], 32, 1),
+    # the plane-streaming 32 -> 32 kernel (conv3_px_kernel: 176-position planes, z 16 .. 22): x-chunks of 1, 2, 3 planes,
+    # an odd chunk behind even ones, several chunks with interior chunk seams, every z extent it covers
+    (1, (1, 12, 20), [(32, 0)], 32, 3),
+    (1, (2, 9, 20), [(32, 0)], 32, 3),
+    (1, (3, 12, 16), [(32, 0)], 32, 3),
+    (2, (37, 14, 20), [(32, 0)], 32, 3),
+    (1, (16, 30, 22), [(32, 0)], 32, 3),
+    (1, (9, 7, 18), [(32, 0)], 32, 3),
+    (1, (5, 8, 23), [(32, 0)], 32, 3),           # 176 positions with no padding position left: conv3_m16_kernel
 ]
 
 
@@ -152,6 +161,74 @@ def test_down_conv_with_fused_activation(U, B, osp, cin, cout):
     # and against torch on the activated operands
     ref = F.conv3d(_cf(act.cpu().float()), w.half().float(), bias.cpu(), stride=2)
     assert (_cf(got.cpu().float()) - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
+def _conv_ffi(srcs, wp, bias, out_shape, cout=32, box=None, affine=None, prefill=None):
+    """sk_conv3d / sk_conv3d_box through the C ABI with everything the U.conv3d helper leaves out."""
+    from skoots_amd import _ffi
+    import ctypes as C
+    B = srcs[0][0].shape[0]
+    ox, oy, oz = out_shape
+    dev = srcs[0][0].device
+    out = torch.empty((B, ox, oy, oz, cout), dtype=torch.float16, device=dev)
+    if prefill is not None:
+        out.fill_(prefill)
+    nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, cout, 3)
+    partial = torch.zeros((B, nblk, cout // 4, 2), dtype=torch.float32, device=dev)
+    arr = (_ffi.ConvSrc * len(srcs))()
+    for i, (t, up) in enumerate(srcs):
+        arr[i].data, arr[i].c, arr[i].upsample = t.data_ptr(), t.shape[-1], up
+        arr[i].affine = affine.data_ptr() if (affine is not None and i == 0) else None
+    zeros = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    bx = (C.c_int32 * 6)(*box) if box is not None else None
+    _ffi.check(_ffi.lib.sk_conv3d_box(arr, len(srcs), _ffi.ptr(wp), _ffi.ptr(bias), _ffi.ptr(out), B, ox, oy, oz, cout, 3,
+                                      _ffi.ptr(partial), _ffi.ptr(zeros), bx, _ffi.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    return out, partial
+
+
+@pytest.mark.parametrize("B,osp", [(1, (8, 12, 20)), (2, (37, 14, 20)), (1, (5, 9, 16)), (1, (6, 10, 10))])
+def test_conv_activates_a_raw_source_in_lds(U, B, osp):
+    """A RAW source (sk_conv_src.affine != NULL) is activated by the staging lanes in LDS -- silu(a*x + b), the
+    arithmetic of sk_groupnorm_silu op for op -- so the conv over it must equal, BIT FOR BIT, the conv over the tensor
+    the separate pass produces.  Covers conv3_px_kernel (z 16 / 20) and conv3_m16_kernel (z 10)."""
+    from skoots_amd import _ffi
+    gen = torch.Generator().manual_seed(osp[0] * 31 + osp[2])
+    x = torch.randn((B,) + osp + (32,), generator=gen).half().to(DEV)
+    aff = torch.stack([torch.rand((B, 32), generator=gen) + 0.5, torch.randn((B, 32), generator=gen) * 0.3], dim=1).to(DEV).contiguous()
+    w = torch.randn((32, 32, 3, 3, 3), generator=gen) / (32 * 27) ** 0.5
+    wp, bias = U.pack_conv_weight(w, DEV), (torch.randn(32, generator=gen) * 0.1).to(DEV)
+    fused, pf = _conv_ffi([(x, 0)], wp, bias, osp, affine=aff)
+    act = x.clone()
+    vox = osp[0] * osp[1] * osp[2]
+    _ffi.check(_ffi.lib.sk_groupnorm_silu(_ffi.ptr(act), _ffi.ptr(aff), B, vox, 32, _ffi.stream_ptr(torch.device(DEV))))
+    plain, pp = _conv_ffi([(act, 0)], wp, bias, osp)
+    assert torch.equal(fused, plain) and torch.equal(pf, pp)
+    a, b_ = aff[:, 0].cpu().view(B, 32, 1, 1, 1), aff[:, 1].cpu().view(B, 32, 1, 1, 1)
+    ref = F.conv3d(F.silu(_cf(x.cpu().float()) * a + b_).half().float(), w.half().float(), bias.cpu(), padding=1)
+    assert (_cf(fused.cpu().float()) - ref).abs().max().item() <= 3e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("osp,box", [((12, 30, 20), (3, 4, 2, 9, 25, 17)), ((37, 14, 20), (0, 0, 0, 37, 14, 20)),
+                                     ((9, 12, 20), (9, 0, 0, 9, 12, 20)), ((8, 12, 10), (2, 2, 2, 6, 9, 8))])
+def test_conv_store_box(U, osp, box):
+    """sk_conv3d_box: the voxels inside the box hold exactly what the plain launch stores, the GroupNorm partial sums
+    are those of the WHOLE tile (bit-identical to the plain launch), and a kernel that honours the box (conv3_px_kernel:
+    first three cases, the third with an empty box) leaves the voxels outside it untouched; the last case runs on a kernel that
+    stores everything, which the contract allows."""
+    gen = torch.Generator().manual_seed(osp[0] + 7 * osp[1])
+    x = torch.randn((2,) + osp + (32,), generator=gen).half().to(DEV)
+    w = torch.randn((32, 32, 3, 3, 3), generator=gen) / (32 * 27) ** 0.5
+    wp, bias = U.pack_conv_weight(w, DEV), (torch.randn(32, generator=gen) * 0.1).to(DEV)
+    full, pfull = _conv_ffi([(x, 0)], wp, bias, osp)
+    got, pbox = _conv_ffi([(x, 0)], wp, bias, osp, box=box, prefill=7.0)
+    assert torch.equal(pbox, pfull)
+    x0, y0, z0, x1, y1, z1 = box
+    assert torch.equal(got[:, x0:x1, y0:y1, z0:z1], full[:, x0:x1, y0:y1, z0:z1])
+    if osp[2] == 20:   # the plane-streaming kernel: nothing outside the box is written
+        outside = torch.ones(osp, dtype=torch.bool, device=DEV)
+        outside[x0:x1, y0:y1, z0:z1] = False
+        assert bool((got[:, outside] == 7.0).all())
 
 
 def test_conv_exact_integer_layout(U):

@@ -21,18 +21,20 @@ def main():
     batch = os.environ.get("BATCH", "8")
     for r in range(rounds):
         for lib in libs:
-            extra = []
+            extra, envx, label = [], {}, lib
             if lib.endswith(":nofold"):   # variant of a library: decoder convs on the direct kernel
                 lib, extra = lib[:-len(":nofold")], ["--no-fold"]
+            if lib.endswith(":nopx"):     # tuning build only: the single-chunk COUT-32 layers on conv3_m16_kernel
+                lib, envx = lib[:-len(":nopx")], {"SK_CONV_NO_PX": "1"}
             path = lib if os.path.isabs(lib) else os.path.join(ROOT, lib)
-            env = dict(os.environ, SKOOTS_HIP_LIB=path)
+            env = dict(os.environ, SKOOTS_HIP_LIB=path, **envx)
             p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_conv.py"), "--tile", tile, "--batch", batch,
                                 "--iters", "6", "--warmup", "2"] + extra, env=env, capture_output=True, text=True)
             if p.returncode != 0:
                 print(lib, "FAILED", p.stderr[-2000:], flush=True)
                 continue
             d = json.loads(p.stdout.strip().splitlines()[-1])
-            print(lib + ("" if not extra else ":nofold"), d["conv3_ms"], d["conv3_tflops"], "fwd", d["forward_ms"],
+            print(label, d["conv3_ms"], d["conv3_tflops"], "fwd", d["forward_ms"],
                   {k: v["ms"] for k, v in d["layers"].items()}, flush=True)
 
 
