@@ -79,6 +79,16 @@ static inline unsigned stream_grid(int64_t n, int block, int per_thread = 1) {
 }
 
 #ifdef __HIPCC__
+// fp32 -> 16-bit of a value that is itself the fp32 result of a multiply: the empty asm keeps the product an fp32 value
+// of its own, so the conversion is a plain v_cvt (two roundings, what gn_silu_kernel and the torch oracle do).  Without
+// it the compiler may fuse multiply + conversion into v_fma_mixlo_f16 -- ONE rounding, a different last bit in about
+// one value of two thousand -- and does so in some kernels and not in others (it did inside the conv kernels' in-LDS
+// activation, not in the GroupNorm pass: tests/test_hip_unet.py::test_conv_activates_a_raw_source_in_lds).
+__device__ inline t16 round_t16(float v) {
+    asm("" : "+v"(v));
+    return (t16)v;
+}
+
 // Buffer loads: the hardware bounds check returns 0 for an offset past the descriptor's byte count, so a
 // masked lane passes kOob instead of branching around the load (a branch per load lets the compiler chain
 // load -> wait -> use, one memory latency at a time).  The descriptor must be wave-uniform.

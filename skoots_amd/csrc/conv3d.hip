@@ -861,7 +861,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                     for (int e = 0; e < 8; ++e) {   // gn_silu_kernel's arithmetic, op for op
                         const float y = fmaf(ga[e], (float)v[k][e], gb[e]);
                         const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
-                        r[e] = real ? (t16)(y * sg) : v[k][e];
+                        r[e] = real ? sk::round_t16(y * sg) : v[k][e];
                     }
                     *reinterpret_cast<half8*>(lbase + t * 1024 + lane * 16) = r;
                 }
@@ -1292,9 +1292,10 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
         const int q = (64 * t + lane) >> 2;
         const int Pq = q + off;
         const int y = ybase + (Pq >= 0 ? Pq / pitch : -1), z = zbase + (Pq >= 0 ? Pq % pitch : 0);
-        // positions >= needed are padding: kept zero (one of them is every tap's zero position)
-        const bool ok = (t < ndma) && q < needed && y >= 0 && y < a.Yt && z >= 0 && z < a.Zt;
-        d_vox[k] = ok ? y * a.Zt + z : -1;
+        // positions >= needed are padding that the LDS-DMA never writes (d_vox -2: the lane sits out of the instruction):
+        // the first of them is every tap's zero position, the next four hold the GroupNorm coefficients of a raw source
+        const bool ok = (t < ndma) && y >= 0 && y < a.Yt && z >= 0 && z < a.Zt;
+        d_vox[k] = q >= needed ? -2 : (ok ? y * a.Zt + z : -1);
     }
 
     const int xa = xc * a.XC;
@@ -1316,7 +1317,7 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
 #pragma unroll
         for (int k = 0; k < kMaxDma; ++k) {
             const int tt = w + 4 * k;
-            if (tt < ndma) {
+            if (tt < ndma && d_vox[k] != -2) {   // padding lanes are masked out of the plane's last piece (EXEC)
                 const unsigned voff = d_vox[k] >= 0 ? (unsigned)d_vox[k] * 64u + (unsigned)d_cs : sk::kOob;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lbase + tt * 1024), 16, voff, 0, 0, 0);
             }
@@ -1327,12 +1328,14 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     auto activate_plane = [&](int t) {
         const int x = xa - 1 + t;
         if (x < 0 || x >= a.Xt) return;
-        const int c0 = (d_cs / 16) * 8;
+        // the coefficients of this lane's 8 channels, from the copy in LDS (a global load here cost the wave a memory
+        // latency and a vmcnt(0) per plane; keeping them in registers costs 16 of the 256)
+        const float* cf = reinterpret_cast<const float*>(lds + (needed + 1) * kPosBytes) + (d_cs / 16) * 8;
         float ga[8], gb[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            ga[j] = af[((long long)b * 2) * 32 + c0 + j];
-            gb[j] = af[((long long)b * 2 + 1) * 32 + c0 + j];
+            ga[j] = cf[j];
+            gb[j] = cf[32 + j];
         }
         char* lbase = lds + (t & (NSLOT - 1)) * plane_bytes;
         half8 v[kMaxDma];
@@ -1349,9 +1352,9 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
                 for (int e = 0; e < 8; ++e) {   // gn_silu_kernel's arithmetic, op for op
                     const float y = fmaf(ga[e], (float)v[k][e], gb[e]);
                     const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
-                    r[e] = real ? (t16)(y * sg) : v[k][e];
+                    r[e] = real ? sk::round_t16(y * sg) : v[k][e];
                 }
-                *reinterpret_cast<half8*>(lbase + tt * 1024 + lane * 16) = r;
+                if (d_vox[k] != -2) *reinterpret_cast<half8*>(lbase + tt * 1024 + lane * 16) = r;   // not the padding
             }
         }
     };
@@ -1368,7 +1371,12 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     char* wlds = lds + NSLOT * plane_bytes;
     for (int i = tid; i < (9 - RESW) * 6 * 64; i += 256)
         *reinterpret_cast<uint4*>(wlds + i * 16) = *reinterpret_cast<const uint4*>(a.wpk + RESW * 6 * 1024 + i * 16);
+    if (tid < NSLOT * 4)   // the zero position of every slot (never written again)
+        *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
+    if (af && tid >= 64 && tid < 128)   // (2, 32) coefficients of this batch item -> padding positions needed + 1 .. + 4 of slot 0
+        reinterpret_cast<float*>(lds + (needed + 1) * kPosBytes)[tid - 64] = af[(long long)b * 64 + (tid - 64)];
 
+    SK_T_DECL
     int issued = 0;
     auto issue_upto = [&](int lim) {   // planes [issued, min(nin, lim))
         const int hi = min(nin, lim);
@@ -1425,7 +1433,7 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
         const char* pa = lds + decltype(SA)::value * plane_bytes;
         const char* pb = lds + decltype(SB)::value * plane_bytes;
         half8 bq[2][2][2];   // [buffer][plane][j]: the B fragments of a tap row, one row ahead
-        half8 wq[2][3];      // [buffer][d]: the weight fragments of a half row, one half row ahead
+        half8 wq[2][3];      // [buffer][d]: the weight fragments of a half row (cout half i of a tap row), one half row ahead
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int ad = baddr(0, j);
@@ -1433,49 +1441,53 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
             bq[0][1][j] = *reinterpret_cast<const half8*>(pb + ad);
         }
         wfrag(0, 0, wq[0]);
+        // The 18 half rows of a step, 12 MFMAs each (192 cycles of the matrix pipe).  The LDS reads of half row h + 1 -- its
+        // three weight fragments when its tap row lives in LDS, and the four B fragments of the next tap row -- are issued
+        // in the FIRST MFMA gaps of half row h, in the order half row h + 1 consumes them, so the youngest read is 80+
+        // cycles old (and not needed before the seventh MFMA) when half row h + 1 starts.  The order is pinned: left to
+        // itself the scheduler spread the reads to the END of the half row and every half row began with an
+        // `s_waitcnt lgkmcnt(0)` on a read issued one MFMA earlier (SQ_WAIT_ANY 38 % of the wave-cycles).
 #pragma unroll
         for (int dydz = 0; dydz < 9; ++dydz) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int h = dydz * 2 + i;   // half-row index: its weights sit in wq[h & 1], its B fragments in bq[dydz & 1]
-                int nreads = 0;
-                if (i == 0) {
-                    wfrag(dydz, 1, wq[(h + 1) & 1]);
-                    nreads = dydz < RESW ? 0 : 3;
-                } else if (dydz < 8) {
-                    wfrag(dydz + 1, 0, wq[(h + 1) & 1]);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int ad = baddr(dydz + 1, j);
-                        bq[(dydz + 1) & 1][0][j] = *reinterpret_cast<const half8*>(pa + ad);
-                        bq[(dydz + 1) & 1][1][j] = *reinterpret_cast<const half8*>(pb + ad);
-                    }
-                    nreads = 4 + (dydz + 1 < RESW ? 0 : 3);
-                }
-                // the next half row's LDS reads one per MFMA gap at the head of this half row's 12 MFMAs (the builtin wants
-                // literal counts: the four cases of `nreads`, three of them dead after unrolling)
-#define SK_PX_PAIR(n) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-                if (nreads == 3) {
-                    SK_PX_PAIR(0) SK_PX_PAIR(1) SK_PX_PAIR(2)
-                    __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
-                } else if (nreads == 4) {
-                    SK_PX_PAIR(0) SK_PX_PAIR(1) SK_PX_PAIR(2) SK_PX_PAIR(3)
-                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-                } else if (nreads == 7) {
-                    SK_PX_PAIR(0) SK_PX_PAIR(1) SK_PX_PAIR(2) SK_PX_PAIR(3) SK_PX_PAIR(4) SK_PX_PAIR(5) SK_PX_PAIR(6)
-                    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
-                }
-#undef SK_PX_PAIR
+                const int h = dydz * 2 + i;   // its weights sit in wq[h & 1], its B fragments in bq[dydz & 1]
                 const half8(&W)[3] = wq[h & 1];
+                const int ndy = i == 0 ? dydz : dydz + 1, ni = i ^ 1;         // the next half row
+                const bool wread = ndy < 9 && ndy >= RESW;                     // ... reads its weights from LDS
+                const bool bread = i == 1 && dydz < 8;                         // ... starts a new tap row: B fragments
+                if (ndy < 9 && !wread) wfrag(ndy, ni, wq[(h + 1) & 1]);        // resident row: register names only
+                // read k of the next half row, in consumption order: W0, A0, B0, W1, W2, A1, B1
+                auto next_read = [&](int k) {
+                    const char* wp = wlds + ((ndy - RESW) * 6 + ni * 3) * 1024 + lane * 16;
+                    int kk = k;
+                    if (!wread) kk = (k == 0 ? 1 : k == 1 ? 2 : k == 2 ? 5 : 6);   // B fragments only: A0, B0, A1, B1
+                    if (!bread && kk > 0) kk = (kk == 1 ? 3 : 4);                  // weights only: W0, W1, W2
+                    switch (kk) {
+                        case 0: wq[(h + 1) & 1][0] = *reinterpret_cast<const half8*>(wp); break;
+                        case 1: bq[(dydz + 1) & 1][0][0] = *reinterpret_cast<const half8*>(pa + baddr(dydz + 1, 0)); break;
+                        case 2: bq[(dydz + 1) & 1][1][0] = *reinterpret_cast<const half8*>(pb + baddr(dydz + 1, 0)); break;
+                        case 3: wq[(h + 1) & 1][1] = *reinterpret_cast<const half8*>(wp + 1024); break;
+                        case 4: wq[(h + 1) & 1][2] = *reinterpret_cast<const half8*>(wp + 2048); break;
+                        case 5: bq[(dydz + 1) & 1][0][1] = *reinterpret_cast<const half8*>(pa + baddr(dydz + 1, 1)); break;
+                        default: bq[(dydz + 1) & 1][1][1] = *reinterpret_cast<const half8*>(pb + baddr(dydz + 1, 1)); break;
+                    }
+                };
+                const int nreads = (wread ? 3 : 0) + (bread ? 4 : 0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int m = 0; m < 12; ++m) {
+                    const int j = m / 6;
                     const half8 fa = bq[dydz & 1][0][j], fb = bq[dydz & 1][1][j];
-                    oB[i][j] = SK_MFMA_16x16x32_T16(W[0], fa, oB[i][j], 0, 0, 0);
-                    oB1[i][j] = SK_MFMA_16x16x32_T16(W[0], fb, oB1[i][j], 0, 0, 0);
-                    oA[i][j] = SK_MFMA_16x16x32_T16(W[1], fa, oA[i][j], 0, 0, 0);
-                    oA1[i][j] = SK_MFMA_16x16x32_T16(W[2], fa, oA1[i][j], 0, 0, 0);
-                    oB[i][j] = SK_MFMA_16x16x32_T16(W[1], fb, oB[i][j], 0, 0, 0);
-                    oA[i][j] = SK_MFMA_16x16x32_T16(W[2], fb, oA[i][j], 0, 0, 0);
+                    switch (m % 6) {   // tap d of a weight row multiplies x_in = x_out + d - 1
+                        case 0: oB[i][j] = SK_MFMA_16x16x32_T16(W[0], fa, oB[i][j], 0, 0, 0); break;
+                        case 1: oB1[i][j] = SK_MFMA_16x16x32_T16(W[0], fb, oB1[i][j], 0, 0, 0); break;
+                        case 2: oA[i][j] = SK_MFMA_16x16x32_T16(W[1], fa, oA[i][j], 0, 0, 0); break;
+                        case 3: oA1[i][j] = SK_MFMA_16x16x32_T16(W[2], fa, oA1[i][j], 0, 0, 0); break;
+                        case 4: oB[i][j] = SK_MFMA_16x16x32_T16(W[1], fb, oB[i][j], 0, 0, 0); break;
+                        default: oA[i][j] = SK_MFMA_16x16x32_T16(W[2], fb, oA[i][j], 0, 0, 0); break;
+                    }
+                    if (m < nreads) next_read(m);
+                    if (m <= nreads) __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1543,26 +1555,34 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     // end of a step: this wave's LDS-DMA of the step (issued before its MFMAs, older than its `ns` stores) has landed ->
     // activate what it staged -> barrier: every wave is done with the step's planes and sees the landed ones
     auto end_step = [&](int ns, int t_lo, int t_hi) {
+        SK_T(3)
         if (ns == 4)
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (ns == 2)
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SK_T(4)
         if (af) {
             for (int t = t_lo; t < t_hi; ++t) activate_plane(t);
         }
+        SK_T(5)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        SK_T(1)
     };
     typedef std::integral_constant<bool, true> T_;
     typedef std::integral_constant<bool, false> F_;
 
     // ---- the march -----------------------------------------------------------------------------------------------
     // P0 / P1: the two oldest live output planes (P0 = plane xa - 1 at first: never stored), Q0 / Q1 the next two
+    // (-DSK_TIMING marks: 0 MFMA | 1 closing barrier | 2 LDS-DMA issue | 3 epilogue | 4 landing wait | 5 in-LDS activation |
+    //  6 workgroup prologue | 7 the single-plane steps at the ends of the x-chunk)
     int t = 0;
+    SK_T(6)
     {   // plane xa - 1 reaches only output plane xa (tap d = 0)
         const int lo = issue_upto(t + NSLOT);
         if (xa > 0) single_step(T_{}, F_{}, F_{}, 0, P1, P1, P1);
+        SK_T(7)
         end_step(0, lo, issued);
         t = 1;
     }
@@ -1576,7 +1596,9 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     auto even_step = [&]() {
         const int lo = issue_upto(t + NSLOT);
         const int xA = xa - 1 + t;   // input plane A = the output plane of the second-oldest accumulator
+        SK_T(2)
         pair_step(S1_{}, S2_{}, P0, P1, Q0, Q1);
+        SK_T(0)
         int ns = 0;
         if (xA - 1 >= xa) ns += finish_plane(P0, xA - 1);
         ns += finish_plane(P1, xA);
@@ -1588,7 +1610,9 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     auto odd_step = [&]() {
         const int lo = issue_upto(t + NSLOT);
         const int xA = xa - 1 + t;
+        SK_T(2)
         pair_step(S3_{}, S0_{}, Q0, Q1, P0, P1);
+        SK_T(0)
         int ns = finish_plane(Q0, xA - 1);
         ns += finish_plane(Q1, xA);
         reset(Q0);
@@ -1613,6 +1637,7 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     if (n & 1) {   // plane xb - 1 alone: taps d = 2 -> P0 (xb - 2), d = 1 -> P1 (xb - 1)
         const int lo = issue_upto(t + NSLOT);
         single_step(F_{}, T_{}, T_{}, t & 3, P0, P1, P0);
+        SK_T(7)
         int ns = 0;
         if (xb - 2 >= xa) ns += finish_plane(P0, xb - 2);
 #pragma unroll
@@ -1624,7 +1649,10 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     }
     // plane xb reaches only output plane xb - 1 (tap d = 2)
     if (xb < a.Xt) single_step(F_{}, F_{}, T_{}, t & 3, P0, P0, P0);
+    SK_T(7)
     finish_plane(P0, xb - 1);
+    SK_T(3)
+    SK_T_DUMP(a, w, lane)
 
     // ---- block-level reduction of the GroupNorm partials (conv3_m16_kernel's) --------------------------------
     if (a.partial) {
@@ -1769,7 +1797,7 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
             const float gb[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};                     \
             _Pragma("unroll") for (int p = 0; p < PV; ++p) _Pragma("unroll") for (int j = 0; j < 8; ++j) {    \
                 float y = fmaf(ga[j], (float)bv[p][j], gb[j]);                                                \
-                bv[p][j] = (t16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));                         \
+                bv[p][j] = sk::round_t16(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));                         \
             }                                                                                                 \
         }                                                                                                     \
         _Pragma("unroll") for (int p = 0; p < PV; ++p) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {    \
@@ -1995,7 +2023,7 @@ __global__ void __launch_bounds__(256, 2) down2_act_kernel(DownArgs a) {
                 for (int e = 0; e < 8; ++e) {   // gn_silu_kernel's arithmetic, op for op
                     const float y = fmaf(ga[e], (float)v[e], gb[e]);
                     const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
-                    r[e] = (t16)(y * sg);
+                    r[e] = sk::round_t16(y * sg);
                 }
                 *lp = r;
                 if (a.writeback && vin[j] >= 0)
@@ -2167,7 +2195,8 @@ int launch_conv3_m16(const Conv3Args& a, const Plan& p, hipStream_t stream) {
 constexpr int kPxResidentRows = 3;
 constexpr int kPxPositions = 176;
 constexpr size_t kPxLds = (size_t)4 * kPxPositions * kPosBytes + (size_t)(9 - kPxResidentRows) * 6144;
-bool conv3_px_covers(const Plan& p, int Zt) { return p.mode == 0 && p.nposp == kPxPositions && kPatch + 2 * Zt + 2 < kPxPositions; }
+// padding positions behind the `needed` ones: 1 (the zero position) + 4 (GroupNorm coefficients of a raw source)
+bool conv3_px_covers(const Plan& p, int Zt, bool raw) { return p.mode == 0 && p.nposp == kPxPositions && kPatch + 2 * Zt + 2 + (raw ? 5 : 1) <= kPxPositions; }
 
 int launch_conv3_px(const Conv3Args& a, const Plan& p, hipStream_t stream) {
     auto kern = conv3_px_kernel<kPxResidentRows, kPxPositions>;
@@ -2394,7 +2423,7 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
             }
             a.has_box = 1;
         }
-        bool use_px = cout == 32 && a.nchunks == 1 && n_src == 1 && !srcs[0].upsample && conv3_px_covers(p, oz) && !a.ablate;
+        bool use_px = cout == 32 && a.nchunks == 1 && n_src == 1 && !srcs[0].upsample && conv3_px_covers(p, oz, a.act[0] != nullptr) && !a.ablate;
 #ifdef SK_TUNING
         if (getenv("SK_CONV_NO_PX")) use_px = false;   // A/B: the single-chunk COUT-32 layers on conv3_m16_kernel
 #endif

@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(256) gn_silu_kernel(t16* __restrict__ x,
         for (int j = 0; j < 8; ++j) {
             float y = fmaf(ga[j], (float)v[j], gb[j]);
             float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
-            r[j] = (t16)(y * sg);
+            r[j] = sk::round_t16(y * sg);
         }
         __builtin_nontemporal_store(r, &p[i]);
     }
@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(256) heads_kernel(HeadArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float y = fmaf(ga[ks][j], (float)raw[j], gb[ks][j]);
-                    raw[j] = (t16)(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));
+                    raw[j] = sk::round_t16(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));
                 }
             }
             bf[ks] = raw;

@@ -14,6 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 NAMES = ["mfma", "barrier1", "dma_issue", "epilogue", "landing_wait", "activation", "barrier2", "-"]
+# conv3_px_kernel (the single-chunk 32 -> 32 layers at the production tile) uses the same eight slots as:
+NAMES_PX = ["mfma", "closing_barrier", "dma_issue", "epilogue", "landing_wait", "activation", "workgroup_prologue", "end_plane_steps"]
 LAYERS = [("32->32 (enc0.1 / dec0.1)", (300, 300, 20), [(32, 0)], 32, False),
           ("32->32 + fused activation (dec0.1)", (300, 300, 20), [(32, 0)], 32, True),
           ("32+32up->32 (dec0.0)", (300, 300, 20), [(32, 0), (32, 1)], 32, False),
@@ -54,7 +56,8 @@ def main():
         used = d.sum(dim=(1, 2)) > 0
         m = d[used].mean(dim=(0, 1))
         tot = m.sum().item()
-        out[name] = {"cycles_per_wave": round(tot), **{n: round(v / tot, 4) for n, v in zip(NAMES[:7], m.tolist())}}
+        names = NAMES_PX if (cout == 32 and len(srcdef) == 1 and ext[2] == 20) else NAMES[:7]
+        out[name] = {"cycles_per_wave": round(tot), **{n: round(v / tot, 4) for n, v in zip(names, m.tolist())}}
         print(name, json.dumps(out[name]), flush=True)
     _ffi.check(_ffi.lib.sk_debug_set_timing_buffer(None, 0))   # detach before `dbg` can be freed
     print(json.dumps(out))
