@@ -79,6 +79,7 @@ struct Conv3Args {
     // fused form of GroupNorm + SiLU (no separate pass over the tensor; same arithmetic as gn_silu_kernel, bit-identical)
     const float* act[2];
     long long* dbg;     // -DSK_TIMING builds: per-wave phase cycle sums
+    int dbg_off;        // ... of the workgroups blockIdx.x in [dbg_off, dbg_off + 4096) (SK_CONV_DBG_OFF)
     int alt;            // multi-chunk layers: visit the chunks in alternating order (see `reuse` in the kernels)
     int has_box, box_lo[3], box_hi[3];   // sk_conv3d_box: only the output voxels inside [lo, hi) are STORED (conv3_px_kernel)
     int ablate;         // timing experiments only (-DSK_TUNING builds, SK_CONV_ABLATE): 1 skip DMA, 2 reuse first weights, 4 skip stores
@@ -95,8 +96,8 @@ struct Conv3Args {
 #ifdef SK_TIMING
 #define SK_T_DECL long long tacc_[sk::kTimingSlots] = {0}; long long tprev_ = __builtin_readcyclecounter();
 #define SK_T(i) { const long long t_ = __builtin_readcyclecounter(); tacc_[i] += t_ - tprev_; tprev_ = t_; }
-#define SK_T_DUMP(a, w, lane) if ((a).dbg && blockIdx.x < sk::kTimingBlocks && (w) < 4 && (lane) == 0) { \
-        for (int i_ = 0; i_ < sk::kTimingSlots; ++i_) (a).dbg[((long long)blockIdx.x * 4 + (w)) * sk::kTimingSlots + i_] = tacc_[i_]; }
+#define SK_T_DUMP(a, w, lane) if ((a).dbg && (int)blockIdx.x >= (a).dbg_off && (int)blockIdx.x < (a).dbg_off + sk::kTimingBlocks && (w) < 4 && (lane) == 0) { \
+        for (int i_ = 0; i_ < sk::kTimingSlots; ++i_) (a).dbg[((long long)((int)blockIdx.x - (a).dbg_off) * 4 + (w)) * sk::kTimingSlots + i_] = tacc_[i_]; }
 #else
 #define SK_T_DECL
 #define SK_T(i)
@@ -861,7 +862,8 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                     for (int e = 0; e < 8; ++e) {   // gn_silu_kernel's arithmetic, op for op
                         const float y = fmaf(ga[e], (float)v[k][e], gb[e]);
                         const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
-                        r[e] = real ? sk::round_t16(y * sg) : v[k][e];
+                        const t16 act = sk::round_t16(y * sg);   // unconditional: the asm inside must not sit behind a per-element branch
+                        r[e] = real ? act : v[k][e];
                     }
                     *reinterpret_cast<half8*>(lbase + t * 1024 + lane * 16) = r;
                 }
@@ -1352,7 +1354,8 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
                 for (int e = 0; e < 8; ++e) {   // gn_silu_kernel's arithmetic, op for op
                     const float y = fmaf(ga[e], (float)v[k][e], gb[e]);
                     const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
-                    r[e] = real ? sk::round_t16(y * sg) : v[k][e];
+                    const t16 act = sk::round_t16(y * sg);   // unconditional: the asm inside must not sit behind a per-element branch
+                    r[e] = real ? act : v[k][e];
                 }
                 if (d_vox[k] != -2) *reinterpret_cast<half8*>(lbase + tt * 1024 + lane * 16) = r;   // not the padding
             }
@@ -2404,6 +2407,7 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
         a.dbg = nullptr;
 #ifdef SK_TIMING
         a.dbg = sk::timing_buffer();
+        if (const char* e = getenv("SK_CONV_DBG_OFF")) a.dbg_off = atoi(e);
 #endif
         a.ablate = 0;
 #ifdef SK_TUNING

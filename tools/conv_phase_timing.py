@@ -27,7 +27,7 @@ LAYERS = [("32->32 (enc0.1 / dec0.1)", (300, 300, 20), [(32, 0)], 32, False),
 def main():
     from skoots_amd import _ffi, unet
     dev = torch.device("cuda", 0)
-    B = 8
+    B = int(os.environ.get("BATCH", "8"))
     dbg = torch.zeros((4096, 4, 16), dtype=torch.int64, device=dev)   # [workgroup][wave][slot]: the library's one record layout
     _ffi.check(_ffi.lib.sk_debug_set_timing_buffer(_ffi.ptr(dbg), dbg.numel() * 8))
     zeros = torch.zeros(4096, dtype=torch.uint8, device=dev)
