@@ -1391,6 +1391,7 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     issue_upto(NSLOT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (af) {
+        __syncthreads();   // the coefficients in LDS were written by other waves
         for (int t = 0; t < issued; ++t) activate_plane(t);
     }
     __syncthreads();
