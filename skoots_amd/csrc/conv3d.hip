@@ -1219,7 +1219,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
 //   * what a step reads from the ring is only its own two planes: the ring holds 4 plane slots (2 being read, 2 landing)
 //     instead of 6, and the LDS-DMA of the planes of step s+1 is issued at the START of step s -- a whole step of MFMAs
 //     (~3.5 k cycles) to land in, nothing serial about it;
-//   * the LDS the ring gives back holds the weights: RESW tap rows in registers, the other 9 - RESW rows in LDS (one copy
+//   * the LDS the ring gives back holds the weights: the first half tap rows in registers, the others in LDS (one copy
 //     per workgroup, loaded once per x-chunk) -- NO weight fragment is loaded in the loop: a wave issues 5-6 LDS-DMA
 //     pieces + 4 stores per 216 MFMAs where conv3_m16_kernel issues 43 vector-memory instructions per 432;
 //   * B fragments: one ds_read_b128 feeds the three x-taps of both cout halves (6 MFMAs), 0.17 reads per MFMA against
@@ -1229,7 +1229,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
 // bit-exact on integer operands).
 // Store box (Conv3Args.box, sk_conv3d_box): only the voxels inside it are stored -- the statistics still cover the
 // whole tile.  The last block's conv (dec0.1) is read by the heads on 28 % of the tile (the scatter's box).
-template <int RESW, int NPOSP>
+template <int RESH, int NPOSP>
 __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     constexpr int NSLOT = 4;
     constexpr int plane_bytes = NPOSP * kPosBytes;   // compile-time: a slot's offset is an immediate of its ds_read_b128
@@ -1362,20 +1362,22 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
         }
     };
 
-    // ---- weights: rows 0 .. RESW-1 in registers, rows RESW .. 8 in LDS behind the ring -------------------
+    // ---- weights: half rows (tap row dydz, cout half i) 0 .. RESH-1 in registers, RESH .. 17 in LDS behind the ring ----
     // fragment of (row dydz, cout half i, x tap d): ((dydz * 2 + i) * 3 + d) KiB into the packed weight
     const __amdgpu_buffer_rsrc_t wrsrc = sk::make_rsrc(a.wpk, 54u * 1024u);
-    half8 wres[2 * RESW][3];
+    half8 wres[RESH][3];
 #pragma unroll
-    for (int r = 0; r < 2 * RESW; ++r)
+    for (int r = 0; r < RESH; ++r)
 #pragma unroll
         for (int d = 0; d < 3; ++d)
             wres[r][d] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, (r * 3 + d) * 1024, 0));
     char* wlds = lds + NSLOT * plane_bytes;
-    for (int i = tid; i < (9 - RESW) * 6 * 64; i += 256)
-        *reinterpret_cast<uint4*>(wlds + i * 16) = *reinterpret_cast<const uint4*>(a.wpk + RESW * 6 * 1024 + i * 16);
+    for (int i = tid; i < (18 - RESH) * 3 * 64; i += 256)
+        *reinterpret_cast<uint4*>(wlds + i * 16) = *reinterpret_cast<const uint4*>(a.wpk + RESH * 3 * 1024 + i * 16);
     if (tid < NSLOT * 4)   // the zero position of every slot (never written again)
         *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
+    if (tid >= 128 && tid < 160)   // the bias -> padding positions needed + 1, + 2 of slot 1
+        reinterpret_cast<float*>(lds + plane_bytes + (needed + 1) * kPosBytes)[tid - 128] = a.bias[tid - 128];
     if (af && tid >= 64 && tid < 128)   // (2, 32) coefficients of this batch item -> padding positions needed + 1 .. + 4 of slot 0
         reinterpret_cast<float*>(lds + (needed + 1) * kPosBytes)[tid - 64] = af[(long long)b * 64 + (tid - 64)];
 
@@ -1399,12 +1401,14 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     // ---- accumulators ----------------------------------------------------------------------------------------
     // element r of [i][j]: cout 16 i + 4 g + r, voxel 16 j + c16 of the wave's column tile
     f32x4 P0[2][2], P1[2][2], Q0[2][2], Q1[2][2];
-    const f32x4 bias0 = *reinterpret_cast<const f32x4*>(a.bias + 4 * g), bias1 = *reinterpret_cast<const f32x4*>(a.bias + 4 * g + 16);
+    // the bias (the accumulators' initial value) is re-read from its copy in LDS -- padding positions of slot 1 -- at every
+    // reset: eight registers less in the loop
+    const float* lbias = reinterpret_cast<const float*>(lds + plane_bytes + (needed + 1) * kPosBytes) + 4 * g;
     auto reset = [&](f32x4 (&o)[2][2]) {
-        o[0][0] = o[0][1] = bias0;
-        o[1][0] = o[1][1] = bias1;
+        o[0][0] = o[0][1] = *reinterpret_cast<const f32x4*>(lbias);
+        o[1][0] = o[1][1] = *reinterpret_cast<const f32x4*>(lbias + 16);
     };
-    reset(P0);
+    reset(P0);   // (behind the barrier above: the bias in LDS was written by another wave)
     reset(P1);
     reset(Q0);
     reset(Q1);
@@ -1419,11 +1423,11 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
         return addr;
     };
     auto wfrag = [&](int dydz, int i, half8 (&dst)[3]) {
-        if (dydz < RESW) {
+        if (2 * dydz + i < RESH) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) dst[d] = wres[2 * dydz + i][d];
         } else {
-            const char* p = wlds + ((dydz - RESW) * 6 + i * 3) * 1024 + lane * 16;
+            const char* p = wlds + (2 * dydz + i - RESH) * 3 * 1024 + lane * 16;
 #pragma unroll
             for (int d = 0; d < 3; ++d) dst[d] = *reinterpret_cast<const half8*>(p + d * 1024);
         }
@@ -1458,12 +1462,12 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
                 const int h = dydz * 2 + i;   // its weights sit in wq[h & 1], its B fragments in bq[dydz & 1]
                 const half8(&W)[3] = wq[h & 1];
                 const int ndy = i == 0 ? dydz : dydz + 1, ni = i ^ 1;         // the next half row
-                const bool wread = ndy < 9 && ndy >= RESW;                     // ... reads its weights from LDS
+                const bool wread = ndy < 9 && 2 * ndy + ni >= RESH;            // ... reads its weights from LDS
                 const bool bread = i == 1 && dydz < 8;                         // ... starts a new tap row: B fragments
                 if (ndy < 9 && !wread) wfrag(ndy, ni, wq[(h + 1) & 1]);        // resident row: register names only
                 // read k of the next half row, in consumption order: W0, A0, B0, W1, W2, A1, B1
                 auto next_read = [&](int k) {
-                    const char* wp = wlds + ((ndy - RESW) * 6 + ni * 3) * 1024 + lane * 16;
+                    const char* wp = wlds + (2 * ndy + ni - RESH) * 3 * 1024 + lane * 16;
                     int kk = k;
                     if (!wread) kk = (k == 0 ? 1 : k == 1 ? 2 : k == 2 ? 5 : 6);   // B fragments only: A0, B0, A1, B1
                     if (!bread && kk > 0) kk = (kk == 1 ? 3 : 4);                  // weights only: W0, W1, W2
@@ -2194,16 +2198,21 @@ int launch_conv3_m16(const Conv3Args& a, const Plan& p, hipStream_t stream) {
 }
 
 // conv3_px_kernel is built for the plane geometry of the production tile: linear mode with 176 positions per plane
-// (Zt 16 .. 22: 128 + 2 Zt + 2 positions, at least one padding position left for the taps' zero position).  RESW tap rows
-// in registers, the other rows in LDS: 4 plane slots (44 KiB) + 6 rows (36 KiB) = 80 KiB, two workgroups per CU.
-constexpr int kPxResidentRows = 3;
+// (Zt 16 .. 22: 128 + 2 Zt + 2 positions, at least one padding position left for the taps' zero position).  The first
+// kPxResidentHalfRows half tap rows (3 fragments each) in registers, the other 18 - that in LDS: 4 plane slots (44 KiB) +
+// 12 half rows (36 KiB) = 80 KiB, two workgroups per CU.  (7 resident half rows, 77 KiB: 18 spilled registers, two scratch
+// reloads per step: enc0.1 5.15 -> 5.92 ms per 64 tiles.)
+#ifndef SK_PX_RESH
+#define SK_PX_RESH 6
+#endif
+constexpr int kPxResidentHalfRows = SK_PX_RESH;   // (tools/ A/B: -DSK_PX_RESH=6 is the 80 KiB form)
 constexpr int kPxPositions = 176;
-constexpr size_t kPxLds = (size_t)4 * kPxPositions * kPosBytes + (size_t)(9 - kPxResidentRows) * 6144;
-// padding positions behind the `needed` ones: 1 (the zero position) + 4 (GroupNorm coefficients of a raw source)
-bool conv3_px_covers(const Plan& p, int Zt, bool raw) { return p.mode == 0 && p.nposp == kPxPositions && kPatch + 2 * Zt + 2 + (raw ? 5 : 1) <= kPxPositions; }
+constexpr size_t kPxLds = (size_t)4 * kPxPositions * kPosBytes + (size_t)(18 - kPxResidentHalfRows) * 3072;
+// padding positions behind the `needed` ones: 1 (the zero position) + 2 (the bias) or + 4 (GroupNorm coefficients of a raw source)
+bool conv3_px_covers(const Plan& p, int Zt, bool raw) { return p.mode == 0 && p.nposp == kPxPositions && kPatch + 2 * Zt + 2 + (raw ? 5 : 3) <= kPxPositions; }
 
 int launch_conv3_px(const Conv3Args& a, const Plan& p, hipStream_t stream) {
-    auto kern = conv3_px_kernel<kPxResidentRows, kPxPositions>;
+    auto kern = conv3_px_kernel<kPxResidentHalfRows, kPxPositions>;
     const size_t lds = kPxLds;
     static_assert(kPxLds <= 80 * 1024, "two workgroups per CU");
     SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
