@@ -126,31 +126,13 @@ __device__ __forceinline__ void unpack_vec4(uint2 raw, float& a, float& b, float
     c = __low2float(hi);
 }
 
+// One voxel: owner crop (ox, oy, oz), own vector (v0, v1, v2) already loaded.  fp32 arithmetic op for op as the reference
+// (vector_to_embedding.py:79-132, eval.py:274-276, skeleton.py:678-693).
 template <typename L>
-__global__ void __launch_bounds__(256)
-follow_assign_kernel(const uint2* __restrict__ vec4, const L* __restrict__ labels,
-                     int32_t* __restrict__ out, AssignGeom g, const int32_t* __restrict__ own_x,
-                     const int32_t* __restrict__ own_y, const int32_t* __restrict__ own_z,
-                     FollowParams p) {
-    const int zspan = g.z_hi - g.z_lo;
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long total = (long long)g.X * g.Y * zspan;
-    if (t >= total) return;
-    int z = g.z_lo + (int)(t % zspan);
-    long long xy = t / zspan;
-    int y = (int)(xy % g.Y);
-    int x = (int)(xy / g.Y);
+__device__ __forceinline__ int32_t follow_one(const uint2* __restrict__ vec4, const L* __restrict__ labels, const AssignGeom& g,
+                                              const FollowParams& p, int x, int y, int z, int ox, int oy, int oz, float v0, float v1,
+                                              float v2) {
     const int Zl = g.win_hi - g.win_lo;
-    long long self = ((long long)x * g.Y + y) * Zl + (z - g.win_lo);
-
-    int ox = own_x[x], oy = own_y[y], oz = own_z[z];
-    const long long oidx = ((long long)x * g.Y + y) * zspan + (z - g.z_lo);  // out is (X, Y, z_hi-z_lo)
-    if ((ox | oy | oz) < 0) {  // no crop interior covers this voxel (eval.py:245 zeros)
-        out[oidx] = 0;
-        return;
-    }
-    float v0, v1, v2;
-    unpack_vec4(vec4[self], v0, v1, v2);
     float mx = __fadd_rn((float)(x - ox), __fmul_rn(v0, p.sc[0][0]));
     float my = __fadd_rn((float)(y - oy), __fmul_rn(v1, p.sc[0][1]));
     float mz = __fadd_rn((float)(z - oz), __fmul_rn(v2, p.sc[0][2]));
@@ -178,7 +160,98 @@ follow_assign_kernel(const uint2* __restrict__ vec4, const L* __restrict__ label
     int xi = (int)clampf(rintf(ex), 0.0f, (float)(g.X - 1));
     int yi = (int)clampf(rintf(ey), 0.0f, (float)(g.Y - 1));
     int zi = (int)clampf(rintf(ez), 0.0f, (float)(g.Z - 1));
-    out[oidx] = (int32_t)labels[((long long)xi * g.Y + yi) * g.Z + zi];
+    return (int32_t)labels[((long long)xi * g.Y + yi) * g.Z + zi];
+}
+
+template <typename L>
+__global__ void __launch_bounds__(256)
+follow_assign_kernel(const uint2* __restrict__ vec4, const L* __restrict__ labels,
+                     int32_t* __restrict__ out, AssignGeom g, const int32_t* __restrict__ own_x,
+                     const int32_t* __restrict__ own_y, const int32_t* __restrict__ own_z,
+                     FollowParams p) {
+    const int zspan = g.z_hi - g.z_lo;
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)g.X * g.Y * zspan;
+    if (t >= total) return;
+    int z = g.z_lo + (int)(t % zspan);
+    long long xy = t / zspan;
+    int y = (int)(xy % g.Y);
+    int x = (int)(xy / g.Y);
+    const int Zl = g.win_hi - g.win_lo;
+    long long self = ((long long)x * g.Y + y) * Zl + (z - g.win_lo);
+
+    int ox = own_x[x], oy = own_y[y], oz = own_z[z];
+    const long long oidx = ((long long)x * g.Y + y) * zspan + (z - g.z_lo);  // out is (X, Y, z_hi-z_lo)
+    if ((ox | oy | oz) < 0) {  // no crop interior covers this voxel (eval.py:245 zeros)
+        out[oidx] = 0;
+        return;
+    }
+    float v0, v1, v2;
+    unpack_vec4(vec4[self], v0, v1, v2);
+    out[oidx] = follow_one<L>(vec4, labels, g, p, x, y, z, ox, oy, oz, v0, v1, v2);
+}
+
+// The same, two z-neighbours per thread (round 3).  Most voxels of a real volume are background: their vector is zero,
+// the follow stops at its first hop and the answer is the label at the voxel's own position.  For them the kernel is a
+// stream -- one 16-byte load of two vectors, one 8-byte label load, one 8-byte store per thread, 32-bit index arithmetic
+// (the one-voxel kernel spends its time in 64-bit divisions and 8-byte accesses: 1.3 TB/s of real traffic,
+// profiles/r03_stage23_hbm_traffic_pmc.json) -- and only voxels with a vector take the dependent hops.  Needs even
+// zspan / window / z offsets and int32 labels; blockIdx.y = x.
+__global__ void __launch_bounds__(256)
+follow_assign2_kernel(const uint4* __restrict__ vec4x2, const int32_t* __restrict__ labels, int32_t* __restrict__ out, AssignGeom g,
+                      const int32_t* __restrict__ own_x, const int32_t* __restrict__ own_y, const int32_t* __restrict__ own_z,
+                      FollowParams p, const bool tiled) {
+    const int zspan = g.z_hi - g.z_lo, zh = zspan >> 1;
+    const int x = blockIdx.y;
+    int y, zp;
+    if (tiled) {
+        // a wave = 8 rows x 16 z voxels (8 lanes = one 128-byte line of vectors): objects are compact, so far fewer
+        // waves contain a voxel that takes the dependent hops than with 128 consecutive z voxels of one row per wave
+        // (the lattice blob field of bench.py: 82 % of the row-segment waves against about a quarter of these)
+        const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6), zq = zh >> 3;
+        const int ty = wv / zq;
+        y = ty * 8 + (lane >> 3);
+        zp = (wv - ty * zq) * 8 + (lane & 7);
+        if (y >= g.Y) return;
+    } else {
+        const int t = blockIdx.x * 256 + threadIdx.x;   // pair index inside the x-plane
+        if (t >= g.Y * zh) return;
+        y = t / zh;
+        zp = t - y * zh;
+    }
+    const int z = g.z_lo + 2 * zp;
+    const int Zl = g.win_hi - g.win_lo;
+    const long long row = (long long)x * g.Y + y;
+    const long long self = row * Zl + (z - g.win_lo);                 // even
+    const long long oidx = row * zspan + (z - g.z_lo);                // even
+    const int ox = own_x[x], oy = own_y[y];
+    const int oz0 = own_z[z], oz1 = own_z[z + 1];
+    const uint4 raw = vec4x2[self >> 1];
+    const uint2 r0 = make_uint2(raw.x, raw.y), r1 = make_uint2(raw.z, raw.w);
+    // the label at the voxel's own position: the answer for a zero vector (embedding = position, skeleton.py:678-693)
+    const int2 own = *reinterpret_cast<const int2*>(labels + (row * g.Z + z));
+    int2 res;
+    {
+        float v0, v1, v2;
+        unpack_vec4(r0, v0, v1, v2);
+        if ((ox | oy | oz0) < 0)
+            res.x = 0;
+        else if (v0 == 0.0f && v1 == 0.0f && v2 == 0.0f)
+            res.x = own.x;
+        else
+            res.x = follow_one<int32_t>(reinterpret_cast<const uint2*>(vec4x2), labels, g, p, x, y, z, ox, oy, oz0, v0, v1, v2);
+    }
+    {
+        float v0, v1, v2;
+        unpack_vec4(r1, v0, v1, v2);
+        if ((ox | oy | oz1) < 0)
+            res.y = 0;
+        else if (v0 == 0.0f && v1 == 0.0f && v2 == 0.0f)
+            res.y = own.y;
+        else
+            res.y = follow_one<int32_t>(reinterpret_cast<const uint2*>(vec4x2), labels, g, p, x, y, z + 1, ox, oy, oz1, v0, v1, v2);
+    }
+    *reinterpret_cast<int2*>(out + oidx) = res;
 }
 
 // ---------------------------------------------------------------- layout kernels
@@ -305,6 +378,17 @@ int sk_follow_assign(const void* vec4, const void* labels, int label_dtype, int3
     AssignGeom g{X, Y, Z, win_lo, win_hi, z_lo, z_hi};
     long long total = (long long)X * Y * (z_hi - z_lo);
     SK_CHECK_ARG(total / 256 < 0x7fffffffLL, "sk_follow_assign: volume too large for one launch");
+    const int zspan = z_hi - z_lo;
+    if (label_dtype == SK_I32 && zspan % 2 == 0 && (win_hi - win_lo) % 2 == 0 && (z_lo - win_lo) % 2 == 0 && Z % 2 == 0 &&
+        z_lo % 2 == 0 && X <= 65535 && ((uintptr_t)vec4 & 15) == 0 && ((uintptr_t)labels & 7) == 0 && ((uintptr_t)out & 7) == 0) {
+        const bool tiled = zspan % 16 == 0;
+        const long long waves = tiled ? (long long)((Y + 7) / 8) * (zspan / 16) : ((long long)Y * (zspan / 2) + 63) / 64;
+        dim3 grid2(sk::cdiv(waves, 4), (unsigned)X);
+        follow_assign2_kernel<<<grid2, 256, 0, (hipStream_t)stream>>>((const uint4*)vec4, (const int32_t*)labels, out, g, owner_x,
+                                                                      owner_y, owner_z, p, tiled);
+        SK_CHECK_LAUNCH();
+        return SK_OK;
+    }
     unsigned grid = sk::cdiv(total, 256);
     if (label_dtype == SK_I16)
         follow_assign_kernel<int16_t><<<grid, 256, 0, (hipStream_t)stream>>>(

@@ -131,6 +131,44 @@ def test_flood_vs_oracle_random(sk, shape, fill):
     assert len(np.unique(pairs[0])) == pairs.shape[1] == len(np.unique(pairs[1]))
 
 
+@pytest.mark.parametrize("shape,fill", [((24, 20, 64), 0.02), ((24, 20, 64), 0.35), ((40, 33, 128), 0.10), ((3, 5, 16), 0.6)])
+def test_ccl_mask_driven_path_equals_generic_path_and_scipy(shape, fill):
+    """sk_ccl_crop has two implementations: the mask-driven one (16 voxels per thread, parent array touched at
+    foreground voxels only; crops whose rows are 16-byte aligned) and the one-thread-per-voxel one.  The same mask through
+    both -- the second time embedded at z0 = 8 in a wider volume, which un-aligns its rows -- must give the same labels,
+    and those are scipy.ndimage.label's numbering (components by first voxel in C order, flood_fill.py:135) + the id
+    offset of flood_all (:45-47, first id 3)."""
+    import scipy.ndimage
+    from skoots_amd import _ffi
+    X, Y, Z = shape
+    gen = torch.Generator().manual_seed(Z + X)
+    m = (torch.rand(shape, generator=gen) < fill).to(torch.uint8)
+    if Z > 16:   # runs across a 16-voxel chunk boundary
+        m[:, :, 15:17] |= (torch.rand((X, Y, 2), generator=gen) < 0.5).to(torch.uint8)
+    want, k = scipy.ndimage.label(m.numpy())
+    want = np.where(want > 0, want + 2, 0).astype(np.int32)
+    dev = torch.device(DEV)
+    st = _ffi.stream_ptr(dev)
+
+    def run(vol, z0, d):
+        Xv, Yv, Zv = vol.shape
+        labels = torch.full((Xv, Yv, Zv), -7, dtype=torch.int32, device=dev)
+        ws_bytes = _ffi.lib.sk_ccl_workspace_bytes(Xv * Yv * d)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        state = torch.tensor([1, 0, 0, 0], dtype=torch.int32, device=dev)
+        _ffi.check(_ffi.lib.sk_ccl_crop(_ffi.ptr(vol), _ffi.ptr(labels), Xv, Yv, Zv, 0, 0, z0, Xv, Yv, d, _ffi.ptr(ws), ws_bytes,
+                                        _ffi.ptr(state), st))
+        torch.cuda.synchronize()
+        return labels[:, :, z0:z0 + d].cpu().numpy(), state.cpu().tolist()
+
+    fast, st_fast = run(m.to(dev).contiguous(), 0, Z)
+    wide = torch.zeros((X, Y, Z + 16), dtype=torch.uint8)
+    wide[:, :, 8:8 + Z] = m
+    slow, st_slow = run(wide.to(dev).contiguous(), 8, Z)
+    assert np.array_equal(fast, want) and np.array_equal(slow, want)
+    assert st_fast == st_slow and st_fast[1] == k
+
+
 # ----------------------------------------------------------------------------- whole post-model path
 def _inject_from(out_vol_dev):
     def inject(_, origin, eff):
