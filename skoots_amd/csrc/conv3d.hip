@@ -1295,7 +1295,7 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
         const int Pq = q + off;
         const int y = ybase + (Pq >= 0 ? Pq / pitch : -1), z = zbase + (Pq >= 0 ? Pq % pitch : 0);
         // positions >= needed are padding that the LDS-DMA never writes (d_vox -2: the lane sits out of the instruction):
-        // the first of them is every tap's zero position, the next four hold the GroupNorm coefficients of a raw source
+        // two of them hold the bias / the GroupNorm coefficients of a raw source, the last four are the zero window
         const bool ok = (t < ndma) && y >= 0 && y < a.Yt && z >= 0 && z < a.Zt;
         d_vox[k] = q >= needed ? -2 : (ok ? y * a.Zt + z : -1);
     }
@@ -1304,7 +1304,14 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     const int xb = min(xa + a.XC, a.Xt);
     const int n = xb - xa;                 // output planes xa .. xb-1 of this workgroup
     const int nin = n + 2;                 // input planes t = 0 .. nin-1 <-> x = xa - 1 + t; plane t lives in slot t & 3
-    const int zero_addr = needed * kPosBytes;   // first padding position of a plane: the LDS-DMA rewrites it with zeros every time
+    // The last four positions of every slot are a 256-byte window of zeros (never written by the LDS-DMA).  A tap that
+    // leaves the tile through a z face reads zeros at `zero_addr + (its own address & 255)`: the SAME banks its data
+    // read would have used.  With one shared zero line instead, the four lanes of a z-face voxel (one per K group, one
+    // in each ds_read_b128 lane group) each collide with another lane's banks: 8 LDS cycles instead of 4 for the reads
+    // of six of the nine tap rows, SQ_LDS_BANK_CONFLICT 18-35 % of the LDS-active cycles in every conv3 kernel
+    // (simulated on the documented lane groups: 6.13 cycles per B read on average against 4.00).
+    constexpr int zero_addr = (NPOSP - 4) * kPosBytes;
+    static_assert(zero_addr % 256 == 0, "the zero window must cover the 64 banks once");
     constexpr int kOvs = 64;               // bytes per output voxel (32 channels)
     const long long out_plane = (long long)a.Yt * a.Zt * kOvs;
     char* outb = a.out + (long long)b * a.Xt * out_plane;
@@ -1332,12 +1339,13 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
         if (x < 0 || x >= a.Xt) return;
         // the coefficients of this lane's 8 channels, from the copy in LDS (a global load here cost the wave a memory
         // latency and a vmcnt(0) per plane; keeping them in registers costs 16 of the 256)
-        const float* cf = reinterpret_cast<const float*>(lds + (needed + 1) * kPosBytes) + (d_cs / 16) * 8;
+        const float* cfa = reinterpret_cast<const float*>(lds + needed * kPosBytes) + (d_cs / 16) * 8;
+        const float* cfb = reinterpret_cast<const float*>(lds + 2 * plane_bytes + needed * kPosBytes) + (d_cs / 16) * 8;
         float ga[8], gb[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            ga[j] = cf[j];
-            gb[j] = cf[32 + j];
+            ga[j] = cfa[j];
+            gb[j] = cfb[j];
         }
         char* lbase = lds + (t & (NSLOT - 1)) * plane_bytes;
         half8 v[kMaxDma];
@@ -1374,12 +1382,15 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     char* wlds = lds + NSLOT * plane_bytes;
     for (int i = tid; i < (18 - RESH) * 3 * 64; i += 256)
         *reinterpret_cast<uint4*>(wlds + i * 16) = *reinterpret_cast<const uint4*>(a.wpk + RESH * 3 * 1024 + i * 16);
-    if (tid < NSLOT * 4)   // the zero position of every slot (never written again)
-        *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
-    if (tid >= 128 && tid < 160)   // the bias -> padding positions needed + 1, + 2 of slot 1
-        reinterpret_cast<float*>(lds + plane_bytes + (needed + 1) * kPosBytes)[tid - 128] = a.bias[tid - 128];
-    if (af && tid >= 64 && tid < 128)   // (2, 32) coefficients of this batch item -> padding positions needed + 1 .. + 4 of slot 0
-        reinterpret_cast<float*>(lds + (needed + 1) * kPosBytes)[tid - 64] = af[(long long)b * 64 + (tid - 64)];
+    // padding positions of a slot: needed, needed + 1 (128 bytes: slot 0 the GroupNorm scales of a raw source, slot 1 the
+    // bias, slot 2 the GroupNorm shifts) | the zero window NPOSP - 4 .. NPOSP - 1
+    if (tid < NSLOT * 16)
+        *reinterpret_cast<uint4*>(lds + (tid >> 4) * plane_bytes + zero_addr + (tid & 15) * 16) = make_uint4(0, 0, 0, 0);
+    if (tid >= 128 && tid < 160) reinterpret_cast<float*>(lds + plane_bytes + needed * kPosBytes)[tid - 128] = a.bias[tid - 128];
+    if (af && tid >= 64 && tid < 128) {   // (2, 32) coefficients of this batch item
+        const int c = tid - 64;
+        reinterpret_cast<float*>(lds + (c < 32 ? 0 : 2 * plane_bytes) + needed * kPosBytes)[c & 31] = af[(long long)b * 64 + c];
+    }
 
     SK_T_DECL
     int issued = 0;
@@ -1403,7 +1414,7 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     f32x4 P0[2][2], P1[2][2], Q0[2][2], Q1[2][2];
     // the bias (the accumulators' initial value) is re-read from its copy in LDS -- padding positions of slot 1 -- at every
     // reset: eight registers less in the loop
-    const float* lbias = reinterpret_cast<const float*>(lds + plane_bytes + (needed + 1) * kPosBytes) + 4 * g;
+    const float* lbias = reinterpret_cast<const float*>(lds + plane_bytes + needed * kPosBytes) + 4 * g;
     auto reset = [&](f32x4 (&o)[2][2]) {
         o[0][0] = o[0][1] = *reinterpret_cast<const f32x4*>(lbias);
         o[1][0] = o[1][1] = *reinterpret_cast<const f32x4*>(lbias + 16);
@@ -1418,8 +1429,8 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
         const int dz = dydz % 3 - 1;
         const int q = q_row + (dydz / 3 - 1) * pitch + dz;
         int addr = (q * 4 + (g ^ (((q >> 2) & 1) << 1))) * 16 + 1024 * j;
-        if (dz < 0) addr = zlo(j) ? zero_addr : addr;
-        if (dz > 0) addr = zhi(j) ? zero_addr : addr;
+        if (dz < 0) addr = zlo(j) ? zero_addr + (addr & 255) : addr;
+        if (dz > 0) addr = zhi(j) ? zero_addr + (addr & 255) : addr;
         return addr;
     };
     auto wfrag = [&](int dydz, int i, half8 (&dst)[3]) {
@@ -2208,8 +2219,8 @@ int launch_conv3_m16(const Conv3Args& a, const Plan& p, hipStream_t stream) {
 constexpr int kPxResidentHalfRows = SK_PX_RESH;   // (tools/ A/B: -DSK_PX_RESH=6 is the 80 KiB form)
 constexpr int kPxPositions = 176;
 constexpr size_t kPxLds = (size_t)4 * kPxPositions * kPosBytes + (size_t)(18 - kPxResidentHalfRows) * 3072;
-// padding positions behind the `needed` ones: 1 (the zero position) + 2 (the bias) or + 4 (GroupNorm coefficients of a raw source)
-bool conv3_px_covers(const Plan& p, int Zt, bool raw) { return p.mode == 0 && p.nposp == kPxPositions && kPatch + 2 * Zt + 2 + (raw ? 5 : 3) <= kPxPositions; }
+// padding positions behind the `needed` ones: 2 (bias / GroupNorm coefficients) + the 4-position zero window
+bool conv3_px_covers(const Plan& p, int Zt, bool /*raw*/) { return p.mode == 0 && p.nposp == kPxPositions && kPatch + 2 * Zt + 2 + 6 <= kPxPositions; }
 
 int launch_conv3_px(const Conv3Args& a, const Plan& p, hipStream_t stream) {
     auto kern = conv3_px_kernel<kPxResidentHalfRows, kPxPositions>;

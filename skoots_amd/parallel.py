@@ -394,7 +394,17 @@ class ShardedVolume:
         elif tile_batch is None:
             tile_batch = MAX_TILE_BATCH
         self.tile_batch_used = tile_batch
-        ctxs = [model] + [model.clone_context() for _ in range(n_streams - 1)] if model is not None else [None]
+        if model is not None:   # the extra contexts (activation buffers of the second, third ... stream) live across calls
+            cache = self.__dict__.setdefault("_ctx_cache", {})
+            extra = cache.setdefault(id(model), [])
+            while len(extra) < n_streams - 1:
+                extra.append(model.clone_context())
+            for c in extra:   # same weights object; follow the switches of the primary
+                c.precision, c.fold_upsample, c.box_store, c.defer_activation = (model.precision, model.fold_upsample,
+                                                                                model.box_store, model.defer_activation)
+            ctxs = [model] + extra[:n_streams - 1]
+        else:
+            ctxs = [None]
         for c in ctxs:
             if c is not None:
                 c.profile = conv_profile
