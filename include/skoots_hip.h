@@ -142,6 +142,20 @@ int sk_seam_pairs(const int32_t* labels, int X, int Y, int Z, int axis, int v,
 int sk_seam_components_host(const int32_t* pairs_host, int n_pairs, int32_t* to_replace_host,
                             int32_t* replace_with_host, int capacity);
 
+/* Device-side seam merge of the Z-sharded labelling (no reference counterpart: the reference is single device; the
+ * partition is that of flood_fill.py:82-117).  Together they let a rank go from its local labelling to the merged global
+ * ids without reading anything back to the host between the collectives:
+ *   sk_compact_nonzero: flat positions of the non-zero labels into positions[capacity] (any order); *count (device,
+ *     pre-zeroed) counts ALL of them, also past the capacity -- the caller detects an overflow from it later.
+ *   sk_seam_union: meta (ranks, row_stride) int32 rows [components, pairs, -, - | pairs in rank-local ids ...] as
+ *     all-gathered; offsets (ranks + 1) int64 exclusive prefix sums of the component counts (device); lut
+ *     (lut_size, pre-filled with the identity) <- smallest global id of every id's component.  One workgroup.
+ *   sk_relabel_lut_offset: labels[i] = lut[labels[i] + *offset] for labels[i] > 0 (offset: device scalar). */
+int sk_compact_nonzero(const int32_t* labels, int64_t n, int64_t* positions, uint64_t* count, int64_t capacity, void* stream);
+int sk_seam_union(const int32_t* meta, int ranks, int row_stride, int pair_capacity, const int64_t* offsets, int32_t* lut,
+                  int64_t lut_size, void* stream);
+int sk_relabel_lut_offset(int32_t* labels, int64_t n, const int32_t* lut, int64_t lut_size, const int64_t* offset, void* stream);
+
 /* labels[i] = lut[labels[i]] for 0 <= labels[i] < lut_size (in place; flood_fill.py:177-234). */
 int sk_relabel_lut(int32_t* labels, int64_t n, const int32_t* lut, int lut_size, void* stream);
 

@@ -63,6 +63,9 @@ _SIGS = {
     "sk_seam_pairs": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]),
     "sk_seam_components_host": (i32, [ip, i32, ip, ip, i32]),
     "sk_relabel_lut": (i32, [vp, i64, vp, i32, vp]),
+    "sk_compact_nonzero": (i32, [vp, i64, vp, vp, i64, vp]),
+    "sk_seam_union": (i32, [vp, i32, i32, i32, vp, vp, i64, vp]),
+    "sk_relabel_lut_offset": (i32, [vp, i64, vp, i64, vp, vp]),
     "sk_renumber_workspace_bytes": (sz, [i64, i32]),
     "sk_first_seen": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "sk_renumber": (i32, [vp, i64, i32, vp, sz, vp, vp]),

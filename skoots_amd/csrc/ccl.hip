@@ -392,9 +392,100 @@ __global__ void __launch_bounds__(256) relabel_lut_kernel(int32_t* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Z-sharded labelling without a host round trip between its collectives (skoots_amd/lib/flood_fill.py: label_slab).
+// ------------------------------------------------------------------------------------------------------------------
+// positions (flat index into `labels`) of the non-zero entries, in any order; *count keeps counting past `capacity`
+__global__ void __launch_bounds__(256) compact_nonzero_kernel(const int32_t* __restrict__ labels, long long n, long long* __restrict__ out,
+                                                              unsigned long long* __restrict__ count, long long capacity) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    for (; i - lane < n; i += stride) {   // whole waves iterate together (ballot)
+        const bool nz = i < n && labels[i] != 0;
+        const unsigned long long bal = __ballot(nz);
+        if (bal == 0) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(bal));
+        base = __shfl(base, 0);
+        if (nz) {
+            const long long slot = (long long)base + __popcll(bal & ((1ull << lane) - 1ull));
+            if (slot < capacity) out[slot] = i;
+        }
+    }
+}
+
+// Union of label ids over seam pairs, on the device: one workgroup.  pairs (R, cap, 2) in rank-LOCAL ids, row r holds
+// min(npairs[r], cap) valid pairs (upper rank's id, this rank's id): column 0 is shifted by offsets[min(r + 1, R - 1)],
+// column 1 by offsets[r] (exclusive prefix sums of the ranks' component counts) to global ids.  lut (>= total + 1
+// entries, pre-filled with the identity by the caller) ends with lut[id] = smallest id of id's component -- the
+// partition of flood_fill.py:82-117; which member names a component is free here (the sharded path renumbers anyway).
+__global__ void __launch_bounds__(1024) seam_union_kernel(const int32_t* __restrict__ meta, int R, int row_stride, int cap,
+                                                          const long long* __restrict__ offsets, int32_t* __restrict__ lut,
+                                                          long long lut_size) {
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int r = 0; r < R; ++r) {
+            const int32_t* row = meta + (long long)r * row_stride;
+            const int n = min(row[1], cap);
+            const long long o0 = offsets[min(r + 1, R - 1)], o1 = offsets[r];
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const long long ga = row[4 + 2 * i] + o0, gb = row[4 + 2 * i + 1] + o1;
+                if (ga <= 0 || gb <= 0 || ga >= lut_size || gb >= lut_size) continue;
+                if (pass == 0) {
+                    unite(lut, (int)ga, (int)gb);
+                } else {   // every id that appears in a pair points at its root
+                    lut[ga] = find_root(lut, (int)ga);
+                    lut[gb] = find_root(lut, (int)gb);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// labels[i] = lut[labels[i] + *offset] for labels[i] > 0 (local ids -> merged global ids)
+__global__ void __launch_bounds__(256) relabel_lut_offset_kernel(int32_t* __restrict__ labels, long long n, const int32_t* __restrict__ lut,
+                                                                 long long lut_size, const long long* __restrict__ offset) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long off = *offset;
+    for (; i < n; i += stride) {
+        const int v = labels[i];
+        if (v > 0) {
+            const long long g = v + off;
+            labels[i] = g < lut_size ? lut[g] : (int32_t)g;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int sk_compact_nonzero(const int32_t* labels, int64_t n, int64_t* positions, uint64_t* count, int64_t capacity, void* stream) {
+    SK_CHECK_ARG(labels && positions && count && n > 0 && capacity > 0, "sk_compact_nonzero: bad arguments");
+    compact_nonzero_kernel<<<sk::stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(labels, n, (long long*)positions,
+                                                                                     (unsigned long long*)count, capacity);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_seam_union(const int32_t* meta, int ranks, int row_stride, int pair_capacity, const int64_t* offsets, int32_t* lut,
+                  int64_t lut_size, void* stream) {
+    SK_CHECK_ARG(meta && offsets && lut && ranks > 0 && pair_capacity >= 0 && row_stride >= 4 + 2 * pair_capacity && lut_size > 0,
+                 "sk_seam_union: bad arguments");
+    seam_union_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(meta, ranks, row_stride, pair_capacity, (const long long*)offsets, lut,
+                                                           lut_size);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_relabel_lut_offset(int32_t* labels, int64_t n, const int32_t* lut, int64_t lut_size, const int64_t* offset, void* stream) {
+    SK_CHECK_ARG(labels && lut && offset && n > 0 && lut_size > 0, "sk_relabel_lut_offset: bad arguments");
+    relabel_lut_offset_kernel<<<sk::stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(labels, n, lut, lut_size, (const long long*)offset);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
 
 size_t sk_ccl_workspace_bytes(int64_t n) {
     size_t chunks = (size_t)((n + kScanChunk - 1) / kScanChunk);

@@ -103,8 +103,92 @@ def label_skeleton(skeleton_u8: Tensor, crop=FLOOD_CROP, reference_ids: bool = T
     return labels
 
 
+NNZ_DIV = 64   # capacity of the sparse label gather: 1 / 64 of a slab's voxels may be skeleton foreground (1.6 %)
+
+
 def label_slab(skeleton_win: Tensor, shape, slab, window, slabs, rank: int, comm, sparse=None, profile=None):
     """Z-sharded labelling.  ``skeleton_win``: this rank's (X, Y, window) uint8 mask.
+    Labels the rank's slab, merges components across slab boundaries (exchange of the boundary label planes, ONE
+    fixed-size all-gather of the seam pairs, union on the device) and all-gathers the foreground (position, label) lists.
+    Returns (full (X, Y, Z) int32 label volume, number of labels before merging as a device scalar, overflow flag as a
+    device scalar).  Ids are 1..K in rank order, not the single-GPU flood-grid numbering; the partition (what stage 3
+    and renumber consume) is identical.
+
+    NO host round trip between the collectives: every data-dependent size has a fixed capacity (PAIR_CAP seam pairs per
+    rank, 1 / NNZ_DIV of the slab's voxels foreground), counts stay on the device, the seam graph is merged by
+    sk_seam_union instead of the host DFS.  When a capacity is exceeded the overflow flag comes back set and the caller
+    (ShardedVolume.run, after the stage's timing synchronisation) repeats the stage with :func:`_label_slab_sync`;
+    ``sparse=False`` (dense label gather) and PAIR_CAP <= 0 take that path directly."""
+    if sparse is False or PAIR_CAP <= 0:
+        full, total = _label_slab_sync(skeleton_win, shape, slab, window, slabs, rank, comm, sparse=sparse, profile=profile)
+        dev = skeleton_win.device
+        return full, torch.tensor(total, dtype=torch.int64, device=dev), torch.zeros((), dtype=torch.bool, device=dev)
+    X, Y, Z = shape
+    dev = skeleton_win.device
+    st = _ffi.stream_ptr(dev)
+    zlo, zhi = slab
+    zl = zhi - zlo
+    w0 = window[0]
+    world = len(slabs)
+    zmax = max(b - a for a, b in slabs)
+    nnz_cap = max(1 << 16, (X * Y * zmax) // NNZ_DIV)
+    local = torch.zeros((X, Y, skeleton_win.shape[2]), dtype=torch.int32, device=dev)
+    ws_bytes = _ffi.lib.sk_ccl_workspace_bytes(X * Y * zl)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    state = torch.tensor([-1, 0, 0, 0], dtype=torch.int32, device=dev)  # first id = state[0] + 2 = 1
+    with maybe_span(profile, "ccl", dev, CCL_BYTES_PER_VOXEL * X * Y * zl):
+        _ffi.check(_ffi.lib.sk_ccl_crop(_ffi.ptr(skeleton_win), _ffi.ptr(local), X, Y, skeleton_win.shape[2],
+                                        0, 0, zlo - w0, X, Y, zl, _ffi.ptr(ws), ws_bytes, _ffi.ptr(state), st))
+    del ws
+    mine = local[:, :, zlo - w0:zhi - w0].contiguous()
+    # boundary planes in LOCAL ids: the first plane of every slab goes to the rank below it
+    sends, like = [], []
+    if rank > 0:
+        sends.append((rank - 1, mine[:, :, 0].contiguous()))
+    if rank < world - 1:
+        like.append((rank + 1, torch.empty((X, Y), dtype=torch.int32, device=dev)))
+    got = comm.exchange(sends, like, what="label_seam_planes")
+    # message: [components, seam pairs, foreground voxels (two 31-bit words) | the pairs, written by the kernel itself]
+    row = 4 + 2 * PAIR_CAP
+    msg = torch.zeros(row, dtype=torch.int32, device=dev)
+    if rank < world - 1:
+        two = torch.stack([mine[:, :, zl - 1], got[0]], dim=2).contiguous()
+        _ffi.check(_ffi.lib.sk_seam_pairs(_ffi.ptr(two), X, Y, 2, 2, 1, _ffi.ptr(msg[4:]), _ffi.ptr(msg[1:2]), PAIR_CAP, st))
+    pos = torch.empty(nnz_cap, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    _ffi.check(_ffi.lib.sk_compact_nonzero(_ffi.ptr(mine), mine.numel(), _ffi.ptr(pos), _ffi.ptr(cnt), nnz_cap, st))
+    msg[0:1] = state[1:2]
+    msg[2:3] = (cnt & 0x7FFFFFFF).to(torch.int32)
+    msg[3:4] = (cnt >> 31).to(torch.int32)
+    meta = torch.stack(comm.all_gather(msg, what="label_meta")).contiguous()          # (world, row) int32, on the device
+    counts = meta[:, 0].to(torch.int64)
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(counts, 0)]).contiguous()
+    nnz_all = meta[:, 2].to(torch.int64) + (meta[:, 3].to(torch.int64) << 31)
+    overflow = ((meta[:, 1] > PAIR_CAP) | (nnz_all > nnz_cap)).any()
+    lut_size = world * nnz_cap + 1     # a rank has at most as many components as foreground voxels
+    lut = torch.arange(lut_size, dtype=torch.int32, device=dev)
+    _ffi.check(_ffi.lib.sk_seam_union(_ffi.ptr(meta), world, row, PAIR_CAP, _ffi.ptr(offsets), _ffi.ptr(lut), lut_size, st))
+    _ffi.check(_ffi.lib.sk_relabel_lut_offset(_ffi.ptr(mine), mine.numel(), _ffi.ptr(lut), lut_size,
+                                              _ffi.ptr(offsets[rank:rank + 1]), st))
+    # every rank needs the full label volume (a 10-step follow ends up to ~165 planes away): fixed-size lists of
+    # (global position << 32 | label), -1 past a rank's count
+    valid = torch.arange(nnz_cap, device=dev) < cnt
+    p = torch.where(valid, pos, torch.zeros_like(pos))
+    xy, zz = torch.div(p, zl, rounding_mode="floor"), p % zl
+    packed = torch.where(valid, ((xy * Z + zz + zlo) << 32) | mine.reshape(-1)[p].to(torch.int64), torch.full_like(p, -1))
+    full = torch.zeros(X * Y * Z + 1, dtype=torch.int32, device=dev)       # + one slot that swallows the padding entries
+    for part in comm.all_gather(packed, what="label_gather"):
+        ok = part >= 0
+        full.index_put_((torch.where(ok, part >> 32, torch.full_like(part, X * Y * Z)),),
+                        torch.where(ok, part & 0xFFFFFFFF, torch.zeros_like(part)).to(torch.int32))
+    return full[:X * Y * Z].view(X, Y, Z), offsets[-1], overflow
+
+
+def _label_slab_sync(skeleton_win: Tensor, shape, slab, window, slabs, rank: int, comm, sparse=None, profile=None):
+    """:func:`label_slab` with every data-dependent size read back to the host (pair counts, foreground counts, the seam
+    graph walked by sk_seam_components_host): exact-size messages, any number of seam pairs, dense or sparse label
+    gather.  The fallback of the sync-free path and what ``sparse=False`` selects.
+    ``skeleton_win``: this rank's (X, Y, window) uint8 mask.
     Labels the rank's slab, merges components across slab boundaries (exchange of the
     boundary label planes + all-gather of the seam equivalences) and all-gathers the
     slabs (``sparse``: as foreground (position, label) lists; None = when that is smaller).  Returns (full (X, Y, Z) int32 label volume, number of labels before merging).

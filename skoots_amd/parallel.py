@@ -448,11 +448,22 @@ class ShardedVolume:
             labels = label_skeleton(state.skeleton, reference_ids=False, profile=stage_profile)
             n_labels_hint = None
         else:
-            labels, n_labels_hint = label_slab(state.skeleton, self.shape, self.slab, self.window,
-                                               self.slabs, self.rank, comm, sparse=self.sparse_labels,
-                                               profile=stage_profile)
+            labels, n_labels_hint, overflow = label_slab(state.skeleton, self.shape, self.slab, self.window,
+                                                         self.slabs, self.rank, comm, sparse=self.sparse_labels,
+                                                         profile=stage_profile)
         state.labels = labels
         self._tick("stage2", t0)
+        if self.world > 1 or self.force_distributed:
+            # label_slab ran without reading anything back; the stage's timing synchronisation above has happened, so
+            # the overflow flag costs one tiny copy.  It is the same on every rank (all-gathered metadata).
+            if bool(overflow.item()):
+                from .lib.flood_fill import _label_slab_sync
+                t0 = time.perf_counter()
+                labels, n_labels_hint = _label_slab_sync(state.skeleton, self.shape, self.slab, self.window, self.slabs,
+                                                         self.rank, comm, sparse=self.sparse_labels, profile=stage_profile)
+                state.labels = labels
+                self._tick("stage2", t0)
+            n_labels_hint = int(n_labels_hint)
 
         # ---- stage 3 --------------------------------------------------------------------
         t0 = time.perf_counter()

@@ -53,7 +53,7 @@ def _run_rank(rank, world, port, q, sparse=None, pair_cap=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,sparse,pair_cap", [(2, None, None), (3, None, None), (2, False, None), (2, None, 0)])
+@pytest.mark.parametrize("world,sparse,pair_cap", [(2, None, None), (3, None, None), (2, False, None), (2, None, 0), (2, None, 1)])
 def test_sharded_equals_single(world, sparse, pair_cap):
     from skoots_amd.lib import eval as E
     out_vol, k = _field()
@@ -86,8 +86,10 @@ def test_sharded_equals_single(world, sparse, pair_cap):
         # per-exchange accounting that bench.py prints for N > 1: one metadata gather per run (two on the overflow path)
         for key in ("block_exchange", "label_seam_planes", "label_meta", "label_gather", "vector_halo", "renumber_allreduce"):
             assert key in comm_stats and comm_stats[key]["calls"] >= 1, (key, comm_stats)
-        # seed 11 puts skeleton cores across the z = 90 slab boundary: with a zero pair capacity the second gather runs
-        assert comm_stats["label_meta"]["calls"] == (2 if pair_cap is not None else 1), comm_stats["label_meta"]
+        # seed 11 puts skeleton cores across the z = 90 slab boundary.  The sync-free path gathers the metadata ONCE; a zero
+        # pair capacity selects the host-synchronised path (its second, exactly sized gather runs: 2 calls); a capacity of
+        # one lets the sync-free path run, overflow, and be repeated on the host-synchronised path (1 + 2 calls)
+        assert comm_stats["label_meta"]["calls"] == {None: 1, 0: 2, 1: 3}[pair_cap], comm_stats["label_meta"]
     assert np.array_equal(got, want)
 
 
