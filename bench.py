@@ -27,10 +27,12 @@ path (BASELINE's dtype), ``also.split`` = the same volume at the precision that 
 Mvoxels/s trained, roofline); ``--no-also`` prints the first alone.  ``box`` = a bare-MFMA-loop probe of this device:
 boxes differ by ~6 % under matrix load, figures from two boxes compare only beside it.
 
-``--streams`` (default 2, with ``--tile-batch 32``): two tile batches in flight on two HIP streams (+1.3 % over one stream
-of 64-tile batches: the conv kernels fill the register file, so only launch tails overlap).  Overlapping launches make
-per-launch durations meaningless, so with more than one stream ``roofline`` (and the stage rooflines) are measured in ONE
-extra single-stream step after the warm-up, outside the timed region (``roofline.timed_over`` says so).
+``--streams N`` (default 1): N tile batches in flight on N HIP streams.  ``--streams 2 --tile-batch 32`` measured +1.3 %
+over one stream of 64-tile batches (the conv kernels fill the register file, so only launch tails overlap).  Overlapping
+launches make per-launch durations meaningless -- rocprofv3's and the bench's own -- so with more than one stream
+``roofline`` (and the stage rooflines) are measured in ONE extra single-stream step after the warm-up, outside the timed
+region (``roofline.timed_over`` says so); the default stays one stream so that the driver's line and a rocprofv3 run of
+the same command time the same launches.
 
 Synthetic data: uint8-range random image, random-init network of the named shape
 (DIMS [32,64,128,64,32], DEPTHS [2,2,2,2,2]).  A random-init net never crosses the 0.8
@@ -710,14 +712,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=["eval", "train"], default="eval",
                     help="eval: BASELINE configs[2]/[3] (the headline metric); train: configs[4], one training step")
-    ap.add_argument("--tile-batch", type=int, default=32, help="tiles per network launch (<= 64) and stream")
+    ap.add_argument("--tile-batch", type=int, default=64, help="tiles per network launch (<= 64) and stream")
     ap.add_argument("--shape", type=str, default="", help="override X,Y,Z (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inject", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the live parity_vs_fp32_mode measurement")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="tile batches in flight (HIP streams); default 2 x 32 tiles: +1.3 %% over 1 x 64 (the convs fill the register "
-                         "file, so only launch tails overlap); `roofline` is then timed in single-stream warm-up steps")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="tile batches in flight (HIP streams).  2 x 32 tiles measured +1.3 %% over 1 x 64 (the convs fill the register "
+                         "file, so only launch tails overlap) -- not the default: overlapped launches make rocprofv3's per-kernel "
+                         "durations of the same command incomparable with `roofline`, which is then taken in one extra single-stream step")
     ap.add_argument("--no-fold", action="store_true", help="A/B: decoder convs on the direct kernels instead of sk_conv3d_upfold")
     ap.add_argument("--precision", choices=["fp16", "split", "fp32", "bf16", "mixed"], default=None,
                     help="eval: fp16 (default) | split (<= 1e-3 vs fp32) | fp32; train: bf16 (default) | mixed (fp16) | fp32")

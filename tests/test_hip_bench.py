@@ -59,7 +59,7 @@ def test_eval_line_contract(precision):
 def test_eval_line_two_streams_keeps_a_roofline():
     """--streams 2: the timed steps overlap two tile batches; the per-launch roofline then comes from the single-stream
     warm-up steps and says so."""
-    d = _run("--steps", "1", "--warmup", "2", "--shape", "512,512,64", "--no-also", "--no-cpu-baseline")   # default: 2 streams x 32 tiles
+    d = _run("--steps", "1", "--warmup", "2", "--shape", "512,512,64", "--streams", "2", "--tile-batch", "32", "--no-also", "--no-cpu-baseline")
     r = d["roofline"]
     assert d["config"]["streams"] == 2 and "warm-up" in r["timed_over"] and r["launches"] > 0 and 0.02 < r["frac"] < 1.0
     assert d["roofline_assign"]["launches"] >= 1 and d["config"]["instances"] > 0

@@ -71,8 +71,8 @@ def sq(sdir, cmd):
 
 
 STAGE_KERNELS = {"gate_dilate_scatter": ("gate_dilate_scatter_kernel",),
-                 "ccl": ("ccl_",),
-                 "follow_assign": ("follow_assign_kernel",),
+                 "ccl": ("ccl_", "ccl16_"),
+                 "follow_assign": ("follow_assign_kernel", "follow_assign2_kernel"),
                  "renumber": ("first_seen_kernel", "mark_kernel", "chunk_popc_kernel", "chunk_scan_kernel", "word_prefix_kernel",
                               "build_lut_kernel", "apply_lut_kernel")}
 
