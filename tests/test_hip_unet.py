@@ -51,15 +51,16 @@ CONV_CASES = [
     (1, (5, 9, 5), [(64, 0)], 128, 2),
     (1, (9, 10, 5), [(128, 0)], 64, 1),          # pointwise reducers
     (1, (12, 10, 10), [(64, 0)], 32, 1),
-    # the plane-streaming 32 -> 32 kernel (conv3_px_kernel: 176-position planes, z 16 .. 22): x-chunks of 1, 2, 3 planes,
-    # an odd chunk behind even ones, several chunks with interior chunk seams, every z extent it covers
+    # the plane-streaming 32 -> 32 kernel (conv3_px_kernel: 176-position planes, z 16 .. 20): x-chunks of 1, 2, 3 planes,
+    # an odd chunk behind even ones, several chunks with interior chunk seams; z 22 / 23 (same plane size, too few padding
+    # positions) stay on conv3_m16_kernel
     (1, (1, 12, 20), [(32, 0)], 32, 3),
     (1, (2, 9, 20), [(32, 0)], 32, 3),
     (1, (3, 12, 16), [(32, 0)], 32, 3),
     (2, (37, 14, 20), [(32, 0)], 32, 3),
     (1, (16, 30, 22), [(32, 0)], 32, 3),
     (1, (9, 7, 18), [(32, 0)], 32, 3),
-    (1, (5, 8, 23), [(32, 0)], 32, 3),           # 176 positions with no padding position left: conv3_m16_kernel
+    (1, (5, 8, 23), [(32, 0)], 32, 3),
 ]
 
 
