@@ -108,6 +108,13 @@ struct Conv3Args {
 #else
 #define SK_ABL(a, bits) 0
 #endif
+// compile-time ablations of conv3_px_kernel's MFMA body (a run-time switch there changes the schedule it is meant to
+// measure): make ... EXTRA="-DSK_TUNING -DSK_PX_ABLATE=48"; 16: no LDS weight reads, 32: no B fragment reads after a
+// step's first tap row.  Results are wrong by design.
+#ifndef SK_PX_ABLATE
+#define SK_PX_ABLATE 0
+#endif
+#define SK_PX_ABL(bits) ((SK_PX_ABLATE) & (bits))
 
 __device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -1321,6 +1328,7 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     auto issue_plane = [&](int t) {
         const int x = xa - 1 + t;
         if (x < 0 || x >= a.Xt) return;   // outside the tile: the steps that would read it skip their MFMAs
+        if (SK_ABL(a, 1) && t >= NSLOT) return;   // timing experiment (-DSK_TUNING): no LDS-DMA after the first planes
         const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(srcb + (long long)x * s0.plane, (unsigned)s0.plane);
         char* lbase = lds + (t & (NSLOT - 1)) * plane_bytes;
 #pragma unroll
@@ -1473,9 +1481,21 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
                 const int h = dydz * 2 + i;   // its weights sit in wq[h & 1], its B fragments in bq[dydz & 1]
                 const half8(&W)[3] = wq[h & 1];
                 const int ndy = i == 0 ? dydz : dydz + 1, ni = i ^ 1;         // the next half row
-                const bool wread = ndy < 9 && 2 * ndy + ni >= RESH;            // ... reads its weights from LDS
-                const bool bread = i == 1 && dydz < 8;                         // ... starts a new tap row: B fragments
-                if (ndy < 9 && !wread) wfrag(ndy, ni, wq[(h + 1) & 1]);        // resident row: register names only
+                bool wread = ndy < 9 && 2 * ndy + ni >= RESH;                  // ... reads its weights from LDS
+                bool bread = i == 1 && dydz < 8;                               // ... starts a new tap row: B fragments
+                if (SK_PX_ABL(16) && wread) {   // timing experiment: no LDS weight reads (a resident half row instead)
+                    wread = false;
+                    wfrag((2 * ndy + ni) % RESH / 2, (2 * ndy + ni) % RESH % 2, wq[(h + 1) & 1]);
+                } else if (ndy < 9 && !wread) {
+                    wfrag(ndy, ni, wq[(h + 1) & 1]);                           // resident row: register names only
+                }
+                if (SK_PX_ABL(32) && bread) {   // timing experiment: no B fragment reads after the first tap row
+                    bread = false;
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) bq[(dydz + 1) & 1][pl][jj] = bq[dydz & 1][pl][jj];
+                }
                 // read k of the next half row, in consumption order: W0, A0, B0, W1, W2, A1, B1
                 auto next_read = [&](int k) {
                     const char* wp = wlds + (2 * ndy + ni - RESH) * 3 * 1024 + lane * 16;
@@ -1537,6 +1557,11 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
     // raw fp16 store of one finished output plane + its GroupNorm partial sums (conv3_m16_kernel's epilogue); returns the
     // number of store instructions issued (0 or 2: the counted landing wait needs it)
     auto finish_plane = [&](f32x4 (&o)[2][2], int x) -> int {
+        if (SK_ABL(a, 4)) {   // timing experiment (-DSK_TUNING): no epilogue (the accumulators stay observable through gsum)
+            gsum[0] += o[0][0][0] + o[0][1][0];
+            gsum[1] += o[1][0][0] + o[1][1][0];
+            return 0;
+        }
         const bool xbox = !a.has_box || (x >= a.box_lo[0] && x < a.box_hi[0]);   // wave-uniform
         const __amdgpu_buffer_rsrc_t rout = sk::make_rsrc(outb + (long long)x * out_plane, (unsigned)out_plane);
 #pragma unroll
@@ -1582,7 +1607,7 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SK_T(4)
-        if (af) {
+        if (af && !SK_ABL(a, 8)) {
             for (int t = t_lo; t < t_hi; ++t) activate_plane(t);
         }
         SK_T(5)
@@ -2452,7 +2477,7 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
             }
             a.has_box = 1;
         }
-        bool use_px = cout == 32 && a.nchunks == 1 && n_src == 1 && !srcs[0].upsample && conv3_px_covers(p, oz, a.act[0] != nullptr) && !a.ablate;
+        bool use_px = cout == 32 && a.nchunks == 1 && n_src == 1 && !srcs[0].upsample && conv3_px_covers(p, oz, a.act[0] != nullptr);
 #ifdef SK_TUNING
         if (getenv("SK_CONV_NO_PX")) use_px = false;   // A/B: the single-chunk COUT-32 layers on conv3_m16_kernel
 #endif
