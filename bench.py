@@ -268,7 +268,7 @@ def stage_rooflines(sprof):
 
 
 def box_probe(dev):
-    """Rate of a bare MFMA register loop on this device (sk_mfma_probe), printed next to the line: MI355X boxes hold
+    """Rates of a bare MFMA register loop on this device (sk_mfma_probe; pseudo-random operands, one pair and rotating), printed next to the line: MI355X boxes hold
     different clocks under matrix load (the same code read 548-580 Mvox/s across boxes in round 2), so a figure from
     another box is comparable only beside this one.  ``band``: this device against the rate the loop sustains on most boxes."""
     import ctypes as C
@@ -276,15 +276,19 @@ def box_probe(dev):
     scratch = torch.empty(512 * 256, dtype=torch.float32, device=dev)
     fl = C.c_double(0.0)
     st = _ffi.stream_ptr(dev)
-    best = 0.0
-    for rep in range(4):   # first launch warms the clocks
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(torch.cuda.current_stream(dev))
-        _ffi.check(_ffi.lib.sk_mfma_probe(_ffi.ptr(scratch), scratch.numel() * 4, 20000, C.byref(fl), st))
-        e1.record(torch.cuda.current_stream(dev))
-        e1.synchronize()
-        if rep:
-            best = max(best, fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    rates = []
+    for vary in (0, 1):
+        best = 0.0
+        for rep in range(4):   # first launch warms the clocks
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
+            _ffi.check(_ffi.lib.sk_mfma_probe(_ffi.ptr(scratch), scratch.numel() * 4, 20000, vary, C.byref(fl), st))
+            e1.record(torch.cuda.current_stream(dev))
+            e1.synchronize()
+            if rep:
+                best = max(best, fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+        rates.append(best)
+    best = rates[0]
     # memory side: a device-to-device copy of 1 GiB (2 GiB of traffic), best of three
     src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
     dst = torch.empty_like(src)
@@ -298,10 +302,12 @@ def box_probe(dev):
         if rep:
             hbm = max(hbm, 2.0 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9)
     del src, dst
-    nominal = 2150.0   # what the loop sustains on most boxes of this pool (rounds 1-3: 2177-2244; the guide's slowest device is 12 % below its fastest)
-    r = best / nominal
-    return {"mfma_probe_tflops": round(best, 1), "probe": "bare v_mfma_f32_16x16x32_f16 loop, 2 waves per SIMD, every CU (sk_mfma_probe)",
-            "vs_nominal_2150": round(r, 3), "band": "slow" if r < 0.97 else ("fast" if r > 1.03 else "typical"),
+    nominal = 1950.0   # the rotating-operand loop on the boxes of round 3 (1 975; round 1's register loop on random data: 1 900)
+    r = rates[1] / nominal
+    return {"mfma_probe_tflops": round(best, 1), "mfma_probe_varying_operands_tflops": round(rates[1], 1),
+            "probe": "bare v_mfma_f32_16x16x32_f16 loop, 2 waves per SIMD, every CU (sk_mfma_probe): one operand pair | four x four "
+                     "pseudo-random fragments in rotation (the clock a kernel on real data gets)",
+            "vs_nominal_1950": round(r, 3), "band": "slow" if r < 0.97 else ("fast" if r > 1.03 else "typical"),
             "hbm_copy_GBps": round(hbm, 1), "hbm_probe": "torch device-to-device copy of 1 GiB, read + write bytes / time",
             "device": torch.cuda.get_device_name(dev)}
 

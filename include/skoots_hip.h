@@ -513,10 +513,12 @@ int sk_mask_iou(const int32_t* gt, const int32_t* pred, int64_t n, const int32_t
  * ------------------------------------------------------------------------ */
 
 /* Box probe: one launch of a bare v_mfma_f32_16x16x32_f16 register loop (512 workgroups of 4 waves, `iters` x 8
- * MFMAs per wave, non-trivial operands).  The caller times it with events on `stream`; *flops (host, may be NULL)
- * receives the FLOPs of the launch.  bench.py prints the rate next to its line: devices hold different clocks under
- * matrix load, so figures from two boxes are comparable only beside it.  scratch: >= 512 KiB of device memory. */
-int sk_mfma_probe(void* scratch, size_t scratch_bytes, int iters, double* flops, void* stream);
+ * MFMAs per wave, pseudo-random operands).  vary_operands = 0: every MFMA multiplies the same register pair;
+ * 1: four A x four B fragments in rotation, so that the operand data changes with every instruction as in a real
+ * kernel (the chip holds a lower clock then: the rate a matrix kernel on real data can reach).  The caller times it
+ * with events on `stream`; *flops (host, may be NULL) receives the FLOPs of the launch.  bench.py prints both rates
+ * next to its line: devices differ, so figures from two boxes compare only beside them.  scratch: >= 512 KiB. */
+int sk_mfma_probe(void* scratch, size_t scratch_bytes, int iters, int vary_operands, double* flops, void* stream);
 
 /* Phase-timing builds (-DSK_TIMING, tools/conv_phase_timing.py) dump per-wave cycle sums of the conv kernels into
  * this device buffer, [4096 workgroups][4 waves][16 slots] int64 (bytes must cover all of it); NULL detaches it.

@@ -47,7 +47,7 @@ class ConvSrc(C.Structure):
 _SIGS = {
     "sk_last_error": (C.c_char_p, []),
     "sk_abi_version": (i32, []),
-    "sk_mfma_probe": (i32, [vp, sz, i32, C.POINTER(C.c_double), vp]),
+    "sk_mfma_probe": (i32, [vp, sz, i32, i32, C.POINTER(C.c_double), vp]),
     "sk_debug_set_timing_buffer": (i32, [vp, sz]),
     "sk_vec_interleave": (i32, [vp, vp, i64, vp]),
     "sk_vec_deinterleave": (i32, [vp, vp, i64, vp]),

@@ -110,7 +110,7 @@ struct Conv3Args {
 #endif
 // compile-time ablations of conv3_px_kernel's MFMA body (a run-time switch there changes the schedule it is meant to
 // measure): make ... EXTRA="-DSK_TUNING -DSK_PX_ABLATE=48"; 16: no LDS weight reads, 32: no B fragment reads after a
-// step's first tap row.  Results are wrong by design.
+// step's first tap row, 64: no barrier between the steps.  Results are wrong by design.
 #ifndef SK_PX_ABLATE
 #define SK_PX_ABLATE 0
 #endif
@@ -1611,7 +1611,10 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
             for (int t = t_lo; t < t_hi; ++t) activate_plane(t);
         }
         SK_T(5)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (SK_PX_ABL(64))   // timing experiment: no barrier between the steps
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         SK_T(1)
     };
     typedef std::integral_constant<bool, true> T_;

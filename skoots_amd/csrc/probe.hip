@@ -9,19 +9,34 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(256, 2) mfma_probe_kernel(float* out, int iters) {
-    half8 a, b;
+__global__ void __launch_bounds__(256, 2) mfma_probe_kernel(float* out, int iters, int vary) {
+    // four A and four B fragments of pseudo-random halves in (-0.5, 0.5), different per lane and element.  vary = 0: every
+    // MFMA multiplies the same pair (what a register loop usually does: the operand buses barely toggle); vary = 1: the
+    // pairs rotate, so consecutive instructions see different data on every operand -- what a real kernel does.  The
+    // chip holds a lower clock on the second (MI355X_MICROARCH.md, DVFS give-back: zero-filled inputs +19 %).
+    half8 a[4], b[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {   // values in (-1, 1) that differ per lane and element (zero operands clock higher)
-        a[i] = (_Float16)((float)((threadIdx.x * 37 + i * 11) % 201 - 100) * 0.0099f);
-        b[i] = (_Float16)((float)((threadIdx.x * 53 + i * 29) % 199 - 99) * 0.0101f);
-    }
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned ha = (threadIdx.x * 2654435761u + (f * 8 + i) * 40503u) >> 7;
+            const unsigned hb = (threadIdx.x * 2246822519u + (f * 8 + i) * 69069u + 12345u) >> 9;
+            a[f][i] = (_Float16)((float)(ha & 1023u) * (1.0f / 1024.0f) - 0.5f);
+            b[f][i] = (_Float16)((float)(hb & 1023u) * (1.0f / 1024.0f) - 0.5f);
+        }
     f32x4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int it = 0; it < iters; ++it) {
+    if (vary) {
+        for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i & 3], b[(i >> 1) & 3], acc[i], 0, 0, 0);
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], acc[i], 0, 0, 0);
+        }
     }
     float s = 0.0f;
 #pragma unroll
@@ -30,12 +45,12 @@ __global__ void __launch_bounds__(256, 2) mfma_probe_kernel(float* out, int iter
 }
 }  // namespace
 
-extern "C" int sk_mfma_probe(void* scratch, size_t scratch_bytes, int iters, double* flops, void* stream) {
+extern "C" int sk_mfma_probe(void* scratch, size_t scratch_bytes, int iters, int vary_operands, double* flops, void* stream) {
     constexpr int kBlocks = 512;   // 256 CUs x 2 workgroups of 4 waves
     SK_CHECK_ARG(scratch != nullptr && scratch_bytes >= (size_t)kBlocks * 256 * sizeof(float),
                  "sk_mfma_probe: scratch must hold %d floats", kBlocks * 256);
     SK_CHECK_ARG(iters > 0, "sk_mfma_probe: iters must be positive");
-    mfma_probe_kernel<<<kBlocks, 256, 0, (hipStream_t)stream>>>((float*)scratch, iters);
+    mfma_probe_kernel<<<kBlocks, 256, 0, (hipStream_t)stream>>>((float*)scratch, iters, vary_operands);
     SK_CHECK_LAUNCH();
     if (flops) *flops = (double)kBlocks * 4 * iters * 8 * (2.0 * 16 * 16 * 32);
     return SK_OK;

@@ -41,7 +41,8 @@ def test_eval_line_contract(precision):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mvoxels/s" and "936" in c["sample"]
     assert d["config"]["instances"] > 0   # the injected blob field went through stages 2-3
-    assert d["box"]["mfma_probe_tflops"] > 500 and d["box"]["band"] in ("slow", "typical", "fast") and d["box"]["hbm_copy_GBps"] > 500
+    assert d["box"]["mfma_probe_tflops"] > 500 and d["box"]["mfma_probe_varying_operands_tflops"] > 500
+    assert d["box"]["band"] in ("slow", "typical", "fast") and d["box"]["hbm_copy_GBps"] > 500
     if precision == "split":
         assert "also" not in d
         return
