@@ -1270,6 +1270,9 @@ __device__ __forceinline__ half8_t tr_read_at(const char* p0, const char* p1) {
 // Walking y: a wave takes columns (x, 16-voxel z block) and steps through y.  The three rows y-1, y, y+1 of its
 // input plane x + dx - 1 sit in a four-slot LDS ring, so a step fetches ONE new strip (row y+2, for the next step)
 // and one dy tile: 2.2 KiB per step against 10 for the whole-line kernel above.
+#ifndef SK_WG_ABL
+#define SK_WG_ABL 0   // experiments only (-DSK_WG_ABL=bits): 1 no tail DMA, 2 no dy DMA, 4 no main DMA, 8 one B read
+#endif
 __global__ void __launch_bounds__(64, 2) wgrad16y_kernel(Wgrad16Args a, const char* zero_page, int ncol_chunk) {
     constexpr int kSlot = 2048;                                   // strip slot: rows 0..15 | rows 16, 17 (own DMA tile)
     __shared__ __attribute__((aligned(16))) char ring[4 * kSlot];
@@ -1346,15 +1349,19 @@ __global__ void __launch_bounds__(64, 2) wgrad16y_kernel(Wgrad16Args a, const ch
             char* slot = ring + slot_idx * kSlot;
             const bool rowok = yr >= 0 && yr < Yf;
             const long long ro = (long long)(S.up ? yr >> 1 : yr) * rowstride;
-            dma16_tile((rowok && mok) ? colm + ro : zp, slot);
-            dma16_tile((rowok && tok) ? colt + ro : zp, slot + 1024);
+            if (!(SK_WG_ABL & 4)) dma16_tile((rowok && mok) ? colm + ro : zp, slot);
+            if (!(SK_WG_ABL & 1)) dma16_tile((rowok && tok) ? colt + ro : zp, slot + 1024);
         };
         auto step = [&](int y, auto Uc) {
             constexpr int U = decltype(Uc)::value;   // y & 3
             if (y + 1 < a.oy) {
                 load_row(y + 2, (U + 3) & 3);        // overwrites the slot of row y - 2: dead since step y - 1
-                dma16_tile(dycol + (long long)(y + 1) * dystride, dyt[(U + 1) & 1]);
-                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // everything but the three loads just issued
+                if (!(SK_WG_ABL & 2)) dma16_tile(dycol + (long long)(y + 1) * dystride, dyt[(U + 1) & 1]);
+                constexpr int kInFlight = 3 - ((SK_WG_ABL & 1) + ((SK_WG_ABL >> 1) & 1) + ((SK_WG_ABL >> 2) & 1));
+                if constexpr (kInFlight == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // everything but the three loads just issued
+                else if constexpr (kInFlight == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if constexpr (kInFlight == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1364,7 +1371,10 @@ __global__ void __launch_bounds__(64, 2) wgrad16y_kernel(Wgrad16Args a, const ch
             for (int dyi = 0; dyi < 3; ++dyi) {
                 const char* slot = ring + ((U + dyi) & 3) * kSlot;   // row y + dyi - 1
 #pragma unroll
-                for (int dz = 0; dz < 3; ++dz) bv[dyi * 3 + dz] = tr_read_at(slot + roff[dz][0], slot + roff[dz][1]);
+                for (int dz = 0; dz < 3; ++dz) {
+                    if ((SK_WG_ABL & 8) && dyi * 3 + dz > 0) bv[dyi * 3 + dz] = bv[0];
+                    else bv[dyi * 3 + dz] = tr_read_at(slot + roff[dz][0], slot + roff[dz][1]);
+                }
             }
             if (want_bias) {   // wave-uniform: only the (cin tile 0, dx 0) waves sum dy for the bias gradient
 #pragma unroll
@@ -1400,6 +1410,286 @@ __global__ void __launch_bounds__(64, 2) wgrad16y_kernel(Wgrad16Args a, const ch
     if (a.part_bias && cit == 0 && grp == 0) {
         bsum += __shfl_xor(bsum, 32);
         if (h == 0) a.part_bias[(long long)chunk * a.cout + 32 * cot + col] = bsum;
+    }
+}
+
+// Marching along x.  wgrad16y_kernel fetches every input plane three times (the dx = 0, 1, 2 waves of a chunk are
+// separate waves, each on its own plane) and has ONE step of LDS-DMA in flight per wave: 22 % MFMA busy, and taking
+// the DMA out (MFMAs and LDS reads kept) brings its 10.5 ms of the training step down to 3.1.  Here a workgroup of
+// four waves -- one per SIMD, all 27 tap accumulators of a 32 x 32 (cout, cin) tile pair in each -- owns a 16 x 16
+// (y, z) footprint and walks x.  The input planes x-1, x, x+1 of the footprint (18 rows: the y halo) sit in a four-slot
+// LDS ring and the dy planes in a three-slot ring, so every input plane and every dy plane is fetched ONCE (plus
+// halo), a whole x step -- 3456 MFMA cycles per SIMD -- before its first use; wave w takes output rows 4w .. 4w+3.
+// The z shift of a tap is taken on dy: with u = z + dz - 1
+//     dW[co][ci][dx, dy, dz] = sum dY[x, y, u - dz + 1][co] * X[x + dx - 1, y + dy - 1, u][ci]
+// a row step needs three x fragments per plane (rows y-1, y, y+1, unshifted) and three dy fragments (shifts +1, 0, -1):
+// 12 fragment reads for 27 MFMAs where the strip kernels make 30 (at full MFMA rate that alone is ~90 % of the LDS
+// bandwidth of a CU).  A source that is a nearest-upsampled half-resolution tensor is expanded by the DMA's own
+// per-lane addresses, so the LDS layout is the same for every source.
+constexpr int kWxPlane = 18 * 1024;        // input tile of one plane: rows y0-1 .. y0+16, 16 z, 64 B (32 cin) each
+constexpr int kWxDy = 16 * 18 * 64;        // dy tile of one plane: 16 rows, z0-1 .. z0+16, 64 B (32 cout) each
+constexpr int kWxLds = 4 * kWxPlane + 3 * kWxDy;
+typedef __attribute__((address_space(3))) char* lds_ptr;
+
+__device__ __forceinline__ fp16x4_t wx_read(lds_ptr p) {
+    return SK_DS_READ_TR16_B64((__attribute__((address_space(3))) fp16x4_t*)p);
+}
+__device__ __forceinline__ half8_t wx_join(fp16x4_t lo, fp16x4_t hi) {
+    half8_t r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = (t16)lo[j];
+        r[4 + j] = (t16)hi[j];
+    }
+    return r;
+}
+#define SK_WX_PIN() __builtin_amdgcn_sched_barrier(0)
+
+// The 27 accumulators of a wave are 432 registers: more than either register class holds, and the compiler's MFMA
+// selection keeps all accumulators in ONE class (it shuttled them through v_accvgpr moves and scratch: 2160 moves, 145
+// spilled registers in the loop).  So the MFMA is written out, the first kWxAgprTaps accumulators pinned to AGPRs
+// ("+a"), the rest to VGPRs ("+v"): 256 + 176, leaving 80 VGPRs for fragments and addresses.  What the compiler no
+// longer knows about these instructions: nothing reads an accumulator before the s_nop block ahead of the epilogue, and a
+// tap's MFMAs are nine instructions apart.
+constexpr int kWxAgprTaps = 16;
+#ifdef SK_BF16
+#define SK_WX_MFMA_ASM "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
+#else
+#define SK_WX_MFMA_ASM "v_mfma_f32_32x32x16_f16 %0, %1, %2, %0"
+#endif
+template <bool AGPR>
+__device__ __forceinline__ void wx_mfma(f32x16& c, half8_t a, half8_t b) {
+    if constexpr (AGPR)
+        asm volatile(SK_WX_MFMA_ASM : "+a"(c) : "v"(a), "v"(b));
+    else
+        asm volatile(SK_WX_MFMA_ASM : "+v"(c) : "v"(a), "v"(b));
+}
+
+__global__ void __launch_bounds__(256, 1) wgrad16x_kernel(Wgrad16Args a, int nfy, int nfz, int nxs, int xseg) {
+    extern __shared__ __attribute__((aligned(16))) char wx_lds[];
+    const lds_ptr L = (lds_ptr)wx_lds;
+    const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // the (cout tile, cin tile) workgroups of one chunk share its dy / input planes: same XCD, dispatched together
+    const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
+    const int per = a.ncot * a.ncit;
+    const int sub = bslot % per;
+    const int chunk = (bslot / per) * 8 + xcd;
+    if (chunk >= a.nchunk) return;
+    const int cit = sub % a.ncit, cot = sub / a.ncit;
+    int c = chunk;
+    const int xsi = c % nxs;
+    c /= nxs;
+    const int z0 = (c % nfz) * 16;
+    c /= nfz;
+    const int y0 = (c % nfy) * 16;
+    const int b = c / nfy;
+    const int xa = xsi * xseg, xb = min(xa + xseg, a.ox);
+    int ci0 = 32 * cit, sidx = 0, cbase = 0;
+    if (a.nsrc == 2 && ci0 >= a.src[0].C) {
+        sidx = 1;
+        cbase = a.src[0].C;
+    }
+    const Wg16Src S = a.src[sidx];
+    const int Xf = S.up ? S.Xs * 2 : S.Xs, Yf = S.up ? S.Ys * 2 : S.Ys;
+    const long long splane = (long long)S.Ys * S.Zs * S.C * 2, dyplane = (long long)a.oy * a.oz * a.cout * 2;
+    const char* sbase = reinterpret_cast<const char*>(S.data) + (long long)b * S.Xs * splane;
+    const char* dybase = reinterpret_cast<const char*>(a.dy) + (long long)b * a.ox * dyplane;
+
+    // LDS-DMA roles: an instruction moves 16 positions x 64 B; lane -> position lane >> 2, 16-byte piece lane & 3.
+    // Input tile: one instruction per row (wave w: rows w, w + 4, ...); dy tile: 288 positions = 18 instructions
+    // (wave w: instructions 3 - w, 7 - w, ...), nine instructions per wave and step.
+    const int pos = lane >> 2, c16 = (lane & 3) * 16;
+    unsigned xoff[5], doff[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int r = w + 4 * k, y = y0 - 1 + r;
+        const bool ok = r < 18 && y >= 0 && y < Yf;
+        const int ys = S.up ? y >> 1 : y, zs = S.up ? (z0 + pos) >> 1 : z0 + pos;
+        xoff[k] = ok ? (unsigned)((ys * S.Zs + zs) * S.C * 2 + (ci0 - cbase) * 2 + c16) : sk::kOob;
+        const int j = 3 - w + 4 * k, p = 16 * j + pos;
+        const int pr = p / 18, z = z0 - 1 + p % 18;
+        doff[k] = (j < 18 && z >= 0 && z < a.oz) ? (unsigned)(((y0 + pr) * a.oz + z) * a.cout * 2 + 64 * cot + c16) : sk::kOob;
+    }
+    auto issue_x = [&](int p, int sl) {   // input plane p (fine index; outside the volume: zeros) -> ring slot sl
+        const bool pv = p >= 0 && p < Xf;
+        const int ps = pv ? (S.up ? p >> 1 : p) : 0;
+        const __amdgpu_buffer_rsrc_t rs = sk::make_rsrc(sbase + (long long)ps * splane, (unsigned)splane);
+        const lds_ptr dst = L + sl * kWxPlane;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (w + 4 * k < 18)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + (w + 4 * k) * 1024), 16,
+                                                         pv ? xoff[k] : sk::kOob, 0, 0, 0);
+    };
+    auto issue_dy = [&](int x, int bi) {
+        const __amdgpu_buffer_rsrc_t rs = sk::make_rsrc(dybase + (long long)x * dyplane, (unsigned)dyplane);
+        const lds_ptr dst = L + 4 * kWxPlane + bi * kWxDy;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (3 - w + 4 * k < 18)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + (3 - w + 4 * k) * 1024), 16,
+                                                         doff[k], 0, 0, 0);
+    };
+
+    // transposed reads (tr_read_frag): this lane supplies the address of voxel row 8h + q (and + 4), columns 4p .. 4p+3
+    // of its 16-channel half
+    const int lane_off = (8 * h + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const lds_ptr Lx = L + lane_off + 4 * w * 1024;                       // + slot * kWxPlane + (row + dyi) * 1024
+    const lds_ptr Ld = L + 4 * kWxPlane + lane_off + 4 * w * 18 * 64;     // + buf * kWxDy + (row * 18 + 2 - dz) * 64
+
+    f32x16 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float bsum = 0.0f;
+    const bool want_bias = a.part_bias != nullptr && cit == 0;
+
+    // planes xa-1, xa, xa+1 -> slots 0, 1, 2; dy planes xa, xa+1 -> buffers 0, 1
+    issue_x(xa - 1, 0);
+    issue_x(xa, 1);
+    issue_x(xa + 1, 2);
+    issue_dy(xa, 0);
+    if (xa + 1 < xb) issue_dy(xa + 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    fp16x4_t Xl[3], Xh[3], Dl[2][3], Dh[2][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {   // fragments of the first group: rows 4w-1 .. 4w+1 of plane xa-1, dy row 4w
+        Xl[i] = wx_read(Lx + i * 1024);
+        Xh[i] = wx_read(Lx + i * 1024 + 256);
+        Dl[0][i] = wx_read(Ld + (2 - i) * 64);
+        Dh[0][i] = wx_read(Ld + (2 - i) * 64 + 256);
+    }
+
+    int t3 = 0;
+    for (int x = xa, t = 0; x < xb; ++x, ++t) {
+        // the loads issued one step ago (plane x+1, dy plane x+1) have landed in every wave, and every wave has
+        // issued the MFMAs that consumed its last fragments of plane x-2 and dy plane x-1: their slots can be refilled
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (x + 1 < xb) issue_x(x + 2, (t + 3) & 3);
+        if (x + 2 < xb) issue_dy(x + 2, t3 == 0 ? 2 : t3 - 1);
+        lds_ptr xs[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xs[i] = Lx + ((t + i) & 3) * kWxPlane;   // plane x + i - 1
+        const lds_ptr dcur = Ld + t3 * kWxDy, dnext = Ld + (t3 == 2 ? 0 : t3 + 1) * kWxDy;
+        // Twelve groups of nine MFMAs: (row rr, plane dx).  The reads between a group's MFMAs fetch the NEXT group's x
+        // fragments (into the registers the group has just finished with) and one dy fragment of the next row; the
+        // last group of a step fetches the first group of the next step (plane x: landed long ago, dy plane x+1:
+        // landed before this step's barrier).
+        auto group = [&](auto Gc) {
+            constexpr int g = decltype(Gc)::value;
+            constexpr int rr = g / 3, dx = g % 3, cur = rr & 1, nxt = cur ^ 1;
+            const lds_ptr xn = (g == 11) ? xs[1] : xs[(g + 1) % 3] + ((g + 1) / 3) * 1024;
+            const lds_ptr dn = (rr == 3) ? dnext + (2 - dx) * 64 : dcur + ((rr + 1) * 18 + 2 - dx) * 64;
+            if (dx == 0 && want_bias) {   // workgroup-uniform: the cin-tile-0 workgroups sum dy for the bias gradient
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bsum += (float)(t16)Dl[cur][1][j] + (float)(t16)Dh[cur][1][j];
+            }
+#define SK_WX_M(dyi, dz) \
+    wx_mfma<(dx * 9 + (dyi) * 3 + (dz) < kWxAgprTaps)>(acc[dx * 9 + (dyi) * 3 + (dz)], wx_join(Dl[cur][dz], Dh[cur][dz]), wx_join(Xl[dyi], Xh[dyi]))
+            SK_WX_PIN();
+            SK_WX_M(0, 0);
+            SK_WX_PIN();
+            Dl[nxt][dx] = wx_read(dn);
+            SK_WX_PIN();
+            SK_WX_M(0, 1);
+            SK_WX_PIN();
+            Dh[nxt][dx] = wx_read(dn + 256);
+            SK_WX_PIN();
+            SK_WX_M(0, 2);
+            SK_WX_PIN();
+            Xl[0] = wx_read(xn);
+            SK_WX_PIN();
+            SK_WX_M(1, 0);
+            SK_WX_PIN();
+            Xh[0] = wx_read(xn + 256);
+            SK_WX_PIN();
+            SK_WX_M(1, 1);
+            SK_WX_PIN();
+            SK_WX_M(1, 2);
+            SK_WX_PIN();
+            Xl[1] = wx_read(xn + 1024);
+            SK_WX_PIN();
+            SK_WX_M(2, 0);
+            SK_WX_PIN();
+            Xh[1] = wx_read(xn + 1024 + 256);
+            SK_WX_PIN();
+            SK_WX_M(2, 1);
+            SK_WX_PIN();
+            SK_WX_M(2, 2);
+            SK_WX_PIN();
+            Xl[2] = wx_read(xn + 2048);
+            Xh[2] = wx_read(xn + 2048 + 256);
+            SK_WX_PIN();
+#undef SK_WX_M
+        };
+        group(std::integral_constant<int, 0>{});
+        group(std::integral_constant<int, 1>{});
+        group(std::integral_constant<int, 2>{});
+        group(std::integral_constant<int, 3>{});
+        group(std::integral_constant<int, 4>{});
+        group(std::integral_constant<int, 5>{});
+        group(std::integral_constant<int, 6>{});
+        group(std::integral_constant<int, 7>{});
+        group(std::integral_constant<int, 8>{});
+        group(std::integral_constant<int, 9>{});
+        group(std::integral_constant<int, 10>{});
+        group(std::integral_constant<int, 11>{});
+        // after four rows the roles of the dy fragment sets are back where they started (row 0 of the next step is
+        // in set 0: it was fetched as "row 4")
+        t3 = t3 == 2 ? 0 : t3 + 1;
+    }
+
+    // One partial per workgroup: the four waves' accumulators are summed through LDS (fixed order), six taps a round
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (see wx_mfma)
+    __syncthreads();
+    sk::f32x4_t* red = reinterpret_cast<sk::f32x4_t*>(wx_lds);   // [tap of the round][wave][r / 4][lane]
+    float* part = a.part + (long long)chunk * a.cout * a.cin * 27;
+    const int cig = ci0 + col;
+#pragma unroll
+    for (int t0 = 0; t0 < 27; t0 += 6) {
+#pragma unroll
+        for (int tt = 0; tt < 6; ++tt) {
+            if (t0 + tt < 27) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    sk::f32x4_t v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = acc[t0 + tt][4 * r4 + k];
+                    red[((tt * 4 + w) * 4 + r4) * 64 + lane] = v;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < 6; ++tt) {
+            if (t0 + tt < 27) {
+                sk::f32x4_t s = red[((tt * 4 + 0) * 4 + w) * 64 + lane];
+#pragma unroll
+                for (int ws = 1; ws < 4; ++ws) {
+                    const sk::f32x4_t v = red[((tt * 4 + ws) * 4 + w) * 64 + lane];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s[k] += v[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {   // accumulator register r = 4w + k of the MFMA tile
+                    const int row = 32 * cot + k + 8 * w + 4 * h;
+                    part[((long long)(t0 + tt) * a.cout + row) * a.cin + cig] = s[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (want_bias) {
+        float* rb = reinterpret_cast<float*>(wx_lds);
+        bsum += __shfl_xor(bsum, 32);
+        if (h == 0) rb[w * 32 + col] = bsum;
+        __syncthreads();
+        if (w == 0 && h == 0) a.part_bias[(long long)chunk * a.cout + 32 * cot + col] = (rb[col] + rb[32 + col]) + (rb[64 + col] + rb[96 + col]);
     }
 }
 
@@ -1869,10 +2159,26 @@ static int wgrad_plan(int B, int ox, int oy, int oz, int cout, int cin, int ksiz
     return 0;
 }
 
+// wgrad16x_kernel: 16 x 16 (y, z) footprints x segments of x, about 1024 workgroups (four rounds of the 256 CUs) but
+// at least eight planes a segment (each segment fetches two planes it does not own).  Returns the chunk count, 0 if the
+// kernel does not cover the shape.
+static int wgrad_x_plan(int B, int ox, int oy, int oz, int cout, int cin, int ksize, int* nxs, int* xseg) {
+    if (ksize != 3 || oy % 16 || oz % 16 || cout % 32 || cin % 32) return 0;
+    const long long wg = (long long)B * (oy / 16) * (oz / 16) * (cout / 32) * (cin / 32);
+    long long s = (1024 + wg - 1) / wg;
+    if (s > ox / 8) s = ox / 8;
+    if (s < 1) s = 1;
+    *xseg = (int)((ox + s - 1) / s);
+    *nxs = (ox + *xseg - 1) / *xseg;
+    return B * (oy / 16) * (oz / 16) * *nxs;
+}
+
 int64_t sk_train_conv_wgrad_workspace_floats(int B, int ox, int oy, int oz, int cout, int cin, int ksize) {
-    int nchunk, nchunk_b, ngroup;
+    int nchunk, nchunk_b, ngroup, nxs, xseg;
     long long chunk;
     wgrad_plan(B, ox, oy, oz, cout, cin, ksize, &nchunk, &nchunk_b, &chunk, &ngroup);
+    const int nx = wgrad_x_plan(B, ox, oy, oz, cout, cin, ksize, &nxs, &xseg);
+    if (nx > nchunk) nchunk = nx;
     return (int64_t)nchunk * ((int64_t)cout * cin * ksize * ksize * ksize + cout);
 }
 
@@ -2026,7 +2332,18 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
 #ifdef SK_TUNING
     strips = getenv("SK_WGRAD_NOSTRIP") == nullptr;
 #endif
-    if (lines && ksize == 3 && oz % 16 == 0 && oy % 4 == 0 && strips) {
+    int nxs = 0, xseg = 0;
+    int nchunk_x = lines && strips ? wgrad_x_plan(B, ox, oy, oz, cout, a.cin, ksize, &nxs, &xseg) : 0;
+#ifdef SK_TUNING
+    if (getenv("SK_WGRAD_NOXMARCH")) nchunk_x = 0;
+#endif
+    if (nchunk_x > 0) {
+        a.nchunk = nchunk_x;
+        a.part_bias = dbias ? workspace + (long long)a.nchunk * nw : nullptr;
+        SK_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad16x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWxLds));
+        const unsigned gx = (unsigned)((((long long)a.nchunk + 7) / 8) * 8 * a.ncot * a.ncit);   // whole XCD rounds of chunks
+        wgrad16x_kernel<<<gx, 256, kWxLds, st>>>(a, oy / 16, oz / 16, nxs, xseg);
+    } else if (lines && ksize == 3 && oz % 16 == 0 && oy % 4 == 0 && strips) {
         a.ngroup = 3;
         const unsigned g3 = (unsigned)((((long long)a.nchunk + 7) / 8) * 8 * a.ncot * a.ncit * 3);   // whole XCD rounds of chunks
         const int ncol = ox * (oz / 16);

@@ -195,6 +195,10 @@ BWD_CASES = [
     (1, (4, 12, 32), [(32, 0), (32, 1)], 32, 3),   # ... with an upsampled half
     (1, (40, 8, 16), [(64, 0)], 64, 3),            # ... several chunks, 2 x 2 tiles
     (1, (6, 6, 16), [(32, 0)], 32, 3),             # y % 4 != 0: whole-line kernel
+    (2, (5, 16, 16), [(32, 0)], 32, 3),            # y % 16 == 0 and z % 16 == 0: the x-marching kernel, one footprint
+    (1, (12, 32, 16), [(32, 0), (32, 1)], 32, 3),  # ... two y footprints, an upsampled half
+    (1, (20, 16, 32), [(64, 0)], 64, 3),           # ... two z footprints, two x segments, 2 x 2 tiles
+    (1, (6, 16, 16), [(32, 0), (64, 1)], 64, 3),   # ... three cin tiles from two sources, two cout tiles
 ]
 
 
