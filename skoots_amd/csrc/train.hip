@@ -839,30 +839,46 @@ __global__ void __launch_bounds__(1024) gn_bwd_finalize16_kernel(const float* __
                                                                  const float* __restrict__ stats, float* __restrict__ coef,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                  float* __restrict__ scale) {
-    __shared__ double accv[1024];
+    __shared__ double accv[4096];
     __shared__ double sums[512];  // (C, 4)
     __shared__ double gm[2 * 16];
     __shared__ float bound[128];
     const int tid = threadIdx.x;
     const int nv = 4 * C;
-    const int val = tid % nv, sl = tid / nv, nsl = 1024 / nv;
-    const bool is_max = (val & 3) >= 2;
+    // a thread owns the four quantities (sum du, sum du*xh, max |du|, max |xh|) of one channel -- one 16-byte load per
+    // partial block -- in one of 1024 / C slices of the blocks, eight loads in flight, combined in a fixed order.  (One
+    // 4-byte load per thread and iteration kept this one-block kernel at 90 us a call, 1.3 ms of the training step:
+    // a single CU with 4 KiB in flight.)
+    const int ch = tid % C, sl = tid / C, nsl = 1024 / C;
     double dg = 0.0, db = 0.0;
     float bnd = 0.0f;
     for (int b = 0; b < B; ++b) {
-        double s = 0.0;
-        const float* base = partial + (long long)b * nblk * nv + val;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        const float4* base = reinterpret_cast<const float4*>(partial + (long long)b * nblk * nv) + ch;
         if (sl < nsl)
-            for (int k = sl; k < nblk; k += nsl) {
-                const double v = (double)base[(long long)k * nv];
-                s = is_max ? (v > s ? v : s) : s + v;
+            for (int k = sl; k < nblk; k += 8 * nsl) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = k + u * nsl < nblk ? base[(long long)(k + u * nsl) * C] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    s0 += (double)v[u].x;
+                    s1 += (double)v[u].y;
+                    s2 = (double)v[u].z > s2 ? (double)v[u].z : s2;
+                    s3 = (double)v[u].w > s3 ? (double)v[u].w : s3;
+                }
             }
-        accv[tid] = s;
+        accv[tid * 4 + 0] = s0;
+        accv[tid * 4 + 1] = s1;
+        accv[tid * 4 + 2] = s2;
+        accv[tid * 4 + 3] = s3;
         __syncthreads();
         if (tid < nv) {
+            const bool is_max = (tid & 3) >= 2;
             double t = 0.0;
             for (int k = 0; k < nsl; ++k) {
-                const double v = accv[k * nv + tid];
+                const double v = accv[(k * C + (tid >> 2)) * 4 + (tid & 3)];
                 t = is_max ? (v > t ? v : t) : t + v;
             }
             sums[tid] = t;
@@ -1116,6 +1132,97 @@ __device__ __forceinline__ half8_t tr_read_frag(const char* tile, int lane) {
         r[4 + j] = (t16)hi[j];
     }
     return r;
+}
+
+// Stem weight gradient (Cin = 1, cout = 32) on the 16-bit MFMA: K = 16 voxels of one z row per step where
+// wgrad_stem_kernel's fp32 MFMA takes 2 (1.59 ms of the training step for 0.22 ms of MFMA time: one 2-byte and one
+// 4-byte load per lane and MFMA).  The dy tile comes by LDS-DMA + transposed reads as in wgrad16t_kernel.  The B operand
+// -- column = tap, K = 8 consecutive z of the fp32 image shifted by the tap -- is two 16-byte loads of the aligned
+// eight values plus one edge value per lane, then split into a 16-bit value and the 16-bit rounding of its remainder
+// (two MFMAs a step): the image keeps 16 (bf16) / 22 (fp16) mantissa bits, so the result differs from the fp32-operand
+// kernel by summation order only.  Needs oz % 16 == 0 and whole 16-voxel chunks.
+__global__ void __launch_bounds__(64) wgrad_stem16_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) char dyt[2][1024];
+    const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
+    const int chunk = blockIdx.x;
+    const int b = chunk / a.nchunk_b, cb = chunk % a.nchunk_b;
+    const bool tapok = col < 27;
+    const int dx = col / 9 - 1, dy = (col / 3) % 3 - 1, dz = col % 3 - 1;  // this lane's tap (B column)
+    const long long nvox = (long long)a.ox * a.oy * a.oz;
+    const char* dyb = reinterpret_cast<const char*>(a.dy) + (long long)b * nvox * 64 + (lane >> 2) * 64 + (lane & 3) * 16;
+    const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(a.src[0].data + (long long)b * nvox, (unsigned)(nvox * 4));
+    const long long q0 = (long long)cb * a.chunk;
+    long long q1 = q0 + a.chunk;
+    if (q1 > nvox) q1 = nvox;
+    const int nsteps = q1 > q0 ? (int)((q1 - q0) / 16) : 0;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float bsum = 0.0f;
+    int z0 = (int)(q0 % a.oz);
+    long long t2 = q0 / a.oz;
+    int y = (int)(t2 % a.oy), x = (int)(t2 / a.oy);
+    long long q = q0;
+    sk::f32x4_t c0, c1;
+    float edge;
+    auto fetch = [&](int buf) {
+        dma16_tile(dyb + q * 64, dyt[buf]);
+        const int xi = x + dx, yi = y + dy, z = z0 + 8 * h;
+        const bool inb = tapok && xi >= 0 && xi < a.ox && yi >= 0 && yi < a.oy;
+        const unsigned row = (unsigned)((xi * a.oy + yi) * a.oz) * 4u;
+        c0 = sk::buf_load_f32x4(rsrc, inb ? row + (unsigned)z * 4u : sk::kOob);
+        c1 = sk::buf_load_f32x4(rsrc, inb ? row + (unsigned)z * 4u + 16u : sk::kOob);
+        const int ze = dz < 0 ? z - 1 : z + 8;   // the value the shifted window takes from outside the aligned eight
+        edge = sk::buf_load_f32(rsrc, (inb && dz != 0 && ze >= 0 && ze < a.oz) ? row + (unsigned)ze * 4u : sk::kOob);
+        q += 16;
+        z0 += 16;
+        if (z0 >= a.oz) {
+            z0 = 0;
+            if (++y >= a.oy) {
+                y = 0;
+                ++x;
+            }
+        }
+    };
+    if (nsteps > 0) fetch(0);
+    for (int s = 0; s < nsteps; ++s) {
+        const sk::f32x4_t p0 = c0, p1 = c1;
+        const float pe = edge;
+        if (s + 1 < nsteps) {
+            fetch((s + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything but the four loads just issued
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const half8_t av = tr_read_frag(dyt[s & 1], lane);
+        float al[8], f[8];   // the aligned eight; the window shifted by the lane's dz
+#pragma unroll
+        for (int j = 0; j < 8; ++j) al[j] = j < 4 ? p0[j & 3] : p1[j & 3];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = dz < 0 ? (j == 0 ? pe : al[(j + 7) & 7]) : (dz > 0 ? (j == 7 ? pe : al[(j + 1) & 7]) : al[j]);
+        half8_t bh, bl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bh[j] = (t16)f[j];
+            bl[j] = (t16)(f[j] - (float)bh[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum += (float)av[j];
+        acc = SK_MFMA_32x32x16_T16(av, bh, acc, 0, 0, 0);
+        acc = SK_MFMA_32x32x16_T16(av, bl, acc, 0, 0, 0);
+    }
+    float* part = a.part + (long long)chunk * a.cout * 27;
+    if (tapok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            part[(long long)row * 27 + col] = acc[r];
+        }
+    }
+    if (a.part_bias) {
+        bsum += __shfl_xor(bsum, 32);
+        if (h == 0) a.part_bias[(long long)chunk * a.cout + col] = bsum;
+    }
 }
 
 template <int NT>
@@ -2272,7 +2379,11 @@ int sk_train_stem_wgrad_f16(const float* image, const void* dy16, const float* d
     a.part = workspace;
     a.part_bias = dbias ? workspace + (long long)a.nchunk * nw : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    wgrad_stem_kernel<true><<<(unsigned)((long long)a.nchunk * a.ncot), 64, 0, st>>>(a);
+    if (Z % 16 == 0) {
+        a.chunk = (a.chunk + 15) & ~15LL;   // whole 16-voxel steps; the plan's chunk count still covers the volume
+        wgrad_stem16_kernel<<<(unsigned)a.nchunk, 64, 0, st>>>(a);
+    } else
+        wgrad_stem_kernel<true><<<(unsigned)((long long)a.nchunk * a.ncot), 64, 0, st>>>(a);
     SK_CHECK_LAUNCH();
     wgrad_reduce_kernel<<<sk::cdiv(nw, 64), 64 * kWredSlices, 0, st>>>(a.part, a.nchunk, nw, dweight, dy_scale, cout, 1, 0);
     SK_CHECK_LAUNCH();

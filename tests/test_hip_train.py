@@ -334,6 +334,35 @@ def test_conv_wgrad_f16(ffi, B, osp, srcdef, cout, ksize):
     _close(back, dyc, 1e-3, "cast round trip")
 
 
+@pytest.mark.parametrize("twin", [False, True])
+@pytest.mark.parametrize("B,osp", [(2, (5, 6, 16)), (1, (9, 4, 32)), (1, (40, 12, 16)), (2, (4, 5, 6))])
+def test_stem_wgrad_f16(ffi, B, osp, twin):
+    """sk_train_stem_wgrad_f16 (the training step's stem: fp32 image x scaled 16-bit dy) against torch autograd on the
+    same rounded dy.  Z % 16 == 0 takes the 16-bit-MFMA kernel (the image as a 16-bit value + remainder: still exact to
+    summation order), the last shape the fp32-MFMA one; both builds (fp16, bf16 twin)."""
+    gen = torch.Generator().manual_seed(osp[0] * 7 + osp[2])
+    dt = torch.bfloat16 if twin else torch.float16
+    sfx = "_bf16" if twin else ""
+    img = torch.randn((B, 1) + osp, generator=gen)
+    w = torch.zeros((32, 1, 3, 3, 3), requires_grad=True)
+    bias = torch.zeros(32, requires_grad=True)
+    y = F.conv3d(img, w, bias, padding=1)
+    dy = torch.randn(y.shape, generator=gen)
+    k = 3
+    scale = torch.tensor([2.0 ** k, 2.0 ** -k, 0.0], device=DEV)
+    dy16 = (_cl(dy) * 2.0 ** k).to(dt).to(DEV)
+    y.backward(_cf(dy16.cpu().float()) * 2.0 ** -k)
+    ox, oy, oz = osp
+    ws = torch.empty(int(ffi.lib.sk_train_conv_wgrad_workspace_floats(B, ox, oy, oz, 32, 1, 3)), device=DEV)
+    dw, dbias = torch.full(w.shape, 7.0, device=DEV), torch.full((32,), 7.0, device=DEV)
+    imgd = img[:, 0].contiguous().to(DEV)
+    st = ffi.stream_ptr(torch.device(DEV))
+    ffi.check(getattr(ffi.lib, "sk_train_stem_wgrad_f16" + sfx)(ffi.ptr(imgd), ffi.ptr(dy16), ffi.ptr(scale), B, ox, oy, oz,
+                                                               ffi.ptr(dw), ffi.ptr(dbias), ffi.ptr(ws), st))
+    _close(dw, w.grad, 1e-4, "stem dweight")
+    _close(dbias, bias.grad, 1e-4, "stem dbias")
+
+
 BF16_TWIN_CASES = [c for c in BWD_CASES if c[4] == 3 and c[2][0][0] % 32 == 0] + [BWD_CASES[4], BWD_CASES[5]]
 
 
