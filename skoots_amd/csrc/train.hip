@@ -1525,19 +1525,28 @@ __global__ void __launch_bounds__(64, 2) wgrad16y_kernel(Wgrad16Args a, const ch
 // the DMA out (MFMAs and LDS reads kept) brings its 10.5 ms of the training step down to 3.1.  Here a workgroup of
 // four waves -- one per SIMD, all 27 tap accumulators of a 32 x 32 (cout, cin) tile pair in each -- owns a 16 x 16
 // (y, z) footprint and walks x.  The input planes x-1, x, x+1 of the footprint (18 rows: the y halo) sit in a four-slot
-// LDS ring and the dy planes in a three-slot ring, so every input plane and every dy plane is fetched ONCE (plus
-// halo), a whole x step -- 3456 MFMA cycles per SIMD -- before its first use; wave w takes output rows 4w .. 4w+3.
+// LDS ring and the dy planes in another four-slot ring, so every input plane and every dy plane is fetched ONCE (plus
+// halo), 1.6 to 2 x steps -- a step is 3456 MFMA cycles per SIMD -- before its first use; wave w takes output rows
+// 4w .. 4w+3.
 // The z shift of a tap is taken on dy: with u = z + dz - 1
 //     dW[co][ci][dx, dy, dz] = sum dY[x, y, u - dz + 1][co] * X[x + dx - 1, y + dy - 1, u][ci]
 // a row step needs three x fragments per plane (rows y-1, y, y+1, unshifted) and three dy fragments (shifts +1, 0, -1):
-// 12 fragment reads for 27 MFMAs where the strip kernels make 30 (at full MFMA rate that alone is ~90 % of the LDS
-// bandwidth of a CU).  A source that is a nearest-upsampled half-resolution tensor is expanded by the DMA's own
+// 12 fragment reads for 27 MFMAs (15 in the group order used below, which fetches a row's dy fragments twice) where
+// the strip kernels make 30 (at full MFMA rate that alone is ~90 % of the LDS bandwidth of a CU).  A source that is a nearest-upsampled half-resolution tensor is expanded by the DMA's own
 // per-lane addresses, so the LDS layout is the same for every source.
 constexpr int kWxPlane = 18 * 1024;        // input tile of one plane: rows y0-1 .. y0+16, 16 z, 64 B (32 cin) each
 constexpr int kWxDy = 16 * 18 * 64;        // dy tile of one plane: 16 rows, z0-1 .. z0+16, 64 B (32 cout) each
-constexpr int kWxLds = 4 * kWxPlane + 3 * kWxDy;
+constexpr int kWxLds = 4 * kWxPlane + 4 * kWxDy;
+// the twelve (row, plane) groups of a step, and which of the two dy fragment register sets a group reads
+constexpr int kWxRow[12] = {0, 0, 1, 1, 2, 2, 3, 3, 0, 1, 2, 3};
+constexpr int kWxDx[12] = {0, 1, 0, 1, 0, 1, 0, 1, 2, 2, 2, 2};
+constexpr int kWxSet[12] = {0, 0, 1, 1, 0, 0, 1, 1, 0, 1, 0, 1};
 typedef __attribute__((address_space(3))) char* lds_ptr;
 
+#ifndef SK_WX_ABL
+#define SK_WX_ABL 0   // timing experiments (-DSK_WX_ABL=bits, results wrong): 1 no LDS-DMA inside the march, 2 no fragment
+                      // reads inside the march, 4 the DMA's loads go to (discarded) registers instead of LDS
+#endif
 __device__ __forceinline__ fp16x4_t wx_read(lds_ptr p) {
     return SK_DS_READ_TR16_B64((__attribute__((address_space(3))) fp16x4_t*)p);
 }
@@ -1551,6 +1560,7 @@ __device__ __forceinline__ half8_t wx_join(fp16x4_t lo, fp16x4_t hi) {
     return r;
 }
 #define SK_WX_PIN() __builtin_amdgcn_sched_barrier(0)
+#define SK_WX_RD(p) ((SK_WX_ABL & 2) ? Xl[0] : wx_read(p))
 
 // The 27 accumulators of a wave are 432 registers: more than either register class holds, and the compiler's MFMA
 // selection keeps all accumulators in ONE class (it shuttled them through v_accvgpr moves and scratch: 2160 moves, 145
@@ -1625,18 +1635,28 @@ __global__ void __launch_bounds__(256, 1) wgrad16x_kernel(Wgrad16Args a, int nfy
         const lds_ptr dst = L + sl * kWxPlane;
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-            if (w + 4 * k < 18)
+            if (w + 4 * k < 18) {
+                if (SK_WX_ABL & 4) {   // timing experiment: the same bytes into (discarded) registers instead of LDS
+                    sk::f32x4_t junk;
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(junk) : "v"(pv ? xoff[k] : sk::kOob), "s"(rs) : "memory");
+                } else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + (w + 4 * k) * 1024), 16,
                                                          pv ? xoff[k] : sk::kOob, 0, 0, 0);
+            }
     };
     auto issue_dy = [&](int x, int bi) {
         const __amdgpu_buffer_rsrc_t rs = sk::make_rsrc(dybase + (long long)x * dyplane, (unsigned)dyplane);
         const lds_ptr dst = L + 4 * kWxPlane + bi * kWxDy;
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-            if (3 - w + 4 * k < 18)
+            if (3 - w + 4 * k < 18) {
+                if (SK_WX_ABL & 4) {
+                    sk::f32x4_t junk;
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(junk) : "v"(doff[k]), "s"(rs) : "memory");
+                } else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + (3 - w + 4 * k) * 1024), 16,
                                                          doff[k], 0, 0, 0);
+            }
     };
 
     // transposed reads (tr_read_frag): this lane supplies the address of voxel row 8h + q (and + 4), columns 4p .. 4p+3
@@ -1671,68 +1691,100 @@ __global__ void __launch_bounds__(256, 1) wgrad16x_kernel(Wgrad16Args a, int nfy
         Dh[0][i] = wx_read(Ld + (2 - i) * 64 + 256);
     }
 
-    int t3 = 0;
+    // A step = twelve groups of nine MFMAs, (row, plane) in the order of kWxRow / kWxDx: planes x-1 and x for the four
+    // rows first, plane x+1 -- the newest -- for the four rows last.  The ONE barrier of a step sits before group 7,
+    // whose reads are the first to touch plane x+1: that plane was requested at the start of step x-1, 1.6 steps
+    // (~2.3 us at full MFMA rate) earlier, the dy plane two steps earlier.  (With the barrier at the start of the step
+    // and one step of lead the layers that miss L2 ran at the loaded HBM latency: 32 -> 32 at 256^3 1170 TFLOP/s, the
+    // 64- and 128-channel layers 950, against 1880 for the 96 -> 32 layer, whose tiles mostly hit.)
+    // The reads between a group's MFMAs fetch the NEXT group's x fragments (into the registers the group has just
+    // finished with) and the dy fragments of the next row (other register set).
+    // What is left on the table (tools/bench_wgrad.py, enc0.1 at 256^3, ms per call incl. the partial reduction): 1.00 as
+    // is; 0.67 without the LDS-DMA; 0.79 without the fragment reads; 0.62 without both; 0.70 with the same bytes loaded
+    // into registers instead of LDS -- so it is neither HBM / L2 nor the LDS reads but the LDS-DMA instruction itself:
+    // with ONE wave per SIMD nothing covers the ~180-340 cycles a wave stands at each of its nine buffer_load ... lds
+    // per step (spreading them over the groups made it 1.60: each then also waits out the fragment reads in flight).
+    // The way out is loads into registers + ds_write_b128, which needs ~36 more VGPRs than the 27 accumulators leave.
     for (int x = xa, t = 0; x < xb; ++x, ++t) {
-        // the loads issued one step ago (plane x+1, dy plane x+1) have landed in every wave, and every wave has
-        // issued the MFMAs that consumed its last fragments of plane x-2 and dy plane x-1: their slots can be refilled
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (x + 1 < xb) issue_x(x + 2, (t + 3) & 3);
-        if (x + 2 < xb) issue_dy(x + 2, t3 == 0 ? 2 : t3 - 1);
+        // slot of plane x-2 (last read before the barrier of step x-1) and buffer of dy plane x-2
+        const bool more_x = x + 1 < xb, more_dy = x + 2 < xb;
+        if (more_x && !(SK_WX_ABL & 1)) issue_x(x + 2, (t + 3) & 3);
+        if (more_dy && !(SK_WX_ABL & 1)) issue_dy(x + 2, (t + 2) & 3);
         lds_ptr xs[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) xs[i] = Lx + ((t + i) & 3) * kWxPlane;   // plane x + i - 1
-        const lds_ptr dcur = Ld + t3 * kWxDy, dnext = Ld + (t3 == 2 ? 0 : t3 + 1) * kWxDy;
-        // Twelve groups of nine MFMAs: (row rr, plane dx).  The reads between a group's MFMAs fetch the NEXT group's x
-        // fragments (into the registers the group has just finished with) and one dy fragment of the next row; the
-        // last group of a step fetches the first group of the next step (plane x: landed long ago, dy plane x+1:
-        // landed before this step's barrier).
+        const lds_ptr dcur = Ld + (t & 3) * kWxDy, dnext = Ld + ((t + 1) & 3) * kWxDy;
         auto group = [&](auto Gc) {
             constexpr int g = decltype(Gc)::value;
-            constexpr int rr = g / 3, dx = g % 3, cur = rr & 1, nxt = cur ^ 1;
-            const lds_ptr xn = (g == 11) ? xs[1] : xs[(g + 1) % 3] + ((g + 1) / 3) * 1024;
-            const lds_ptr dn = (rr == 3) ? dnext + (2 - dx) * 64 : dcur + ((rr + 1) * 18 + 2 - dx) * 64;
+            constexpr int dx = kWxDx[g], cur = kWxSet[g], nxt = cur ^ 1;
+            constexpr int gn = (g + 1) % 12;
+            // next group's x fragments: plane slot of its dx (the next step's plane x-1 is this step's plane x)
+            const lds_ptr xn = (g == 11 ? xs[1] : xs[kWxDx[gn]]) + kWxRow[gn] * 1024;
+            // dy fragments of the next row: groups 0 .. 7 fetch half a set each (the row changes every other group),
+            // groups 8 .. 11 a whole set
+            constexpr int nrow = g < 8 ? (g / 2 + 1) % 4 : (g == 11 ? 0 : g - 7);
+            const lds_ptr dn = (g == 11 ? dnext : dcur) + nrow * 18 * 64;
+            constexpr int d0 = g < 8 ? 3 * (g & 1) : 0, nd = g < 8 ? 3 : 6;   // reads d0 .. d0 + nd - 1 of the set
+            auto dread = [&](auto Ic) {
+                constexpr int i = decltype(Ic)::value;   // read i of the set: dz = i / 2, half i % 2
+                if constexpr (i >= d0 && i < d0 + nd) {
+                    if constexpr (i % 2 == 0)
+                        Dl[nxt][i / 2] = SK_WX_RD(dn + (2 - i / 2) * 64);
+                    else
+                        Dh[nxt][i / 2] = SK_WX_RD(dn + (2 - i / 2) * 64 + 256);
+                }
+            };
             if (dx == 0 && want_bias) {   // workgroup-uniform: the cin-tile-0 workgroups sum dy for the bias gradient
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bsum += (float)(t16)Dl[cur][1][j] + (float)(t16)Dh[cur][1][j];
             }
 #define SK_WX_M(dyi, dz) \
     wx_mfma<(dx * 9 + (dyi) * 3 + (dz) < kWxAgprTaps)>(acc[dx * 9 + (dyi) * 3 + (dz)], wx_join(Dl[cur][dz], Dh[cur][dz]), wx_join(Xl[dyi], Xh[dyi]))
+#define SK_WX_D(i) dread(std::integral_constant<int, d0 + (i)>{})
             SK_WX_PIN();
             SK_WX_M(0, 0);
             SK_WX_PIN();
-            Dl[nxt][dx] = wx_read(dn);
+            SK_WX_D(0);
             SK_WX_PIN();
             SK_WX_M(0, 1);
             SK_WX_PIN();
-            Dh[nxt][dx] = wx_read(dn + 256);
+            SK_WX_D(1);
             SK_WX_PIN();
             SK_WX_M(0, 2);
             SK_WX_PIN();
-            Xl[0] = wx_read(xn);
+            Xl[0] = SK_WX_RD(xn);
             SK_WX_PIN();
             SK_WX_M(1, 0);
             SK_WX_PIN();
-            Xh[0] = wx_read(xn + 256);
+            Xh[0] = SK_WX_RD(xn + 256);
             SK_WX_PIN();
             SK_WX_M(1, 1);
             SK_WX_PIN();
+            SK_WX_D(2);
+            if constexpr (nd == 6) SK_WX_D(3);
+            SK_WX_PIN();
             SK_WX_M(1, 2);
             SK_WX_PIN();
-            Xl[1] = wx_read(xn + 1024);
+            Xl[1] = SK_WX_RD(xn + 1024);
             SK_WX_PIN();
             SK_WX_M(2, 0);
             SK_WX_PIN();
-            Xh[1] = wx_read(xn + 1024 + 256);
+            Xh[1] = SK_WX_RD(xn + 1024 + 256);
             SK_WX_PIN();
             SK_WX_M(2, 1);
             SK_WX_PIN();
+            if constexpr (nd == 6) {
+                SK_WX_D(4);
+                SK_WX_D(5);
+                SK_WX_PIN();
+            }
             SK_WX_M(2, 2);
             SK_WX_PIN();
-            Xl[2] = wx_read(xn + 2048);
-            Xh[2] = wx_read(xn + 2048 + 256);
+            Xl[2] = SK_WX_RD(xn + 2048);
+            Xh[2] = SK_WX_RD(xn + 2048 + 256);
             SK_WX_PIN();
 #undef SK_WX_M
+#undef SK_WX_D
         };
         group(std::integral_constant<int, 0>{});
         group(std::integral_constant<int, 1>{});
@@ -1741,14 +1793,17 @@ __global__ void __launch_bounds__(256, 1) wgrad16x_kernel(Wgrad16Args a, int nfy
         group(std::integral_constant<int, 4>{});
         group(std::integral_constant<int, 5>{});
         group(std::integral_constant<int, 6>{});
+        // everything but this step's own requests has landed (the last steps request less: wait for all)
+        if (more_x && more_dy && !(SK_WX_ABL & 1))
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         group(std::integral_constant<int, 7>{});
         group(std::integral_constant<int, 8>{});
         group(std::integral_constant<int, 9>{});
         group(std::integral_constant<int, 10>{});
         group(std::integral_constant<int, 11>{});
-        // after four rows the roles of the dy fragment sets are back where they started (row 0 of the next step is
-        // in set 0: it was fetched as "row 4")
-        t3 = t3 == 2 ? 0 : t3 + 1;
     }
 
     // One partial per workgroup: the four waves' accumulators are summed through LDS (fixed order), six taps a round
