@@ -1703,7 +1703,8 @@ __global__ void __launch_bounds__(256, 1) wgrad16x_kernel(Wgrad16Args a, int nfy
     // is; 0.67 without the LDS-DMA; 0.79 without the fragment reads; 0.62 without both; 0.70 with the same bytes loaded
     // into registers instead of LDS -- so it is neither HBM / L2 nor the LDS reads but the LDS-DMA instruction itself:
     // with ONE wave per SIMD nothing covers the ~180-340 cycles a wave stands at each of its nine buffer_load ... lds
-    // per step (spreading them over the groups made it 1.60: each then also waits out the fragment reads in flight).
+    // per step (spreading them over the groups made it 1.60: each then also waits out the fragment reads in flight;
+    // issuing them right after the barrier instead of at the top of the step: 0.99).
     // The way out is loads into registers + ds_write_b128, which needs ~36 more VGPRs than the 27 accumulators leave.
     for (int x = xa, t = 0; x < xb; ++x, ++t) {
         // slot of plane x-2 (last read before the barrier of step x-1) and buffer of dy plane x-2
