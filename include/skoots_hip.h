@@ -473,6 +473,19 @@ int sk_train_stem_wgrad_f16(const float* image, const void* dy16, const float* d
  * tensor, add16 (B, 2cx, 2cy, 2cz, C) * add_scale[1] -- the two contributions to a skip tensor in one pass. */
 int sk_train_interleave2_add16(const void* t16, const void* add16, const float* add_scale, float* dx, int B, int cx,
                                int cy, int cz, int C, const float* scale, void* stream);
+/* 16-bit hand-off of a gradient to the GroupNorm backward that consumes it (sk_train_gn_silu_bwd_f16h): the producer
+ * writes the scaled 16-bit tensor AND its scale vector out_scale (3 floats, device) = [s, 1/s, bound], s a power of two
+ * derived from the input scales so that the result cannot overflow (no max pass, no fp32 tensor).
+ * sk_train_interleave2_h: sk_train_interleave2 / _add16 (add16 may be NULL) with a 16-bit result dx16 (B, 2cx, 2cy, 2cz, C).
+ * sk_train_sumpool2_hh: sk_train_sumpool2_f16 with a 16-bit result coarse16 (B, cx, cy, cz, C), s = scale[0] / 8.
+ * sk_train_heads_dgrad_f16: data gradient of the heads, dx[v][c] = sum_k dlogits[v][k] W[k][c] (W (5, C) fp32), from the
+ *   fp32 dlogits (nvox, 5) and dl_scale = sk_train_absmax_scale(dlogits).  C % 8 == 0. */
+int sk_train_interleave2_h(const void* t16, const void* add16, const float* add_scale, void* dx16, float* out_scale, int B,
+                           int cx, int cy, int cz, int C, const float* scale, void* stream);
+int sk_train_sumpool2_hh(const void* fine16, const float* scale, void* coarse16, float* out_scale, int B, int cx, int cy, int cz,
+                         int C, void* stream);
+int sk_train_heads_dgrad_f16(const float* dlogits, const float* dl_scale, const float* weight, void* dx16, float* out_scale,
+                             int64_t nvox, int C, void* stream);
 int sk_train_heads_fwd_f16(const void* z16, const float* weight, const float* bias, float* logits, int64_t nvox,
                            void* stream);
 int64_t sk_train_heads_wgrad_workspace_floats(int64_t nvox);

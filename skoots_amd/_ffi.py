@@ -120,6 +120,9 @@ _SIGS = {
     "sk_train_gn_silu_bwd_f16h": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, vp, vp, vp]),
     "sk_train_sumpool2_f16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "sk_train_interleave2_add16": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "sk_train_interleave2_h": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "sk_train_sumpool2_hh": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "sk_train_heads_dgrad_f16": (i32, [vp, vp, vp, vp, vp, i64, i32, vp]),
     "sk_train_heads_fwd_f16": (i32, [vp, vp, vp, vp, i64, vp]),
     "sk_train_heads_wgrad_workspace_floats": (i64, [i64]),
     "sk_train_heads_wgrad_f16": (i32, [vp, vp, vp, vp, i64, vp, vp]),
@@ -144,7 +147,8 @@ BF16_TWINS = (
     "sk_train_conv_wgrad_workspace_floats", "sk_train_gn_bwd_f16_workspace_floats", "sk_train_gn_bwd_num_blocks",
     "sk_train_gn_bwd_workspace_floats", "sk_train_gn_silu", "sk_train_gn_silu_bwd", "sk_train_gn_silu_bwd_f16",
     "sk_train_gn_silu_bwd_f16h", "sk_train_gn_silu_f16", "sk_train_heads_fwd_f16", "sk_train_heads_wgrad_f16",
-    "sk_train_heads_wgrad_workspace_floats", "sk_train_interleave2", "sk_train_interleave2_add16", "sk_train_loss",
+    "sk_train_heads_wgrad_workspace_floats", "sk_train_interleave2", "sk_train_interleave2_add16", "sk_train_interleave2_h",
+    "sk_train_sumpool2_hh", "sk_train_heads_dgrad_f16", "sk_train_loss",
     "sk_train_loss_num_blocks", "sk_train_loss_workspace_floats", "sk_train_pack_weight", "sk_train_stem_fwd_f16",
     "sk_train_stem_wgrad_f16", "sk_train_sumpool2", "sk_train_sumpool2_f16", "sk_train_tversky",
 )

@@ -2208,8 +2208,10 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
     int nxc = (target + p.npatch * kPlanBatch - 1) / (p.npatch * kPlanBatch);
     // COUT 32 on linear patches (the full-resolution layers of the production tile): half as many, twice as long chunks.
     // conv3_px_kernel pays a fixed price per workgroup (weights into registers / LDS, four planes staged, the planes at
-    // the chunk ends): x-chunks of 76 instead of 36 planes measured -2 % (enc0.1) / -4 % (dec0.1) per 64 tiles
-    if (cout == 32 && p.mode == 0) nxc = (nxc + 1) / 2;
+    // the chunk ends): x-chunks of 76 instead of 36 planes measured -2 % (enc0.1) / -4 % (dec0.1) per 64 tiles, and two
+    // chunks of 150 against five of 60 another -0.5 % / -1.5 % (one of 300: -1 % / -2.7 %, but a batch of 8 or 16 tiles
+    // then leaves CUs idle: 376 / 752 workgroups for 512 slots)
+    if (cout == 32 && p.mode == 0) nxc = nxc >= 4 ? 2 : (nxc + 1) / 2;
     int max_nxc = (Xt + 2 * p.xs - 1) / (2 * p.xs);  // at least two steps per chunk
     if (nxc > max_nxc) nxc = max_nxc;
     if (nxc < 1) nxc = 1;

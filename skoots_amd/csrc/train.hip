@@ -1972,6 +1972,138 @@ __global__ void __launch_bounds__(256) interleave2_kernel(const t16* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 16-bit hand-off of the gradients that used to leave their producer as fp32 (the skip tensors' stride-2 interleave, the
+// 2x2x2 sum pooling under an upsampled source, the heads' data gradient): the consumer is a GroupNorm backward that
+// reads a scaled 16-bit dz as it is (gn_bwd_*16_kernel<true>), so the fp32 tensor cost 4 B/element written once and
+// read twice.  The output scale is a power of two derived from the INPUT scales, so that the result cannot overflow:
+// out_scale (3 floats, written by the kernel) = [s, 1/s, bound].
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) interleave2_h_kernel(const t16* __restrict__ tens16, t16* __restrict__ out16, int B, int cx,
+                                                            int cy, int cz, int C, const float* __restrict__ scale,
+                                                            const t16* __restrict__ add16, const float* __restrict__ add_scale,
+                                                            float* __restrict__ out_scale) {
+    // dx * s_out = T16 * (s_out / s_T) + add16 * (s_out / s_add): with s_out = min(s_T, s_add) / 2 both factors are <= 1/2,
+    // the sum stays below the larger 16-bit operand's range; without a second operand the parity tensor passes through
+    const float sT = scale[0];
+    const float s_out = add16 ? fminf(sT, add_scale[0]) * 0.5f : sT;
+    const float fa = s_out * scale[1], fb = add16 ? s_out * add_scale[1] : 0.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out_scale[0] = s_out;
+        out_scale[1] = 1.0f / s_out;
+        out_scale[2] = scale[2] + (add16 ? add_scale[2] : 0.0f);
+    }
+    const int nq = C / 8;
+    const long long ncoarse = (long long)B * cx * cy * cz * C;
+    const long long n = (long long)B * cx * cy * cz * 8 * nq;   // fine voxels x channel octets
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int q = (int)(i % nq);
+        long long t = i / nq;
+        const int z = (int)(t % (2 * cz));
+        t /= 2 * cz;
+        const int y = (int)(t % (2 * cy));
+        t /= 2 * cy;
+        const int x = (int)(t % (2 * cx));
+        const int b = (int)(t / (2 * cx));
+        const int p = ((x & 1) << 2) | ((y & 1) << 1) | (z & 1);
+        const long long ci = ((((long long)b * cx + (x >> 1)) * cy + (y >> 1)) * cz + (z >> 1)) * C + 8 * q;
+        const half8_t h = *reinterpret_cast<const half8_t*>(tens16 + (long long)p * ncoarse + ci);
+        half8_t o;
+        if (add16) {
+            const half8_t g = *reinterpret_cast<const half8_t*>(add16 + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (t16)fmaf((float)g[j], fb, (float)h[j] * fa);
+        } else {
+            o = h;
+        }
+        *reinterpret_cast<half8_t*>(out16 + i * 8) = o;
+    }
+}
+
+// coarse * (s / 8) = (sum of the 8 children, each scaled by s) / 8
+__global__ void __launch_bounds__(256) sumpool2_hh_kernel(const t16* __restrict__ fine, const float* __restrict__ scale,
+                                                          t16* __restrict__ coarse, float* __restrict__ out_scale, int B, int cx,
+                                                          int cy, int cz, int C) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out_scale[0] = scale[0] * 0.125f;
+        out_scale[1] = scale[1] * 8.0f;
+        out_scale[2] = scale[2] * 8.0f;
+    }
+    const int nq = C / 8;
+    const long long n = (long long)B * cx * cy * cz * nq;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int q = (int)(i % nq);
+        long long t = i / nq;
+        const int z = (int)(t % cz);
+        t /= cz;
+        const int y = (int)(t % cy);
+        t /= cy;
+        const int x = (int)(t % cx);
+        const int b = (int)(t / cx);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const long long fi = (((long long)b * 2 * cx + 2 * x + (d >> 2)) * 2 * cy + 2 * y + ((d >> 1) & 1)) * 2 * cz +
+                                 2 * z + (d & 1);
+            const half8_t h = *reinterpret_cast<const half8_t*>(fine + fi * C + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)h[j];
+        }
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (t16)(acc[j] * 0.125f);
+        *reinterpret_cast<half8_t*>(coarse + i * 8) = o;
+    }
+}
+
+// Data gradient of the heads (K = 5 logits -> C features) as a scaled 16-bit tensor: dx[v][c] = sum_k dl[v][k] W[k][c].
+// dl_scale = sk_train_absmax_scale(dl): max |dl| * dl_scale[0] in [2^12, 2^13); with 2^e >= max_c sum_k |W[k][c]| the scale
+// s = dl_scale[0] * 2^-e keeps |dx| * s below 2^13.  8 channels per lane (one 16-byte store), the voxel's lanes share dl.
+template <int K>
+__global__ void __launch_bounds__(256) heads_dgrad_h_kernel(const float* __restrict__ dl, const float* __restrict__ w,
+                                                            t16* __restrict__ dx16, float* __restrict__ out_scale,
+                                                            const float* __restrict__ dl_scale, long long nvox, int C) {
+    float wmax = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        float sc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) sc += fabsf(w[k * C + c]);
+        wmax = fmaxf(wmax, sc);
+    }
+    int e = 0;
+    if (wmax > 0.0f && isfinite(wmax)) frexpf(wmax, &e);   // wmax < 2^e
+    e = e > 60 ? 60 : (e < -60 ? -60 : e);
+    const float s = dl_scale[0] * ldexpf(1.0f, -e);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out_scale[0] = s;
+        out_scale[1] = 1.0f / s;
+        out_scale[2] = ldexpf(1.0f, 13) / s;
+    }
+    const int nq = C / 8;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int q = (int)(i % nq);   // fixed per lane: 256 and the grid stride are multiples of nq
+    float wk[K][8];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wk[k][j] = w[k * C + 8 * q + j] * s;
+    for (; i < nvox * nq; i += (long long)gridDim.x * 256) {
+        const long long v = i / nq;
+        float g[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) g[k] = dl[v * K + k];
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float r = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) r = fmaf(g[k], wk[k][j], r);
+            o[j] = (t16)r;
+        }
+        *reinterpret_cast<half8_t*>(dx16 + v * C + 8 * q) = o;
+    }
+}
+
 // out = sum over chunks of part[c] (fixed order -> deterministic): 64 elements per block, four chunk slices.
 // k3 > 0: the partials are tap-major (tap, cout, cin) -- written with the lanes (cin) contiguous -- and the result
 // goes to the torch layout (cout, cin, k3); k3 == 0: same layout in and out.
@@ -2597,6 +2729,38 @@ int sk_train_interleave2_add16(const void* tens16, const void* add16, const floa
                                int cz, int C, const float* scale, void* stream) {
     SK_CHECK_ARG(add16, "sk_train_interleave2_add16: add16 is NULL");
     return interleave2_impl(tens16, add16, add_scale, dx, B, cx, cy, cz, C, scale, 0, stream);
+}
+
+int sk_train_interleave2_h(const void* tens16, const void* add16, const float* add_scale, void* dx16, float* out_scale, int B,
+                           int cx, int cy, int cz, int C, const float* scale, void* stream) {
+    SK_CHECK_ARG(tens16 && dx16 && out_scale && scale && (!add16 || add_scale), "sk_train_interleave2_h: NULL pointer");
+    SK_CHECK_ARG(B >= 1 && cx >= 1 && cy >= 1 && cz >= 1 && C >= 8 && C % 8 == 0, "sk_train_interleave2_h: bad extents (C %% 8 == 0)");
+    const long long n = (long long)B * cx * cy * cz * 8 * (C / 8);
+    interleave2_h_kernel<<<sk::stream_grid(n, 256, 4), 256, 0, (hipStream_t)stream>>>((const t16*)tens16, (t16*)dx16, B, cx, cy, cz, C,
+                                                                                    scale, (const t16*)add16, add_scale, out_scale);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_train_sumpool2_hh(const void* fine16, const float* scale, void* coarse16, float* out_scale, int B, int cx, int cy, int cz,
+                         int C, void* stream) {
+    SK_CHECK_ARG(fine16 && scale && coarse16 && out_scale, "sk_train_sumpool2_hh: NULL pointer");
+    SK_CHECK_ARG(B >= 1 && cx >= 1 && cy >= 1 && cz >= 1 && C >= 8 && C % 8 == 0, "sk_train_sumpool2_hh: bad extents (C %% 8 == 0)");
+    const long long n = (long long)B * cx * cy * cz * (C / 8);
+    sumpool2_hh_kernel<<<sk::stream_grid(n, 256, 2), 256, 0, (hipStream_t)stream>>>((const t16*)fine16, scale, (t16*)coarse16,
+                                                                                  out_scale, B, cx, cy, cz, C);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_train_heads_dgrad_f16(const float* dlogits, const float* dl_scale, const float* weight, void* dx16, float* out_scale,
+                             int64_t nvox, int C, void* stream) {
+    SK_CHECK_ARG(dlogits && dl_scale && weight && dx16 && out_scale && nvox >= 1, "sk_train_heads_dgrad_f16: bad arguments");
+    SK_CHECK_ARG(C >= 8 && C % 8 == 0 && 256 % (C / 8) == 0 && C <= 256, "sk_train_heads_dgrad_f16: C=%d unsupported", C);
+    heads_dgrad_h_kernel<5><<<sk::stream_grid(nvox * (C / 8), 256, 4), 256, 0, (hipStream_t)stream>>>(
+        dlogits, weight, (t16*)dx16, out_scale, dl_scale, (long long)nvox, C);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
 }
 
 int sk_train_gn_silu_f16(const void* y16, const float* affine, void* z16, float* z32, int B, int64_t voxels, int C,

@@ -389,8 +389,9 @@ class TrainUNet:
             ws = None
             dz_scale = None
             if isinstance(dz, tuple):
-                dz, dz_scale = dz
-                assert fast and n_readers.get(out.data_ptr(), 0) == 1, "a pending fp16 gradient was never summed"
+                final = len(dz) == 3   # (tensor, scale, True): complete, whatever the number of readers (see below)
+                dz, dz_scale = dz[0], dz[1]
+                assert fast and (final or n_readers.get(out.data_ptr(), 0) == 1), "a pending fp16 gradient was never summed"
             if fast:
                 # GroupNorm + SiLU backward straight to the scaled fp16 output gradient (no fp32 dy, no max / cast passes)
                 ws = self._workspace(max(self._L.sk_train_gn_bwd_f16_workspace_floats(B, vox, cout),
@@ -463,7 +464,11 @@ class TrainUNet:
                     pend = grads.get(key)
                     pend = pend if isinstance(pend, tuple) else None   # the decoder's fp16 contribution, not yet summed
                     have = key in grads and pend is None
-                    if not have:
+                    # this conv is the tensor's last reader to report (the decoder's contribution, if any, is `pend`): the
+                    # sum leaves as a scaled 16-bit tensor + its scale for the producer's GroupNorm backward, no fp32 copy
+                    h_out = (self.f16_grad_handoff and not have and key in fast_out and
+                             n_readers.get(key, 0) == (2 if pend is not None else 1))
+                    if not have and not h_out:
                         grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
                     packed = self._pack(layer, 2, 0, c)
                     per = packed.numel() // 8
@@ -472,7 +477,15 @@ class TrainUNet:
                         _ffi.check(self._L.sk_conv3d(self._srcs([(dy16, 0)]), 1, _ffi.ptr(packed[par * per:(par + 1) * per]),
                                                       _ffi.ptr(self._zero_bias), _ffi.ptr(t16[par]), B, ox, oy, oz, c, 1, None,
                                                       _ffi.ptr(self._zero_page), st))
-                    if pend is not None:
+                    if h_out:
+                        dx16 = torch.empty(t.shape, dtype=self.t16, device=self.device)
+                        oscale = torch.empty(3, dtype=torch.float32, device=self.device)
+                        _ffi.check(self._L.sk_train_interleave2_h(_ffi.ptr(t16), _ffi.ptr(pend[0]) if pend is not None else None,
+                                                                   _ffi.ptr(pend[1]) if pend is not None else None,
+                                                                   _ffi.ptr(dx16), _ffi.ptr(oscale), B, ox, oy, oz, c,
+                                                                   _ffi.ptr(scale), st))
+                        grads[key] = (dx16, oscale, True)
+                    elif pend is not None:
                         _ffi.check(self._L.sk_train_interleave2_add16(_ffi.ptr(t16), _ffi.ptr(pend[0]), _ffi.ptr(pend[1]),
                                                                        _ffi.ptr(grads[key]), B, ox, oy, oz, c, _ffi.ptr(scale),
                                                                        st))
@@ -494,9 +507,16 @@ class TrainUNet:
                     if up:
                         if key in grads:
                             raise RuntimeError("an upsampled tensor has one consumer in this graph")
-                        grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
-                        _ffi.check(self._L.sk_train_sumpool2_f16(_ffi.ptr(dx16), _ffi.ptr(scale), _ffi.ptr(grads[key]), B,
-                                                                  ox // 2, oy // 2, oz // 2, c, st))
+                        if self.f16_grad_handoff and key in fast_out and n_readers.get(key, 0) == 1:
+                            c16 = torch.empty(t.shape, dtype=self.t16, device=self.device)
+                            oscale = torch.empty(3, dtype=torch.float32, device=self.device)
+                            _ffi.check(self._L.sk_train_sumpool2_hh(_ffi.ptr(dx16), _ffi.ptr(scale), _ffi.ptr(c16),
+                                                                     _ffi.ptr(oscale), B, ox // 2, oy // 2, oz // 2, c, st))
+                            grads[key] = (c16, oscale, True)
+                        else:
+                            grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
+                            _ffi.check(self._L.sk_train_sumpool2_f16(_ffi.ptr(dx16), _ffi.ptr(scale), _ffi.ptr(grads[key]), B,
+                                                                      ox // 2, oy // 2, oz // 2, c, st))
                     elif (key in fast_out and key not in grads and self.f16_grad_handoff and
                           (n_readers.get(key, 0) == 1 or (n_readers.get(key, 0) == 2 and key in k2_read))):
                         # single reader: handed to the GroupNorm backward as it is; a skip tensor whose other reader is a
@@ -517,6 +537,16 @@ class TrainUNet:
                     grads[key] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
                     _ffi.check(self._L.sk_train_sumpool2(_ffi.ptr(fine), _ffi.ptr(grads[key]), B, ox // 2, oy // 2,
                                                           oz // 2, c, st))
+                elif (self.f16_grad_handoff and t.dtype == self.t16 and layer.ksize == 1 and cout == 5 and len(srcs) == 1 and
+                      key in fast_out and key not in grads and n_readers.get(key, 0) == 1 and c % 8 == 0 and 256 % (c // 8) == 0):
+                    # the heads on the 16-bit activation: their data gradient leaves as a scaled 16-bit tensor as well
+                    dl_scale = torch.zeros(3, dtype=torch.float32, device=self.device)
+                    _ffi.check(self._L.sk_train_absmax_scale(_ffi.ptr(dy), dy.numel(), _ffi.ptr(dl_scale), st))
+                    dx16 = torch.empty(t.shape, dtype=self.t16, device=self.device)
+                    oscale = torch.empty(3, dtype=torch.float32, device=self.device)
+                    _ffi.check(self._L.sk_train_heads_dgrad_f16(_ffi.ptr(dy), _ffi.ptr(dl_scale), _ffi.ptr(layer.weight),
+                                                                 _ffi.ptr(dx16), _ffi.ptr(oscale), B * vox, c, st))
+                    grads[key] = (dx16, oscale, True)
                 else:
                     have = key in grads
                     if not have:

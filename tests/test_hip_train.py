@@ -363,6 +363,59 @@ def test_stem_wgrad_f16(ffi, B, osp, twin):
     _close(dbias, bias.grad, 1e-4, "stem dbias")
 
 
+@pytest.mark.parametrize("twin", [False, True])
+def test_16bit_gradient_handoffs(ffi, twin):
+    """sk_train_interleave2_h / sk_train_sumpool2_hh / sk_train_heads_dgrad_f16: the three gradients that leave their
+    producer as a scaled 16-bit tensor + scale vector (for sk_train_gn_silu_bwd_f16h) against the fp32 value computed
+    from the same operands; bound = one rounding of the 16-bit type relative to the tensor's maximum (the scale keeps
+    the maximum within a factor 4 of the type's working range 2^13)."""
+    gen = torch.Generator().manual_seed(11)
+    dt = torch.bfloat16 if twin else torch.float16
+    sfx = "_bf16" if twin else ""
+    L = lambda n: getattr(ffi.lib, n + sfx)
+    eps = 2.0 ** -8 if twin else 2.0 ** -11
+    st = ffi.stream_ptr(torch.device(DEV))
+    B, cx, cy, cz, C = 2, 3, 4, 5, 32
+    # parity tensor (scaled by 2^20) and a second fine gradient (scaled by 2^17), both near the top of their range
+    t16 = (torch.randn((8, B, cx, cy, cz, C), generator=gen) * 1500).to(dt).to(DEV)
+    add = (torch.randn((B, 2 * cx, 2 * cy, 2 * cz, C), generator=gen) * 1500).to(dt).to(DEV)
+    sc = torch.tensor([2.0 ** 20, 2.0 ** -20, 1e-2], device=DEV)
+    asc = torch.tensor([2.0 ** 17, 2.0 ** -17, 5e-2], device=DEV)
+    ref32 = torch.empty((B, 2 * cx, 2 * cy, 2 * cz, C), device=DEV)
+    ffi.check(L("sk_train_interleave2_add16")(ffi.ptr(t16), ffi.ptr(add), ffi.ptr(asc), ffi.ptr(ref32), B, cx, cy, cz, C, ffi.ptr(sc), st))
+    for with_add in (True, False):
+        out = torch.empty(ref32.shape, dtype=dt, device=DEV)
+        osc = torch.zeros(3, device=DEV)
+        ffi.check(L("sk_train_interleave2_h")(ffi.ptr(t16), ffi.ptr(add) if with_add else None, ffi.ptr(asc) if with_add else None,
+                                              ffi.ptr(out), ffi.ptr(osc), B, cx, cy, cz, C, ffi.ptr(sc), st))
+        if not with_add:
+            ffi.check(L("sk_train_interleave2")(ffi.ptr(t16), ffi.ptr(ref32), B, cx, cy, cz, C, ffi.ptr(sc), 0, st))
+        o = osc.cpu()
+        assert abs(o[0].item() * o[1].item() - 1) < 1e-6 and float(out.float().abs().max()) < 2.0 ** 15
+        assert o[0].item() == (2.0 ** 16 if with_add else 2.0 ** 20)
+        _close(out.float() * o[1].item(), ref32, 2 * eps, "interleave2_h")
+    fine = (torch.randn((B, 2 * cx, 2 * cy, 2 * cz, C), generator=gen) * 2000).to(dt).to(DEV)
+    ref32 = torch.empty((B, cx, cy, cz, C), device=DEV)
+    ffi.check(L("sk_train_sumpool2_f16")(ffi.ptr(fine), ffi.ptr(sc), ffi.ptr(ref32), B, cx, cy, cz, C, st))
+    out = torch.empty(ref32.shape, dtype=dt, device=DEV)
+    osc = torch.zeros(3, device=DEV)
+    ffi.check(L("sk_train_sumpool2_hh")(ffi.ptr(fine), ffi.ptr(sc), ffi.ptr(out), ffi.ptr(osc), B, cx, cy, cz, C, st))
+    assert osc[0].item() == 2.0 ** 17 and float(out.float().abs().max()) < 2.0 ** 15
+    _close(out.float() * osc[1].item(), ref32, 2 * eps, "sumpool2_hh")
+    nv = B * 2 * cx * 2 * cy * 2 * cz
+    dl = (torch.randn((nv, 5), generator=gen) * 3e-6).to(DEV)
+    w = torch.randn((5, C), generator=gen).to(DEV) * 0.3
+    dls = torch.zeros(3, device=DEV)
+    ffi.check(L("sk_train_absmax_scale")(ffi.ptr(dl), dl.numel(), ffi.ptr(dls), st))
+    out = torch.empty((nv, C), dtype=dt, device=DEV)
+    osc = torch.zeros(3, device=DEV)
+    ffi.check(L("sk_train_heads_dgrad_f16")(ffi.ptr(dl), ffi.ptr(dls), ffi.ptr(w), ffi.ptr(out), ffi.ptr(osc), nv, C, st))
+    ref = dl @ w
+    m = float(out.float().abs().max())
+    assert 2.0 ** 8 < m < 2.0 ** 13, m   # uses the type's range without leaving it
+    _close(out.float() * osc[1].item(), ref, 2 * eps, "heads_dgrad_f16")
+
+
 BF16_TWIN_CASES = [c for c in BWD_CASES if c[4] == 3 and c[2][0][0] % 32 == 0] + [BWD_CASES[4], BWD_CASES[5]]
 
 
@@ -562,8 +615,12 @@ def test_training_step_is_deterministic(precision):
 @pytest.mark.parametrize("precision", ["mixed", "bf16"])
 def test_fp16_gradient_handoff_equals_the_fp32_copies(precision):
     """Mixed / bf16 mode hands a fast conv's scaled 16-bit data gradient straight to the producer's GroupNorm backward
-    (and pools an upsampled one without an fp32 fine tensor).  The values are the same numbers as with the fp32 copies
-    in between (``f16_grad_handoff = False``): the gradients agree to fp32 summation-order noise."""
+    (and pools an upsampled one without an fp32 fine tensor): the same numbers as with the fp32 copies in between
+    (``f16_grad_handoff = False``).  Three hand-offs carry ONE extra rounding to the 16-bit type -- the sum of a skip
+    tensor's two contributions (sk_train_interleave2_h), the pooled gradient of an upsampled source
+    (sk_train_sumpool2_hh) and the heads' data gradient (sk_train_heads_dgrad_f16) used to be fp32 tensors -- so the
+    parameter gradients agree to a fraction of that rounding (2^-11 / 2^-8 per element, averaged over the voxels a
+    weight gradient sums), not to fp32 noise: measured 1.1e-4 (mixed) of the largest gradient."""
     from skoots_amd.train import TrainStep, TrainUNet
     from skoots_amd.unet import random_state_dict
     model = TrainUNet(random_state_dict(), DEV, precision=precision)
@@ -577,7 +634,7 @@ def test_fp16_gradient_handoff_equals_the_fp32_copies(precision):
         model.backward(dl)
         grads.append(model.flat_grad.clone())
     scale = grads[1].abs().max().item()
-    assert (grads[0] - grads[1]).abs().max().item() <= 1e-5 * scale
+    assert (grads[0] - grads[1]).abs().max().item() <= (4e-3 if precision == "bf16" else 5e-4) * scale
     assert not torch.equal(grads[0], torch.zeros_like(grads[0]))
 
 
