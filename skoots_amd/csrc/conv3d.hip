@@ -2204,7 +2204,7 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
     // depend on how many tiles share its launch (tests/test_hip_geometry.py: batch invariance).
     (void)B;
     const int kPlanBatch = 8;
-    int target = 256 * 2 * 6;
+    int target = 256 * 2 * 8;   // (x 6 left the 64-channel layers of a 256^3 training crop, batch 1, with 384 workgroups for 512 slots)
     int nxc = (target + p.npatch * kPlanBatch - 1) / (p.npatch * kPlanBatch);
     // COUT 32 on linear patches (the full-resolution layers of the production tile): half as many, twice as long chunks.
     // conv3_px_kernel pays a fixed price per workgroup (weights into registers / LDS, four planes staged, the planes at
