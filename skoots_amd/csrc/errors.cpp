@@ -29,5 +29,5 @@ int sk_debug_set_timing_buffer(void* device_ptr, size_t bytes) {
     return SK_OK;
 }
 const char* sk_last_error(void) { return sk::g_err; }
-int sk_abi_version(void) { return 3; }  // 3: round 3 (sk_debug_set_timing_buffer, sk_mfma_probe, sk_conv3d_box); 2: round 2 (split mode, fused down conv, bf16 twins)
+int sk_abi_version(void) { return 3; }  // 3: round 3 (sk_debug_set_timing_buffer, sk_mfma_probe, sk_conv3d_box, the 16-bit gradient hand-offs sk_train_interleave2_h / sumpool2_hh / heads_dgrad_f16); 2: round 2 (split mode, fused down conv, bf16 twins)
 }

@@ -1705,7 +1705,9 @@ __global__ void __launch_bounds__(256, 1) wgrad16x_kernel(Wgrad16Args a, int nfy
     // with ONE wave per SIMD nothing covers the ~180-340 cycles a wave stands at each of its nine buffer_load ... lds
     // per step (spreading them over the groups made it 1.60: each then also waits out the fragment reads in flight;
     // issuing them right after the barrier instead of at the top of the step: 0.99).
-    // The way out is loads into registers + ds_write_b128, which needs ~36 more VGPRs than the 27 accumulators leave.
+    // The way out is loads into registers + ds_write_b128, which needs ~36 more VGPRs than the 27 accumulators leave; with
+    // the 20 that can be had (two half-step batches of five and four loads, offsets recomputed per use; 256 VGPRs, three
+    // scratch reloads a step) the writes wait for loads half a step old: 1.25.
     for (int x = xa, t = 0; x < xb; ++x, ++t) {
         // slot of plane x-2 (last read before the barrier of step x-1) and buffer of dy plane x-2
         const bool more_x = x + 1 < xb, more_dy = x + 2 < xb;
