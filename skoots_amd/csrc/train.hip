@@ -994,6 +994,7 @@ struct Wgrad16Args {
     int B, ox, oy, oz, cout, cin, ksize;
     int nchunk, nchunk_b, ncot, ncit, ngroup;
     long long chunk;   // voxels per chunk, multiple of 16
+    long long* dbg;    // -DSK_TIMING builds: per-wave phase cycle sums of wgrad16x_kernel (sk_debug_set_timing_buffer), else null
 };
 
 
@@ -1545,7 +1546,8 @@ typedef __attribute__((address_space(3))) char* lds_ptr;
 
 #ifndef SK_WX_ABL
 #define SK_WX_ABL 0   // timing experiments (-DSK_WX_ABL=bits, results wrong): 1 no LDS-DMA inside the march, 2 no fragment
-                      // reads inside the march, 4 the DMA's loads go to (discarded) registers instead of LDS
+                      // reads inside the march, 4 the DMA's loads go to (discarded) registers instead of LDS, 8 an
+                      // s_waitcnt lgkmcnt(0) right after the step's LDS-DMA burst (timed in slot 7 of the -DSK_TIMING build)
 #endif
 __device__ __forceinline__ fp16x4_t wx_read(lds_ptr p) {
     return SK_DS_READ_TR16_B64((__attribute__((address_space(3))) fp16x4_t*)p);
@@ -1569,6 +1571,11 @@ __device__ __forceinline__ half8_t wx_join(fp16x4_t lo, fp16x4_t hi) {
 // longer knows about these instructions: nothing reads an accumulator before the s_nop block ahead of the epilogue, and a
 // tap's MFMAs are nine instructions apart.
 constexpr int kWxAgprTaps = 16;
+#ifdef SK_WX_AGPR_LAST   // experiment: the LAST 16 taps in AGPRs instead of the first 16
+#define SK_WX_AGPR_OF(i) ((i) >= 27 - kWxAgprTaps)
+#else
+#define SK_WX_AGPR_OF(i) ((i) < kWxAgprTaps)
+#endif
 #ifdef SK_BF16
 #define SK_WX_MFMA_ASM "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
 #else
@@ -1672,6 +1679,20 @@ __global__ void __launch_bounds__(256, 1) wgrad16x_kernel(Wgrad16Args a, int nfy
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     float bsum = 0.0f;
     const bool want_bias = a.part_bias != nullptr && cit == 0;
+#ifdef SK_TIMING   // per-wave cycle sums: 0 groups 0..6 | 1 landing wait | 2 barrier | 3 groups 7..11 | 4 LDS-DMA issue | 5 prologue | 6 epilogue
+    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev_ = __builtin_readcyclecounter();
+#define SK_WX_T(i) { const long long t_ = __builtin_readcyclecounter(); tacc_[i] += t_ - tprev_; tprev_ = t_; }
+#else
+#define SK_WX_T(i)
+#endif
+#if defined(SK_TIMING) && defined(SK_WX_TGROUP)   // per-group cycles instead of the phase split: slots 0..11 = groups, 12 issue, 13 wait + barrier
+    long long tg_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tgp_ = __builtin_readcyclecounter();
+#define SK_WX_TG(i) { const long long t_ = __builtin_readcyclecounter(); tg_[i] += t_ - tgp_; tgp_ = t_; }
+#else
+#define SK_WX_TG(i)
+#endif
 
     // planes xa-1, xa, xa+1 -> slots 0, 1, 2; dy planes xa, xa+1 -> buffers 0, 1
     issue_x(xa - 1, 0);
@@ -1701,18 +1722,29 @@ __global__ void __launch_bounds__(256, 1) wgrad16x_kernel(Wgrad16Args a, int nfy
     // finished with) and the dy fragments of the next row (other register set).
     // What is left on the table (tools/bench_wgrad.py, enc0.1 at 256^3, ms per call incl. the partial reduction): 1.00 as
     // is; 0.67 without the LDS-DMA; 0.79 without the fragment reads; 0.62 without both; 0.70 with the same bytes loaded
-    // into registers instead of LDS -- so it is neither HBM / L2 nor the LDS reads but the LDS-DMA instruction itself:
-    // with ONE wave per SIMD nothing covers the ~180-340 cycles a wave stands at each of its nine buffer_load ... lds
-    // per step (spreading them over the groups made it 1.60: each then also waits out the fragment reads in flight;
-    // issuing them right after the barrier instead of at the top of the step: 0.99).
-    // The way out is loads into registers + ds_write_b128, which needs ~36 more VGPRs than the 27 accumulators leave; with
-    // the 20 that can be had (two half-step batches of five and four loads, offsets recomputed per use; 256 VGPRs, three
-    // scratch reloads a step) the writes wait for loads half a step old: 1.25.
+    // into registers instead of LDS -- neither HBM / L2 nor the LDS reads, the LDS-DMA itself.  Per-group cycle counts
+    // (-DSK_TIMING -DSK_WX_TGROUP, `tools/bench_wgrad.py --phases`): the groups 1 .. 11 of a step take 4.5-5.9 % of it
+    // each, group 0 -- the first one behind the step's burst of nine buffer_load ... lds per wave -- 19-29 %, the burst's
+    // issue 9 %.  An `s_waitcnt lgkmcnt(0)` right behind the burst returns at once (the fragments requested BEFORE it
+    // arrive as usual; the DMA does not count there), and which accumulators live in AGPRs does not matter: it is the
+    // ds_reads issued BEHIND the burst that stand until its data has landed -- about one L2 / HBM round trip of LDS
+    // black-out per burst, for every wave of the CU.  Hence spreading the nine over the groups costs nine round trips
+    // (1.60), moving the burst or the barrier changes nothing (0.99), and only loads into registers + ds_write_b128 avoid
+    // it: ~36 more VGPRs than the 27 accumulators leave (with the 20 that can be had -- two half-step batches, offsets
+    // recomputed per use, three scratch reloads a step -- the writes wait for loads half a step old: 1.25).
+    SK_WX_T(5)
     for (int x = xa, t = 0; x < xb; ++x, ++t) {
         // slot of plane x-2 (last read before the barrier of step x-1) and buffer of dy plane x-2
         const bool more_x = x + 1 < xb, more_dy = x + 2 < xb;
+        SK_WX_T(3)
         if (more_x && !(SK_WX_ABL & 1)) issue_x(x + 2, (t + 3) & 3);
         if (more_dy && !(SK_WX_ABL & 1)) issue_dy(x + 2, (t + 2) & 3);
+        SK_WX_T(4)
+        SK_WX_TG(12)
+        if (SK_WX_ABL & 8) {   // experiment: does an LDS-DMA in flight hold lgkmcnt?  (time of this wait -> slot 7)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SK_WX_T(7)
+        }
         lds_ptr xs[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) xs[i] = Lx + ((t + i) & 3) * kWxPlane;   // plane x + i - 1
@@ -1742,7 +1774,7 @@ __global__ void __launch_bounds__(256, 1) wgrad16x_kernel(Wgrad16Args a, int nfy
                 for (int j = 0; j < 4; ++j) bsum += (float)(t16)Dl[cur][1][j] + (float)(t16)Dh[cur][1][j];
             }
 #define SK_WX_M(dyi, dz) \
-    wx_mfma<(dx * 9 + (dyi) * 3 + (dz) < kWxAgprTaps)>(acc[dx * 9 + (dyi) * 3 + (dz)], wx_join(Dl[cur][dz], Dh[cur][dz]), wx_join(Xl[dyi], Xh[dyi]))
+    wx_mfma<SK_WX_AGPR_OF(dx * 9 + (dyi) * 3 + (dz))>(acc[dx * 9 + (dyi) * 3 + (dz)], wx_join(Dl[cur][dz], Dh[cur][dz]), wx_join(Xl[dyi], Xh[dyi]))
 #define SK_WX_D(i) dread(std::integral_constant<int, d0 + (i)>{})
             SK_WX_PIN();
             SK_WX_M(0, 0);
@@ -1790,25 +1822,42 @@ __global__ void __launch_bounds__(256, 1) wgrad16x_kernel(Wgrad16Args a, int nfy
 #undef SK_WX_D
         };
         group(std::integral_constant<int, 0>{});
+        SK_WX_TG(0)
         group(std::integral_constant<int, 1>{});
+        SK_WX_TG(1)
         group(std::integral_constant<int, 2>{});
+        SK_WX_TG(2)
         group(std::integral_constant<int, 3>{});
+        SK_WX_TG(3)
         group(std::integral_constant<int, 4>{});
+        SK_WX_TG(4)
         group(std::integral_constant<int, 5>{});
+        SK_WX_TG(5)
         group(std::integral_constant<int, 6>{});
+        SK_WX_TG(6)
         // everything but this step's own requests has landed (the last steps request less: wait for all)
+        SK_WX_T(0)
         if (more_x && more_dy && !(SK_WX_ABL & 1))
             asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SK_WX_T(1)
         __builtin_amdgcn_s_barrier();
+        SK_WX_T(2)
+        SK_WX_TG(13)
         group(std::integral_constant<int, 7>{});
+        SK_WX_TG(7)
         group(std::integral_constant<int, 8>{});
+        SK_WX_TG(8)
         group(std::integral_constant<int, 9>{});
+        SK_WX_TG(9)
         group(std::integral_constant<int, 10>{});
+        SK_WX_TG(10)
         group(std::integral_constant<int, 11>{});
+        SK_WX_TG(11)
     }
 
+    SK_WX_T(3)
     // One partial per workgroup: the four waves' accumulators are summed through LDS (fixed order), six taps a round
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (see wx_mfma)
     __syncthreads();
@@ -1856,6 +1905,17 @@ __global__ void __launch_bounds__(256, 1) wgrad16x_kernel(Wgrad16Args a, int nfy
         __syncthreads();
         if (w == 0 && h == 0) a.part_bias[(long long)chunk * a.cout + 32 * cot + col] = (rb[col] + rb[32 + col]) + (rb[64 + col] + rb[96 + col]);
     }
+#ifdef SK_TIMING
+    SK_WX_T(6)
+    if (a.dbg && lane == 0 && blockIdx.x < (unsigned)sk::kTimingBlocks)
+#ifdef SK_WX_TGROUP
+        for (int i = 0; i < 16; ++i) a.dbg[((long long)blockIdx.x * 4 + w) * sk::kTimingSlots + i] = tg_[i];
+#else
+        for (int i = 0; i < 8; ++i) a.dbg[((long long)blockIdx.x * 4 + w) * sk::kTimingSlots + i] = tacc_[i];
+#endif
+#endif
+#undef SK_WX_TG
+#undef SK_WX_T
 }
 
 // Device-side counterpart of sk_conv3d_pack_weight_host (weights change every step in training): fp32
@@ -2639,6 +2699,9 @@ int sk_train_conv_wgrad_f16(const sk_conv_src* srcs, int n_src, const void* dy, 
     if (getenv("SK_WGRAD_NOXMARCH")) nchunk_x = 0;
 #endif
     if (nchunk_x > 0) {
+#ifdef SK_TIMING
+        a.dbg = sk::timing_buffer();
+#endif
         a.nchunk = nchunk_x;
         a.part_bias = dbias ? workspace + (long long)a.nchunk * nw : nullptr;
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad16x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWxLds));

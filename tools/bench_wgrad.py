@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--scale", type=int, default=1, help="divide the spatial extents (smoke runs)")
     ap.add_argument("--zeros", action="store_true", help="all-zero operands (clock / data-dependence check)")
+    ap.add_argument("--phases", action="store_true", help="-DSK_TIMING build (make timing; SKOOTS_HIP_LIB=.../libskoots_hip_timing.so): "
+                    "where a wave of wgrad16x_kernel spends its cycles")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if a.bf16 else torch.float16
@@ -39,6 +41,11 @@ def main():
     zero_page = torch.zeros(4096, dtype=torch.uint8, device=dev)
     out = {}
     mk = torch.zeros if a.zeros else torch.randn
+    dbg = None
+    if a.phases:
+        dbg = torch.zeros((4096, 4, 16), dtype=torch.int64, device=dev)
+        _ffi.check(_ffi.lib.sk_debug_set_timing_buffer(_ffi.ptr(dbg), dbg.numel() * 8))
+    names = ["groups_0_6", "landing_wait", "barrier", "groups_7_11", "dma_issue", "prologue", "epilogue", "lgkm_after_burst"]
     for name, n, srcdef, cout in LAYERS:
         n //= a.scale
         srcs = [(mk((1, n // 2, n // 2, n // 2, c) if up else (1, n, n, n, c), device=dev).to(dt), up) for c, up in srcdef]
@@ -66,6 +73,18 @@ def main():
         ms = e0.elapsed_time(e1) / a.iters
         fl = 2.0 * 27 * cin * cout * n ** 3
         out[name] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}
+        if dbg is not None:
+            dbg.zero_()
+            run()
+            torch.cuda.synchronize()
+            d = dbg.double()
+            m = d[d.sum(dim=(1, 2)) > 0].mean(dim=(0, 1))
+            tot = m.sum().item()
+            out[name]["phases"] = {k: round(v / tot, 4) for k, v in zip(names, m.tolist())}
+            out[name]["slots"] = [round(v / tot, 4) for v in m.tolist()]   # -DSK_WX_TGROUP build: groups 0..11, issue, wait + barrier
+            out[name]["cycles_per_wave"] = round(tot)
+    if dbg is not None:
+        _ffi.check(_ffi.lib.sk_debug_set_timing_buffer(None, 0))
     print(json.dumps(out))
 
 
