@@ -1731,7 +1731,8 @@ __global__ void __launch_bounds__(256, 1) wgrad16x_kernel(Wgrad16Args a, int nfy
     // black-out per burst, for every wave of the CU.  Hence spreading the nine over the groups costs nine round trips
     // (1.60), moving the burst or the barrier changes nothing (0.99), and only loads into registers + ds_write_b128 avoid
     // it: ~36 more VGPRs than the 27 accumulators leave (with the 20 that can be had -- two half-step batches, offsets
-    // recomputed per use, three scratch reloads a step -- the writes wait for loads half a step old: 1.25).
+    // recomputed per use, three scratch reloads a step -- the writes wait for loads half a step old: 1.25; one load and
+    // one write per group with five groups of lead, offsets kept: 256 VGPRs + two in-loop reloads behind vmcnt(0): 1.27).
     SK_WX_T(5)
     for (int x = xa, t = 0; x < xb; ++x, ++t) {
         // slot of plane x-2 (last read before the barrier of step x-1) and buffer of dy plane x-2
