@@ -120,6 +120,20 @@ def device_blob_field(shape, z_window, device, seed=0, pitch=(64, 64, 16), dense
     return out, nx * ny * nz
 
 
+def contiguous_tile_blocks(field, shape, rank, world, zlo):
+    """{window-local tile origin: (5, w, h, d) fp16 view} of this rank's tiles of the reference grid, all views of ONE
+    contiguous (T, 5, w, h, d) buffer copied from ``field`` (5, X, Y, window planes) -- the layout a network output has."""
+    from skoots_amd.parallel import tile_plan
+    plan, eff = tile_plan(shape, (300, 300, 20), (50, 50, 5), world)
+    mine = plan[rank]
+    blocks = torch.empty((len(mine), 5) + tuple(eff), dtype=field.dtype, device=field.device)
+    cache = {}
+    for i, (x, y, z) in enumerate(mine):
+        blocks[i].copy_(field[:, x:x + eff[0], y:y + eff[1], z - zlo:z - zlo + eff[2]])
+        cache[(x, y, z - zlo)] = blocks[i]
+    return cache, blocks
+
+
 def cpu_threads() -> int:
     """Host threads for the CPU baseline: the GPU box grants 16 cores per GPU."""
     try:
@@ -384,6 +398,57 @@ def parity_vs_fp32_mode(model, image, origins, eff, mean, std, out_box, precisio
             "north_star_tolerance": 1e-3}
 
 
+def conv_c1_measure(dev, iters=5, warmup=2, tile=(512, 512, 128)):
+    """BASELINE configs[1]: ONE 512x512x128 fp16 tile through the conv + GroupNorm/SiLU stack (stem, every conv, the
+    GroupNorm passes, heads -- no tiling, no assignment; the reference's `model(crop)`, skoots/lib/eval.py:142-143, on
+    one crop of that size).  ``roofline``: the 3x3x3 MFMA conv launches (HIP events around each) against the dense fp16
+    peak, per layer and for the encoder alone (north_star's >= 40 % target is stated for the conv encoder)."""
+    from skoots_amd import unet
+    model = unet.smoke_model(dev)
+    g = torch.Generator(device=dev).manual_seed(0)
+    vol = torch.randint(0, 256, tile, generator=g, device=dev, dtype=torch.uint8).to(torch.float16)
+    org = [(0, 0, 0)]
+    for _ in range(warmup):
+        model.forward_tiles(vol, org, tile, 127.5, 73.9)
+    torch.cuda.synchronize(dev)
+    prof = unet.ConvProfile()
+    model.profile = prof
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream(dev))
+    for _ in range(iters):
+        model.forward_tiles(vol, org, tile, 127.5, 73.9)
+    e1.record(torch.cuda.current_stream(dev))
+    e1.synchronize()
+    model.profile = None
+    fwd_ms = e0.elapsed_time(e1) / iters
+    vox = tile[0] * tile[1] * tile[2]
+    per = {}
+    for a, b, fl, name in prof.named():
+        d = per.setdefault(name, [0.0, 0.0, 0])
+        d[0] += a.elapsed_time(b)
+        d[1] += fl
+        d[2] += 1
+    layers = {k: {"avg_launch_ms": round(v[0] / v[2], 4), "tflops": round(v[1] / v[0] / 1e9, 1),
+                  "frac": round(v[1] / v[0] / 1e9 / MFMA_PEAK_TFLOPS, 4)} for k, v in per.items()}
+    conv_ms, conv_fl, n = prof.totals()
+    enc = [v for k, v in per.items() if k.startswith(("enc", "mid"))]
+    enc_ms, enc_fl = sum(v[0] for v in enc), sum(v[1] for v in enc)
+    ach = conv_fl / conv_ms / 1e9
+    out = {"metric": "one 512x512x128 fp16 tile, conv + GN/SiLU stack only (BASELINE configs[1])",
+           "forward_ms": round(fwd_ms, 3), "value": round(vox / fwd_ms / 1e3, 1), "unit": "Mvoxels/s (tile voxels)",
+           "iters": iters, "warmup": warmup, "dtype": "f16",
+           "forward_tflops_algorithmic": round(model.flops_per_tile_voxel() * vox / fwd_ms / 1e9, 1),
+           "roofline": {"bound": "mfma", "kernel": "all 3x3x3 MFMA conv launches of the tile (conv3_m16_kernel / conv3_kernel)",
+                        "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": n,
+                        "conv3_ms_per_forward": round(conv_ms / iters, 3),
+                        "encoder_frac": round(enc_fl / enc_ms / 1e9 / MFMA_PEAK_TFLOPS, 4) if enc_ms > 0 else None,
+                        "layers": layers}}
+    del model, vol
+    torch.cuda.empty_cache()
+    return out
+
+
 def eval_main(args, rank, world, local):
     """The headline line.  At N = 1 the same process then times, on the same resident volume, the precision that
     meets north_star's 1e-3 tolerance (``also.split``) and one training leg (``also.train_bf16``, configs[4]) --
@@ -425,9 +490,19 @@ def eval_main(args, rank, world, local):
     mean, std = 127.5, 73.9  # uniform[0,255] statistics ("dataset_mean/std" of the checkpoint, eval.py:87-88)
     inject_vol, n_blobs = (None, 0) if args.no_inject else device_blob_field(shape, (zlo, zhi), dev)
 
+    # The injected field of every tile of this rank as a CONTIGUOUS (5, w, h, d) block -- the layout a network output
+    # has -- copied once here, outside every timed region (625 tiles x 18 MB at N = 1).  (Rounds 1-3 handed the scatter
+    # kernel strided 300x300x20 windows of the (5, X, Y, Z) field: 40-byte runs of 128-byte lines, 6.8x the bytes.)
+    tile_cache, blocks = {}, None
+    if inject_vol is not None and not args.strided_inject:
+        tile_cache, blocks = contiguous_tile_blocks(inject_vol, shape, rank, world, zlo)
+
     def inject(out5, origin, eff):
         if inject_vol is None:
             return out5
+        t = tile_cache.get(tuple(int(v) for v in origin))
+        if t is not None:
+            return t
         x, y, z = origin
         return inject_vol[:, x:x + eff[0], y:y + eff[1], z:z + eff[2]]  # strided view: no copy
 
@@ -461,13 +536,23 @@ def eval_main(args, rank, world, local):
             roof_steps, roof_src = 1, "extra single-stream step after the warm-up, untimed"
         sv.timings.clear()
         sv.comm._acct.clear()
+        mstat0 = torch.cuda.memory_stats(dev)
         barrier()
         t0 = time.perf_counter()
+        step_marks = []
         for _ in range(steps):
             res = step(prof, sprof, 1) if streams == 1 else step(None, None, streams)
+            step_marks.append(time.perf_counter())   # sv.run ends with a device synchronisation (its stage timings)
         barrier()
         dt = time.perf_counter() - t0
-        log(f"[{precision}] timed {steps} steps in {dt:.3f} s")
+        mstat1 = torch.cuda.memory_stats(dev)
+        per_step_ms = [round((b_ - a_) * 1e3, 1) for a_, b_ in zip([t0] + step_marks[:-1], step_marks)]
+        # device allocations inside the timed region: a hipMalloc / hipFree in the steady state would stall the launch queue
+        alloc = {"device_mallocs": int(mstat1.get("num_device_alloc", 0) - mstat0.get("num_device_alloc", 0)),
+                 "device_frees": int(mstat1.get("num_device_free", 0) - mstat0.get("num_device_free", 0)),
+                 "alloc_retries": int(mstat1.get("num_alloc_retries", 0) - mstat0.get("num_alloc_retries", 0)),
+                 "reserved_gib": round(mstat1.get("reserved_bytes.all.current", 0) / 2 ** 30, 1)}
+        log(f"[{precision}] timed {steps} steps in {dt:.3f} s; per step {per_step_ms[:8]} ms; allocator {alloc}")
         comm_stats = sv.comm.stats()
         tiles = sv.tiles_this_rank
         if world > 1:
@@ -512,8 +597,12 @@ def eval_main(args, rank, world, local):
                                        f"Z-sharded x{world}", "precision": precision,
                            "tile_batch": args.tile_batch, "streams": streams, "fold_upsample": not args.no_fold,
                            "instances": int(res.get("n_instances", -1)), "blobs_injected": n_blobs,
-                           "stage_ms": {k: round(v / steps * 1e3, 2) for k, v in sv.timings.items()}},
-                "roofline": {"bound": "mfma", "kernel": "conv3_m16_kernel / conv3_kernel / conv3_upf_kernel (all 3x3x3 MFMA conv launches)",
+                           "inject_layout": "none" if inject_vol is None else ("strided windows" if args.strided_inject else "contiguous per-tile blocks"),
+                           "stage_ms": {k: round(v / steps * 1e3, 2) for k, v in sv.timings.items()},
+                           "step_ms_min_max": [min(per_step_ms), max(per_step_ms)], "allocator_in_timed_steps": alloc},
+                "roofline": {"bound": "mfma", "kernel": "conv3_px_kernel (enc0.1, dec0.1: the kernel with the most time) + conv3_upf_kernel (dec0.0, dec1.0) "
+                                                          "+ conv3_kernel<64|128> (enc1.x, dec1.1, mid.x): all 3x3x3 MFMA conv launches" if precision == "fp16" else
+                                                          "conv3_m16_kernel / conv3_kernel / conv3_upf_kernel, split variants (all 3x3x3 MFMA conv launches)",
                              "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic if precision == "fp16" else None,
                              # the two decoder convs over [skip, upsample(x)] run with the upsample folded into the weights
@@ -562,6 +651,8 @@ def eval_main(args, rank, world, local):
         also["split"]["roofline"]["note"] = ("achieved = ALGORITHMIC FLOPs (2*Cin*Cout*27) / conv time; the split mode issues three fp16 "
                                              "MFMA products per algorithmic product, `executed` counts them")
         also["split"]["stage_ms"] = sp["config"]["stage_ms"]
+        also["split"]["step_ms_min_max"] = sp["config"]["step_ms_min_max"]
+        also["split"]["allocator_in_timed_steps"] = sp["config"]["allocator_in_timed_steps"]
     if rank == 0:
         line["box"] = probe
         if not args.no_cpu_baseline and world == 1:
@@ -569,7 +660,10 @@ def eval_main(args, rank, world, local):
             line["cpu_baseline"] = cpu_baseline(args.cpu_budget)
     if world == 1 and not args.no_also and args.precision == "fp16":
         del sv, model, image, inject_vol
+        tile_cache.clear()
+        blocks = None
         torch.cuda.empty_cache()
+        also["conv_c1"] = conv_c1_measure(dev)
         targs = argparse.Namespace(**vars(args))
         targs.precision, targs.steps, targs.warmup, targs.no_cpu_baseline = "bf16", args.also_train_steps, 2, True
         targs.shape = args.also_train_shape
@@ -722,6 +816,9 @@ def main():
     ap.add_argument("--shape", type=str, default="", help="override X,Y,Z (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inject", action="store_true")
+    ap.add_argument("--strided-inject", action="store_true",
+                    help="rounds 1-3 behaviour: the injected field reaches the scatter kernel as strided windows of one (5, X, Y, Z) "
+                         "array instead of per-tile contiguous blocks (what a network output looks like)")
     ap.add_argument("--no-parity", action="store_true", help="skip the live parity_vs_fp32_mode measurement")
     ap.add_argument("--streams", type=int, default=1,
                     help="tile batches in flight (HIP streams).  2 x 32 tiles measured +1.3 %% over 1 x 64 (the convs fill the register "

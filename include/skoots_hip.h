@@ -212,11 +212,17 @@ int sk_conv3d(const sk_conv_src* srcs, int n_src, const void* weight, const floa
 /* sk_conv3d with a STORE BOX (round 3): store_box = {lo_x, lo_y, lo_z, hi_x, hi_y, hi_z} (host, tile-local, half open)
  * or NULL.  The convolution and its GroupNorm partial sums cover the whole tile as always; output voxels outside the
  * box may be left unwritten -- for a tensor whose only reader looks at a box of it (the last block's conv: the heads
- * evaluate the scatter's box, 28 % of a 300x300x20 tile).  Honoured by the single-chunk 32 -> 32 kernel
- * (conv3_px_kernel); every other shape stores the whole tile, which satisfies the contract too. */
+ * evaluate the scatter's box, 28 % of a 300x300x20 tile).  Honoured by the COUT-32 kernels (conv3_px_kernel, and since
+ * round 4 conv3_m16_kernel); wider layers store the whole tile, which satisfies the contract too. */
 int sk_conv3d_box(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,
                   int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial,
                   void* zero_page, const int* store_box, void* stream);
+
+/* sk_conv3d_box for the split precision (round 4; tensors and weight as sk_conv3d_split): the last block's conv of the
+ * precision="split" network stores only the heads' box -- 28 % of the 14.7 GB a 64-tile batch of [hi | lo] lines is. */
+int sk_conv3d_box_split(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,
+                        int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial,
+                        void* zero_page, const int* store_box, void* stream);
 
 /* 2x2x2 stride-2 down conv with the GroupNorm + SiLU of its INPUT folded in (the fused form of north_star's
  * "fused GroupNorm+SiLU" for the two skip tensors): in_raw (B, 2ox, 2oy, 2oz, cin) fp16 is the RAW output of the
@@ -228,6 +234,14 @@ int sk_conv3d_box(const sk_conv_src* srcs, int n_src, const void* weight, const 
 int sk_conv3d_down_act(void* in_raw, const float* affine, const void* weight, const float* bias, void* out,
                        int B, int ox, int oy, int oz, int cin, int cout, float* gn_partial,
                        void* zero_page, void* stream);
+
+/* sk_conv3d_down_act for the split precision (round 4): in_raw (B, 2ox, 2oy, 2oz, 2 cin) and out (B, ox, oy, oz, 2 cout)
+ * hold [hi | lo] fp16 pairs per voxel line, weight = sk_conv3d_pack_weight_split_host(ksize 2).  Activates hi + lo with
+ * the arithmetic of sk_groupnorm_silu_split (bit-identical), writes the pair back, three MFMA products per K step.
+ * Same partial-sum rows as sk_conv3d_num_blocks(.., ksize 2) reports. */
+int sk_conv3d_down_act_split(void* in_raw, const float* affine, const void* weight, const float* bias, void* out,
+                             int B, int ox, int oy, int oz, int cin, int cout, float* gn_partial,
+                             void* zero_page, void* stream);
 
 /* Decoder conv over cat([skip, nearest-upsample x2 (up)]) with the upsample FOLDED INTO THE WEIGHTS of the upsampled
  * channels (csrc/conv3d_up.hip): 3x3x3, stride 1, zero pad 1, the same function as sk_conv3d(ksize 3) with sources

@@ -71,7 +71,9 @@ _SIGS = {
     "sk_renumber": (i32, [vp, i64, i32, vp, sz, vp, vp]),
     "sk_conv3d": (i32, [C.POINTER(ConvSrc), i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "sk_conv3d_box": (i32, [C.POINTER(ConvSrc), i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, ip, vp]),
+    "sk_conv3d_box_split": (i32, [C.POINTER(ConvSrc), i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, ip, vp]),
     "sk_conv3d_down_act": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "sk_conv3d_down_act_split": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "sk_conv3d_num_blocks": (i32, [i32, i32, i32, i32, i32, i32]),
     "sk_conv3d_pack_weight_host": (i64, [fp, i32, i32, i32, vp]),
     "sk_conv3d_upfold": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
@@ -138,7 +140,7 @@ _SIGS = {
 # bf16 twins (include/skoots_hip_bf16.h): the training-path sources are compiled a second time on bf16 storage and
 # exported with the suffix _bf16, same signatures
 BF16_TWINS = (
-    "sk_conv3d", "sk_conv3d_box", "sk_conv3d_down_act", "sk_conv3d_num_blocks", "sk_conv3d_pack_weight_host", "sk_conv3d_pack_weight_split_host",
+    "sk_conv3d", "sk_conv3d_box", "sk_conv3d_box_split", "sk_conv3d_down_act", "sk_conv3d_down_act_split", "sk_conv3d_num_blocks", "sk_conv3d_pack_weight_host", "sk_conv3d_pack_weight_split_host",
     "sk_conv3d_split", "sk_conv3d_stem", "sk_conv3d_stem_apply", "sk_conv3d_stem_apply_split",
     "sk_conv3d_stem_num_blocks", "sk_conv3d_stem_workspace_bytes", "sk_groupnorm_finalize",
     "sk_groupnorm_finalize_stats", "sk_groupnorm_silu", "sk_groupnorm_silu_split", "sk_heads", "sk_heads_split",

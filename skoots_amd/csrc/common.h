@@ -84,6 +84,17 @@ static inline unsigned stream_grid(int64_t n, int block, int per_thread = 1) {
 // it the compiler may fuse multiply + conversion into v_fma_mixlo_f16 -- ONE rounding, a different last bit in about
 // one value of two thousand -- and does so in some kernels and not in others (it did inside the conv kernels' in-LDS
 // activation, not in the GroupNorm pass: tests/test_hip_unet.py::test_conv_activates_a_raw_source_in_lds).
+// The "zero position" of a staged plane, read by a tap that leaves the tile through a z face.  SK_ZERO_WINDOW = 1 (default,
+// round 4): a 256-byte window of zeros (4 positions) and the tap reads `zero + (its own address & 255)` -- the banks its
+// data read would have used, so a ds_read_b128 lane group stays conflict-free (conv3_px_kernel's finding, round 3:
+// with ONE shared 64-byte zero line the four lanes of a z-face voxel each land on another lane's banks, 22-35 % of the
+// LDS-active cycles in conflicts).  SK_ZERO_WINDOW = 0 builds the one-line form for the A/B (tools/kernel_ab.sh).
+#ifndef SK_ZERO_WINDOW
+#define SK_ZERO_WINDOW 1
+#endif
+constexpr int kZeroPos = SK_ZERO_WINDOW ? 4 : 1;   // zero positions behind the nposp staged ones of every plane slot
+__device__ inline int zero_of(int zero_addr, int addr) { return SK_ZERO_WINDOW ? zero_addr + (addr & 255) : zero_addr; }
+
 __device__ inline t16 round_t16(float v) {
     asm("" : "+v"(v));
     return (t16)v;

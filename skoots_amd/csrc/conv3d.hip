@@ -74,6 +74,7 @@ struct Conv3Args {
     int mode;           // 0: linear (y,z) ranges (small Zt), 1: TY x TZ rectangles
     int TZ, nzc;
     int pitch, nposp;
+    int jstep;          // conv3_m16_kernel: region positions from a lane's voxel c16 to voxel 16 + c16 of its column tile (16 | pitch)
     // act[i] != NULL: source i is the RAW output of its producing conv and act[i] (B, 2, C_i) the affine of its GroupNorm:
     // every lane applies silu(a*x + b) to the chunks it staged itself, in LDS, once its own LDS-DMA has landed -- the
     // fused form of GroupNorm + SiLU (no separate pass over the tensor; same arithmetic as gn_silu_kernel, bit-identical)
@@ -241,7 +242,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
 
     const int xa = xc * a.XC;
     const int xb = min(xa + a.XC, a.Xt);
-    const int plane_bytes = (a.nposp + 1) * kPosBytes;  // + the zero position (never written by the DMA)
+    const int plane_bytes = (a.nposp + sk::kZeroPos) * kPosBytes;  // + the zero window (never written by the DMA)
     const int zero_addr = a.nposp * kPosBytes;
     // Plane reuse: when a phase multiplies the SAME chunk as the phase before it, one step further along x, the two
     // trailing planes of that chunk are still staged and only XS new planes are loaded (`reuse`); the slots rotate
@@ -325,8 +326,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) wres[r][d] = wload(wbase(0) + ((r * 3 + d) * NT) * 1024);
     }
-    if (tid < R * 4)
-        *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
+    if (tid < R * 4 * sk::kZeroPos)
+        *reinterpret_cast<uint4*>(lds + (tid / (4 * sk::kZeroPos)) * plane_bytes + zero_addr + (tid % (4 * sk::kZeroPos)) * 16) = make_uint4(0, 0, 0, 0);
     issue_dma(0, ch0, false, 0);
     if constexpr (RES == 0) {
 #pragma unroll
@@ -368,8 +369,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                 for (int p = 0; p < P; ++p) {
                     const int q = q_row[p] + tapoff;
                     int addr = (q * 4 + ((ks * 2 + h) ^ ((q >> 2) & 3))) * 16;
-                    if (dz < 0) addr = zlo[p] ? zero_addr : addr;
-                    if (dz > 0) addr = zhi[p] ? zero_addr : addr;
+                    if (dz < 0) addr = zlo[p] ? sk::zero_of(zero_addr, addr) : addr;
+                    if (dz > 0) addr = zhi[p] ? sk::zero_of(zero_addr, addr) : addr;
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
                         const half8 bfr = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
@@ -403,8 +404,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                 const int tapoff = (dydz / 3 - 1) * pitch + dz;
                 const int q = q_row[p] + tapoff;
                 int addr = (q * 4 + ((ks * 2 + h) ^ ((q >> 2) & 3))) * 16;
-                if (dz < 0) addr = zlo[p] ? zero_addr : addr;
-                if (dz > 0) addr = zhi[p] ? zero_addr : addr;
+                if (dz < 0) addr = zlo[p] ? sk::zero_of(zero_addr, addr) : addr;
+                if (dz > 0) addr = zhi[p] ? sk::zero_of(zero_addr, addr) : addr;
 #pragma unroll
                 for (int i = 0; i < R; ++i) dst[i] = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
             };
@@ -684,9 +685,9 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     // ---- patch geometry ------------------------------------------------------------
     const int pitch = a.pitch;
     int off, ybase, zbase;      // region position q -> (y, z): Pq = q + off; y = ybase + Pq/pitch; z = zbase + Pq%pitch
-    int q_row[P];               // region position of this lane's voxel c16 of column tile p (voxel 16 + c16: + 16)
-    int out_vox0[P];            // in-plane voxel index of column 0 of tile p (the 32 columns are contiguous)
-    int tile_nvox[P];           // columns with out_vox0 + c < tile_nvox are inside the tile
+    int q_row[P];               // region position of this lane's voxel c16 of column tile p (voxel 16 + c16: + a.jstep)
+    int svox[P];                // in-plane index of the voxel this lane STORES for column tile p (column c16 + 16 (g & 1)
+                                // after the permlane transpose), -1: outside the tile
     // per-lane flags of voxel (p, j), bit 2p + j: on the z = 0 face (linear mode) | << 8: on the z = Zt-1 face | << 16:
     // inside the tile.  One VGPR instead of 3 x 2P lane masks (the COUT 128 variant spilled on those).
     unsigned vflags = 0;
@@ -715,8 +716,8 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                 vflags |= (unsigned)(vz == a.Zt - 1) << (8 + 2 * p + j);
                 if (j == 0) q_row[p] = v - off;
             }
-            out_vox0[p] = v0 + 32 * (wm * P + p);
-            tile_nvox[p] = a.Yt * a.Zt;
+            const int sv = v0 + 32 * (wm * P + p) + c16 + 16 * (g & 1);
+            svox[p] = sv < a.Yt * a.Zt ? sv : -1;
         }
     } else {
         const int TY = kPatch / a.TZ;
@@ -735,10 +736,23 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                 vflags |= (unsigned)(vy < a.Yt && vz < a.Zt) << (16 + 2 * p + j);
                 if (j == 0) q_row[p] = (yl + 1) * pitch + (zl + 1);
             }
-            // a column tile is one 32-voxel z segment of one line (TZ == 32)
-            const int ty = y0 + (32 * (wm * P + p)) / a.TZ;
-            out_vox0[p] = ty * a.Zt + zc0;
-            tile_nvox[p] = ty < a.Yt ? ty * a.Zt + a.Zt : 0;
+            // a column tile is one 32-voxel z segment of one line (TZ = 32) or two 16-voxel segments of two lines (TZ = 16)
+            const int svl = 32 * (wm * P + p) + c16 + 16 * (g & 1);
+            const int syl = svl / a.TZ, sy = y0 + syl, sz = zc0 + svl - syl * a.TZ;
+            svox[p] = (sy < a.Yt && sz < a.Zt) ? sy * a.Zt + sz : -1;
+        }
+    }
+
+    // Store box (Conv3Args.has_box, sk_conv3d_box / sk_conv3d_box_split): bit p = the voxel this lane STORES for column tile p
+    // (column c16 + 16 (g & 1) after the permlane transpose) lies inside the box in (y, z); the x test is wave-uniform
+    unsigned sboxm = ~0u;
+    if (a.has_box) {
+        sboxm = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int sv = max(svox[p], 0);
+            const int sy = sv / a.Zt, sz = sv - sy * a.Zt;
+            sboxm |= (unsigned)(sy >= a.box_lo[1] && sy < a.box_hi[1] && sz >= a.box_lo[2] && sz < a.box_hi[2]) << p;
         }
     }
 
@@ -771,7 +785,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
 
     const int xa = xc * a.XC;
     const int xb = min(xa + a.XC, a.Xt);
-    const int plane_bytes = (a.nposp + 1) * kPosBytes;  // + the zero position (never written by the DMA)
+    const int plane_bytes = (a.nposp + sk::kZeroPos) * kPosBytes;  // + the zero window (never written by the DMA)
     const int zero_addr = a.nposp * kPosBytes;
     // Plane reuse: when a phase multiplies the SAME chunk as the phase before it, one step further along x, the two
     // trailing planes of that chunk are still staged and only XS new planes are loaded (`reuse`); the slots rotate
@@ -895,8 +909,8 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) wres[r][d] = wload(wbase(0) + ((r * 3 + d) * NT) * 1024);
     }
-    if (tid < R * 4)
-        *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
+    if (tid < R * 4 * sk::kZeroPos)
+        *reinterpret_cast<uint4*>(lds + (tid / (4 * sk::kZeroPos)) * plane_bytes + zero_addr + (tid % (4 * sk::kZeroPos)) * 16) = make_uint4(0, 0, 0, 0);
     if constexpr (RES > 0 && WL > 0) {   // rows RES .. RES + WL - 1 of chunk 0: one copy per workgroup
         for (int i = tid; i < WL * 6 * 64; i += 256)
             *reinterpret_cast<uint4*>(lds + R * plane_bytes + i * 16) =
@@ -937,15 +951,15 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                 const int tapoff = (dydz / 3 - 1) * pitch + dz;
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    // the second voxel half sits 16 positions on: same swizzle term ((q + 16) >> 2 has the parity of
-                    // q >> 2), so its address is this one + 1 KiB
+                    // the second voxel half sits a.jstep positions on: 16 (the same row: same swizzle term, + 1 KiB) or,
+                    // for the 16-wide rectangle patches, one pitch (the next row)
                     const int q = q_row[p] + tapoff;
-                    const int base = (q * 4 + (g ^ (((q >> 2) & 1) << 1))) * 16;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        int addr = base + 1024 * j;
-                        if (dz < 0) addr = zlo(p, j) ? zero_addr : addr;
-                        if (dz > 0) addr = zhi(p, j) ? zero_addr : addr;
+                        const int qj = q + j * a.jstep;
+                        int addr = (qj * 4 + (g ^ (((qj >> 2) & 1) << 1))) * 16;
+                        if (dz < 0) addr = zlo(p, j) ? sk::zero_of(zero_addr, addr) : addr;
+                        if (dz > 0) addr = zhi(p, j) ? sk::zero_of(zero_addr, addr) : addr;
 #pragma unroll
                         for (int i = 0; i < R; ++i) {
                             const half8 bfr = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
@@ -977,12 +991,12 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                 auto load_row = [&](int dydz, half8 (&dst)[2][R]) {
                     const int dz = dydz % 3 - 1;
                     const int q = q_row[0] + (dydz / 3 - 1) * pitch + dz;
-                    const int base = (q * 4 + (g ^ (((q >> 2) & 1) << 1))) * 16;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        int addr = base + 1024 * j;
-                        if (dz < 0) addr = zlo(0, j) ? zero_addr : addr;
-                        if (dz > 0) addr = zhi(0, j) ? zero_addr : addr;
+                        const int qj = q + j * a.jstep;
+                        int addr = (qj * 4 + (g ^ (((qj >> 2) & 1) << 1))) * 16;
+                        if (dz < 0) addr = zlo(0, j) ? sk::zero_of(zero_addr, addr) : addr;
+                        if (dz > 0) addr = zhi(0, j) ? sk::zero_of(zero_addr, addr) : addr;
 #pragma unroll
                         for (int i = 0; i < R; ++i) dst[j][i] = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
                     }
@@ -1103,7 +1117,6 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
             const __amdgpu_buffer_rsrc_t rout = sk::make_rsrc(outw, (unsigned)(XS * out_plane));
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int tile_vox0 = out_vox0[p];  // in-plane index of the tile's first voxel
 #pragma unroll
                 for (int o = 0; o < XS; ++o) {
                     const int x = x0 + o;
@@ -1151,10 +1164,10 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                             // this lane now owns channels 16 i + 8 (g >> 1) .. +7 of voxel c16 + 16 (g & 1)
                             const uint4 line = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                             if (!SK_ABL(a, 4)) {
-                                const int vv = c16 + 16 * (g & 1);
-                                char* op = outb + (long long)x * out_plane + (long long)tile_vox0 * kOvs + wn * 64 + part * (COUT * 2);
-                                const bool sok = x < xb && tile_vox0 + vv < tile_nvox[p];
-                                char* dst = op + (long long)vv * kOvs + 32 * i + 16 * (g >> 1);
+                                const bool xbox = !a.has_box || (x >= a.box_lo[0] && x < a.box_hi[0]);   // wave-uniform
+                                const bool sok = x < xb && xbox && ((sboxm >> p) & 1u) && svox[p] >= 0;
+                                char* dst = outb + (long long)x * out_plane + (long long)svox[p] * kOvs + wn * 64 + part * (COUT * 2) +
+                                            32 * i + 16 * (g >> 1);
                                 // always issued (the counted wait relies on it); a masked lane's offset is out of range: dropped
                                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                                 const u32x4 lv = {line.x, line.y, line.z, line.w};
@@ -1843,8 +1856,15 @@ __global__ void __launch_bounds__(256) gather_gemm_kernel(GatherArgs a) {
             const float ga[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};                     \
             const float gb[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};                     \
             _Pragma("unroll") for (int p = 0; p < PV; ++p) _Pragma("unroll") for (int j = 0; j < 8; ++j) {    \
-                float y = fmaf(ga[j], (float)bv[p][j], gb[j]);                                                \
-                bv[p][j] = sk::round_t16(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));                         \
+                if constexpr (SPLIT) { /* gn_silu_split_kernel's arithmetic, op for op: activate hi + lo, split again */ \
+                    const float y = fmaf(ga[j], (float)bv[p][j] + (float)bvl[p][j], gb[j]);                   \
+                    const float sv = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));                            \
+                    bv[p][j] = sk::round_t16(sv);                                                             \
+                    bvl[p][j] = (t16)(sv - (float)bv[p][j]);                                                  \
+                } else {                                                                                      \
+                    float y = fmaf(ga[j], (float)bv[p][j], gb[j]);                                            \
+                    bv[p][j] = sk::round_t16(y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)));                   \
+                }                                                                                             \
             }                                                                                                 \
         }                                                                                                     \
         _Pragma("unroll") for (int p = 0; p < PV; ++p) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {    \
@@ -2158,6 +2178,243 @@ __global__ void __launch_bounds__(256, 2) down2_act_kernel(DownArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// down2_act_split_kernel (round 4): down2_act_kernel for precision = "split".
+//
+// Tensors hold [hi (C) | lo (C)] fp16 pairs per voxel line (value = hi + lo), the weight comes as all hi fragments
+// followed by all lo fragments (sk_conv3d_pack_weight_split_host, ksize 2), a K step is three MFMAs -- w_lo x_hi,
+// w_hi x_lo, w_hi x_hi -- exactly as in gather_gemm_kernel<.., SPLIT>, which ran these layers until round 3 behind a
+// separate gn_silu_split pass over the skip tensor (read + write of 14.7 GB per 64 production tiles for enc0.1's
+// output).  Here the RAW tensor comes in and is activated while it is staged, as in down2_act_kernel:
+//   * a staged row = the two z-adjacent input voxels of an output voxel = 2 x [hi | lo] = RB = 8 CIN bytes (256 | 512);
+//     a stage buffer (one (dx, dy)) holds NV = 32 KiB / RB rows; a workgroup runs kSub such sub-blocks one after the
+//     other so that it owns the same 256 | 128 output voxels as a down2_act_kernel workgroup (same partial-sum rows:
+//     sk_conv3d_num_blocks);
+//   * 16-byte chunk c of row n sits at chunk slot c ^ (n & 15): every 16-lane group of the B-fragment reads (16
+//     consecutive rows, one chunk index) covers the 64 banks for 256-byte rows (once) and for 512-byte rows;
+//   * the hi chunk and the lo chunk of the same 8 channels of a voxel are CPH chunk slots apart in the SAME row, i.e.
+//     staged by lanes l and l ^ CPH of the same LDS-DMA instruction: after its own counted vmcnt wait a lane reads both
+//     (no barrier), computes silu(a (hi + lo) + b) with gn_silu_split_kernel's arithmetic, op for op, and writes back
+//     the half it staged -- hi' = fp16(s) or lo' = fp16(s - hi') -- to LDS and to the tensor (the decoder's skip conv
+//     reads it activated).  Both lanes of a pair evaluate the same expression: the kernel is bound by its HBM stream.
+// ------------------------------------------------------------------------------------------
+template <int COUT, int CIN>
+__global__ void __launch_bounds__(256, 2) down2_act_split_kernel(DownArgs a) {
+    constexpr int NT = COUT / 32;
+    constexpr int VB = 4 * CIN;                // bytes per voxel line [hi | lo]
+    constexpr int RB = 2 * VB;                 // bytes per staged row (256 | 512)
+    constexpr int CPR = RB / 16;               // chunks per row (16 | 32)
+    constexpr int CPV = VB / 16;               // chunks per voxel (8 | 16)
+    constexpr int CPH = CPV / 2;               // chunks per half: the hi / lo partner of a chunk is CPH slots away (4 | 8)
+    constexpr int NV = 32768 / RB;             // output voxels per sub-block (128 | 64)
+    constexpr int kSub = 2;                    // sub-blocks per workgroup: 256 | 128 output voxels, as down2_act_kernel
+    constexpr int WN = NT / 2;                 // wave groups along cout (1 | 2)
+    constexpr int NTW = NT / WN;               // cout tiles per wave (2)
+    constexpr int PV = (NV / 32) / (4 / WN);   // column tiles per wave (1)
+    constexpr int NKS = CIN / 16;              // K steps per input voxel and half
+    constexpr int kStage = 32768;
+    constexpr int kOvs = COUT * 4;             // bytes per output voxel line [hi | lo]
+    static_assert((CIN == 32 && COUT == 64) || (CIN == 64 && COUT == 128), "the two stride-2 layers of the network");
+    static_assert(PV == 1 && NTW == 2, "one column tile, two cout tiles per wave");
+    extern __shared__ __attribute__((aligned(16))) char dlds[];   // [2][32 KiB] stages + 4 epilogue pads
+    __shared__ float red[4 * 2 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int wn = w % WN, wm = w / WN;
+    const int b = blockIdx.x / a.nblk, blk = blockIdx.x % a.nblk;
+    const int Yi = 2 * a.Yo, Zi = 2 * a.Zo;
+    const long long nvox = (long long)a.Xo * a.Yo * a.Zo;
+    char* inb = a.in + (long long)b * 8 * nvox * VB;
+    char* outb = a.out + (long long)b * nvox * kOvs;
+    const bool raw = a.affine != nullptr;
+    const char* wlo = a.wpk + (long long)(8 * NKS) * NT * 1024;   // the lo fragments follow the 8 taps x NKS hi steps
+
+    // this thread's slots of a stage: slot = tid + 256 j -> row n_j = tid / CPR + (256 / CPR) j, chunk slot cs = tid % CPR
+    const int cs = tid % CPR;
+    auto row_of = [&](int j) { return tid / CPR + (256 / CPR) * j; };
+    auto csrc_of = [&](int j) { return cs ^ (row_of(j) & 15); };   // source chunk of slot j (swizzle on the source side)
+    float ga[8], gb[8];
+    if (raw) {
+        const int c0 = (csrc_of(0) % CPH) * 8;   // the 8 channels of this thread's chunks: the same for every j, hi or lo
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ga[j] = a.affine[(long long)b * 2 * CIN + c0 + j];
+            gb[j] = a.affine[(long long)b * 2 * CIN + CIN + c0 + j];
+        }
+    }
+    float gsum[NTW][4], gsq[NTW][4];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gsum[nt][q] = gsq[nt][q] = 0.0f;
+    char* pad = dlds + 2 * kStage + w * kPadBytes;
+    const int rv = lane >> 2, rc = lane & 3;
+
+    for (int sub = 0; sub < kSub; ++sub) {
+        const long long v0 = ((long long)blk * kSub + sub) * NV;
+        if (v0 >= nvox) break;   // block-uniform
+        long long vin[8];        // input voxel index of tap (0, 0, 0) of row n_j, or -1 beyond the tensor
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long v = v0 + row_of(j);
+            if (v < nvox) {
+                const int zo = (int)(v % a.Zo);
+                const long long t = v / a.Zo;
+                const int yo = (int)(t % a.Yo), xo = (int)(t / a.Yo);
+                vin[j] = ((long long)(2 * xo) * Yi + 2 * yo) * Zi + 2 * zo;
+            } else {
+                vin[j] = -1;
+            }
+        }
+        auto issue_stage = [&](int st) {
+            const long long toff = ((long long)(st >> 1) * Yi + (st & 1)) * Zi;   // (dx, dy)
+            char* lbase = dlds + (st & 1) * kStage;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const char* g = vin[j] >= 0 ? inb + (vin[j] + toff) * VB + csrc_of(j) * 16 : a.zeros + lane * 16;
+                dma16(g, lbase + (w + 4 * j) * 1024);
+            }
+        };
+        f32x16 acc[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + 32 * (NTW * wn + nt) + 8 * q + 4 * h);
+                acc[nt][4 * q] = bv[0];
+                acc[nt][4 * q + 1] = bv[1];
+                acc[nt][4 * q + 2] = bv[2];
+                acc[nt][4 * q + 3] = bv[3];
+            }
+        // weight fragments one K step ahead: [buffer][cout tile][hi | lo]
+        half8 wf[2][NTW][2];
+        auto wload = [&](int s, half8 (&dst)[NTW][2]) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const long long off = ((long long)s * NT + NTW * wn + nt) * 1024 + lane * 16;
+                dst[nt][0] = *reinterpret_cast<const half8*>(a.wpk + off);
+                dst[nt][1] = *reinterpret_cast<const half8*>(wlo + off);
+            }
+        };
+        __syncthreads();   // the previous sub-block's epilogue pads / stage buffers are free
+        issue_stage(0);
+        for (int st = 0; st < 4; ++st) {
+            if (st + 1 < 4) {
+                issue_stage(st + 1);   // its buffer was last read by stage st - 1's MFMAs: the closing barrier below
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // everything older than those 8 pieces has landed
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            wload(st * 2 * NKS, wf[0]);
+            char* buf = dlds + (st & 1) * kStage;
+            if (raw) {
+                const long long toff = ((long long)(st >> 1) * Yi + (st & 1)) * Zi;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int slot = tid + 256 * j;
+                    half8* lp = reinterpret_cast<half8*>(buf + slot * 16);
+                    const half8 own = *lp;
+                    const half8 oth = *reinterpret_cast<const half8*>(buf + (slot ^ CPH) * 16);
+                    const int csrc = csrc_of(j);
+                    const bool is_lo = (csrc / CPH) & 1;
+                    half8 r;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {   // gn_silu_split_kernel's arithmetic, op for op
+                        const float vh = is_lo ? (float)oth[e] : (float)own[e];
+                        const float vl = is_lo ? (float)own[e] : (float)oth[e];
+                        const float y = fmaf(ga[e], vh + vl, gb[e]);
+                        const float sv = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+                        const t16 rh = sk::round_t16(sv);
+                        const t16 rl = (t16)(sv - (float)rh);
+                        r[e] = is_lo ? rl : rh;
+                    }
+                    *lp = r;
+                    if (a.writeback && vin[j] >= 0)
+                        *reinterpret_cast<half8*>(inb + (vin[j] + toff) * VB + csrc * 16) = r;
+                }
+            }
+            __syncthreads();
+            // K steps of the stage: (dz, ks); weight step index = st * 2 NKS + dz * NKS + ks
+            const int n = 32 * wm + col;
+            const char* rowp = buf + n * RB;
+            const int sw = n & 15;
+#pragma unroll
+            for (int k = 0; k < 2 * NKS; ++k) {
+                if (k + 1 < 2 * NKS) wload(st * 2 * NKS + k + 1, wf[(k + 1) & 1]);
+                const int dz = k / NKS, ks = k % NKS;
+                const int chi = dz * CPV + 2 * ks + h, clo = chi + CPH;
+                const half8 bh = *reinterpret_cast<const half8*>(rowp + ((chi ^ sw) * 16));
+                const half8 bl = *reinterpret_cast<const half8*>(rowp + ((clo ^ sw) * 16));
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    acc[nt] = SK_MFMA_32x32x16_T16(wf[k & 1][nt][1], bh, acc[nt], 0, 0, 0);
+                    acc[nt] = SK_MFMA_32x32x16_T16(wf[k & 1][nt][0], bl, acc[nt], 0, 0, 0);
+                    acc[nt] = SK_MFMA_32x32x16_T16(wf[k & 1][nt][0], bh, acc[nt], 0, 0, 0);
+                }
+            }
+            __syncthreads();   // stage buffer free for the DMA of stage st + 2
+        }
+
+        // ---- epilogue: hi then lo halves through the per-wave pad, 16-byte stores; statistics of the fp32 accumulators
+        const long long vbase = v0 + (long long)wm * 32;
+        const bool okp = vbase + col < nvox;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x0 = acc[nt][4 * q], x1 = acc[nt][4 * q + 1];
+                    const float x2 = acc[nt][4 * q + 2], x3 = acc[nt][4 * q + 3];
+                    half4 hv = {(t16)x0, (t16)x1, (t16)x2, (t16)x3};
+                    if (part == 1)
+                        hv = half4{(t16)(x0 - (float)hv[0]), (t16)(x1 - (float)hv[1]), (t16)(x2 - (float)hv[2]),
+                                   (t16)(x3 - (float)hv[3])};
+                    *reinterpret_cast<half4*>(pad + col * kPadStride + ((q ^ ((col >> 1) & 3)) * 16) + 8 * h) = hv;
+                    if (part == 0 && okp) {
+                        gsum[nt][q] += (x0 + x1) + (x2 + x3);
+                        gsq[nt][q] += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
+                    }
+                }
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int vv = rv + 16 * hh;
+                    const half8 line = *reinterpret_cast<const half8*>(pad + vv * kPadStride + ((rc ^ ((vv >> 1) & 3)) * 16));
+                    const long long v = vbase + vv;
+                    if (v < nvox) *reinterpret_cast<half8*>(outb + v * kOvs + part * (COUT * 2) + (NTW * wn + nt) * 64 + rc * 16) = line;
+                }
+            }
+        }
+    }
+    if (a.partial) {
+        // red[wave][quad of the wave's NTW cout tiles][2]; quad Q of the block = 8 * (NTW * wn + nt) + 2 q + h
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float s = gsum[nt][q], ss = gsq[nt][q];
+#pragma unroll
+                for (int m = 16; m > 0; m >>= 1) {
+                    s += __shfl_xor(s, m);
+                    ss += __shfl_xor(ss, m);
+                }
+                if (col == 0) {
+                    const int quad = 8 * nt + 2 * q + h;
+                    red[(w * (NTW * 8) + quad) * 2 + 0] = s;
+                    red[(w * (NTW * 8) + quad) * 2 + 1] = ss;
+                }
+            }
+        __syncthreads();
+        if (tid < NT * 16) {
+            const int g = tid / (NTW * 16), e = tid % (NTW * 16);   // cout wave group, (local quad, sum | sumsq)
+            float t = 0.0f;
+#pragma unroll
+            for (int m = 0; m < 4 / WN; ++m) t += red[(m * WN + g) * (NTW * 16) + e];   // waves with wn == g, fixed order
+            a.partial[((long long)b * a.nblk + blk) * (NT * 16) + tid] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side planning
 // ------------------------------------------------------------------------------------------
 struct Plan {
@@ -2178,16 +2435,22 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
         p.npatch = (int)((nv + kPatch - 1) / kPatch);
         p.nposp = (kPatch + 2 * Zt + 2 + 15) / 16 * 16;  // 128 voxels + one row and one voxel on each side
     } else {
+        // Rectangle patches TY x TZ with a one-voxel halo.  COUT 32 (conv3_m16_kernel, round 4): 8 x 16 -- a 16-column MFMA
+        // operand is one z segment of one row, the region is 10 x 18 = 180 positions instead of 6 x 34 = 204, and a
+        // six-plane ring (XS = 4) fits two workgroups per CU (round 1-3: 4 x 32 rectangles, 208 positions, XS = 3 at
+        // +13-20 % time).  COUT 64 / 128 (conv3_kernel, 32-column operands): 4 x 32.
         p.mode = 1;
-        p.TZ = 32;
-        p.nzc = (Zt + 31) / 32;
+        p.TZ = cout == 32 ? 16 : 32;
+        p.nzc = (Zt + p.TZ - 1) / p.TZ;
         p.pitch = p.TZ + 2;
         int TY = kPatch / p.TZ;
         p.npatch = ((Yt + TY - 1) / TY) * p.nzc;
         p.nposp = ((TY + 2) * p.pitch + 15) / 16 * 16;
     }
     if (p.nposp > 64 * kMaxDma) return -1;
-    p.lds = (size_t)(p.xs + 2) * (p.nposp + 1) * kPosBytes + 4 * kPadBytes;
+    // the 16x16x32 kernels (COUT 32) transpose their results with v_permlane16_swap: no LDS pads
+    const size_t pads = cout == 32 ? 0 : 4 * kPadBytes;
+    p.lds = (size_t)(p.xs + 2) * (p.nposp + sk::kZeroPos) * kPosBytes + pads;
     // Two workgroups per CU need <= 80 KiB each.  The rectangle patches (208 positions a plane) miss that with a
     // 6-plane ring: run them with XS = 3 (5 planes); measured on the 512x512x128 tile (SK_CONV_RECT_XS4=1 to compare).
     bool keep_xs4 = false;
@@ -2196,7 +2459,7 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
 #endif
     if (p.xs == 4 && p.lds > 80 * 1024 && !keep_xs4) {
         p.xs = 3;
-        p.lds = (size_t)(p.xs + 2) * (p.nposp + 1) * kPosBytes + 4 * kPadBytes;
+        p.lds = (size_t)(p.xs + 2) * (p.nposp + sk::kZeroPos) * kPosBytes + pads;
     }
     // x-chunks: enough workgroups to fill the CUs (2 per CU) several times over at the batch sizes the pipeline runs
     // (8-32 tiles).  The cut is a function of the tile geometry ONLY, not of B: the GroupNorm partial sums are fp32 sums
@@ -2231,8 +2494,7 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
 template <int XS, int RES = 0, bool SPLIT = false, int WL = 0>
 int launch_conv3_m16(const Conv3Args& a, const Plan& p, hipStream_t stream) {
     auto kern = conv3_m16_kernel<32, XS, RES, SPLIT, WL>;
-    size_t lds = p.lds;
-    if (RES > 0 && WL > 0) lds = p.lds - 4 * kPadBytes + WL * 6144;   // this kernel has no transpose pads
+    const size_t lds = p.lds + (RES > 0 ? WL * 6144 : 0);   // the ring + the tap rows kept in LDS behind it
     if (lds > 48 * 1024)
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
@@ -2346,7 +2608,8 @@ int64_t sk_conv3d_pack_weight_host(const float* w, int cout, int cin, int ksize,
 }
 
 static int launch_down2(const void* in, const float* affine, int writeback, const void* weight, const float* bias, void* out,
-                        int B, int ox, int oy, int oz, int cin, int cout, float* gn_partial, void* zeros, hipStream_t stream) {
+                        int B, int ox, int oy, int oz, int cin, int cout, float* gn_partial, void* zeros, hipStream_t stream,
+                        bool split = false) {
     SK_CHECK_ARG(in && weight && bias && out && zeros, "down conv: NULL pointer (the zero page is required)");
     SK_CHECK_ARG((cin == 32 && cout == 64) || (cin == 64 && cout == 128), "down conv: (cin, cout) must be (32, 64) or (64, 128)");
     SK_CHECK_ARG(!writeback || affine, "down conv: write-back needs the affine of the raw input");
@@ -2366,7 +2629,17 @@ static int launch_down2(const void* in, const float* affine, int writeback, cons
     a.nblk = sk_conv3d_num_blocks(B, ox, oy, oz, cout, 2);   // 256 (cout 64) / 128 (cout 128) voxels per block: NV
     const int lds = 2 * 32768 + 4 * kPadBytes;
     const unsigned grid = (unsigned)(a.nblk * B);
-    if (cin == 32) {
+    if (split) {
+        if (cin == 32) {
+            auto kern = down2_act_split_kernel<64, 32>;
+            SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            kern<<<grid, 256, lds, stream>>>(a);
+        } else {
+            auto kern = down2_act_split_kernel<128, 64>;
+            SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            kern<<<grid, 256, lds, stream>>>(a);
+        }
+    } else if (cin == 32) {
         auto kern = down2_act_kernel<64, 32>;
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         kern<<<grid, 256, lds, stream>>>(a);
@@ -2456,6 +2729,7 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
         a.nzc = p.nzc;
         a.pitch = p.pitch;
         a.nposp = p.nposp;
+        a.jstep = (p.mode == 1 && p.TZ == 16) ? p.pitch : 16;
         // two-chunk layers only: with four chunks the reuse is 1/12 of the loads and measured +1.6 % time (COUT 128);
         // split mode: the chunk triples carry their own reuse flags
         a.alt = (!split && a.nchunks == 2) ? 1 : 0;
@@ -2468,13 +2742,8 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
 #ifdef SK_TUNING
         if (const char* e = getenv("SK_CONV_ABLATE")) a.ablate = atoi(e);
 #endif
-        if (split) {
-            if (cout == 32) return p.xs == 3 ? launch_conv3_m16<3, 0, true>(a, p, stream) : launch_conv3_m16<4, 0, true>(a, p, stream);
-            if (cout == 64) return p.xs == 3 ? launch_conv3<64, 3, 0, true>(a, p, stream) : launch_conv3<64, 4, 0, true>(a, p, stream);
-            return launch_conv3<128, 2, 0, true>(a, p, stream);
-        }
         a.has_box = 0;
-        if (store_box) {
+        if (store_box && cout == 32) {   // honoured by the COUT-32 kernels (conv3_px_kernel, conv3_m16_kernel); wider layers store everything
             for (int k = 0; k < 3; ++k) {
                 a.box_lo[k] = store_box[k];
                 a.box_hi[k] = store_box[3 + k];
@@ -2482,16 +2751,21 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
             }
             a.has_box = 1;
         }
+        if (split) {
+            if (cout == 32) return p.xs == 3 ? launch_conv3_m16<3, 0, true>(a, p, stream) : launch_conv3_m16<4, 0, true>(a, p, stream);
+            if (cout == 64) return p.xs == 3 ? launch_conv3<64, 3, 0, true>(a, p, stream) : launch_conv3<64, 4, 0, true>(a, p, stream);
+            return launch_conv3<128, 2, 0, true>(a, p, stream);
+        }
         bool use_px = cout == 32 && a.nchunks == 1 && n_src == 1 && !srcs[0].upsample && conv3_px_covers(p, oz, a.act[0] != nullptr);
 #ifdef SK_TUNING
         if (getenv("SK_CONV_NO_PX")) use_px = false;   // A/B: the single-chunk COUT-32 layers on conv3_m16_kernel
 #endif
         if (use_px) return launch_conv3_px(a, p, stream);
-        a.has_box = 0;   // the other kernels store the whole tile (a superset of any box)
         if (cout == 32) {   // 16x16x32 kernel
             if (p.xs == 3) return launch_conv3_m16<3>(a, p, stream);
             if (a.nchunks == 1 && !a.ablate) {   // single chunk: 3 tap rows in registers, 2 more in LDS where they fit
-                if (p.lds - 4 * kPadBytes + 2 * 6144 <= 80 * 1024) return launch_conv3_m16<4, 3, false, 2>(a, p, stream);
+                if (p.lds + 2 * 6144 <= 80 * 1024) return launch_conv3_m16<4, 3, false, 2>(a, p, stream);
+                if (p.lds + 1 * 6144 <= 80 * 1024) return launch_conv3_m16<4, 3, false, 1>(a, p, stream);   // the 8 x 16 rectangles
                 return launch_conv3_m16<4, 3>(a, p, stream);
             }
             return launch_conv3_m16<4>(a, p, stream);
@@ -2502,7 +2776,6 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
     SK_CHECK_ARG(ksize == 1 || ksize == 2, "sk_conv3d: ksize must be 1, 2 or 3");
     SK_CHECK_ARG(n_src == 1 && !srcs[0].upsample, "sk_conv3d: ksize %d takes one plain source", ksize);
     SK_CHECK_ARG(srcs[0].c % 16 == 0, "sk_conv3d: cin must be a multiple of 16");
-    SK_CHECK_ARG(!split || srcs[0].affine == nullptr, "sk_conv3d_split: sources must be activated (affine NULL)");
     if (!split && ksize == 2 && ((srcs[0].c == 32 && cout == 64) || (srcs[0].c == 64 && cout == 128)))
         return launch_down2(srcs[0].data, srcs[0].affine, 0, weight, bias, out, B, ox, oy, oz, srcs[0].c, cout, gn_partial,
                             zeros, stream);
@@ -2560,10 +2833,23 @@ int sk_conv3d_box(const sk_conv_src* srcs, int n_src, const void* weight, const 
     return conv3d_impl(srcs, n_src, weight, bias, out, B, ox, oy, oz, cout, ksize, gn_partial, zeros, stream, false, store_box);
 }
 
+int sk_conv3d_box_split(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,
+                        int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial,
+                        void* zeros, const int* store_box, void* stream) {
+    SK_CHECK_ARG(ksize == 3 || store_box == nullptr, "sk_conv3d_box_split: a store box needs ksize 3");
+    return conv3d_impl(srcs, n_src, weight, bias, out, B, ox, oy, oz, cout, ksize, gn_partial, zeros, stream, true, store_box);
+}
+
 int sk_conv3d_down_act(void* in_raw, const float* affine, const void* weight, const float* bias, void* out, int B,
                        int ox, int oy, int oz, int cin, int cout, float* gn_partial, void* zeros, void* stream) {
     SK_CHECK_ARG(affine, "sk_conv3d_down_act: affine is NULL (use sk_conv3d for an activated input)");
     return launch_down2(in_raw, affine, 1, weight, bias, out, B, ox, oy, oz, cin, cout, gn_partial, zeros, (hipStream_t)stream);
+}
+
+int sk_conv3d_down_act_split(void* in_raw, const float* affine, const void* weight, const float* bias, void* out, int B,
+                             int ox, int oy, int oz, int cin, int cout, float* gn_partial, void* zeros, void* stream) {
+    SK_CHECK_ARG(affine, "sk_conv3d_down_act_split: affine is NULL (use sk_conv3d_split for an activated input)");
+    return launch_down2(in_raw, affine, 1, weight, bias, out, B, ox, oy, oz, cin, cout, gn_partial, zeros, (hipStream_t)stream, true);
 }
 
 int sk_conv3d_split(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,

@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
     const int xa = xc * a.XC;
     const int xb = min(xa + a.XC, a.Xt);
     const int Xl = a.Xt >> 1;
-    const int plane_bytes = (a.nposp + 1) * kPosBytes;
+    const int plane_bytes = (a.nposp + sk::kZeroPos) * kPosBytes;
     const int zero_addr = a.nposp * kPosBytes;   // never written by either image's DMA (nposl <= nposp)
     const long long out_plane = (long long)a.Yt * Zt * a.out_vs;
     char* outb = a.out + (long long)b * a.Xt * out_plane;
@@ -274,8 +274,8 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
         load_af(wbase_up(cu), 1, wq1);
     };
 
-    if (tid < R * 4)
-        *reinterpret_cast<uint4*>(lds + (tid >> 2) * plane_bytes + zero_addr + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
+    if (tid < R * 4 * sk::kZeroPos)
+        *reinterpret_cast<uint4*>(lds + (tid / (4 * sk::kZeroPos)) * plane_bytes + zero_addr + (tid % (4 * sk::kZeroPos)) * 16) = make_uint4(0, 0, 0, 0);
     if constexpr (WLDS) {
         for (int i = tid; i < 12 * 64; i += 256)
             *reinterpret_cast<uint4*>(lds + R * plane_bytes + i * 16) = *reinterpret_cast<const uint4*>(a.wpk + i * 16);
@@ -316,8 +316,8 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
                 const int tapoff = ((Y & 1) * 2 + (Z & 1)) * a.SUBP + 1 + (Y >= 1 ? Zl : 0) + (Z >> 1);   // Z >> 1: floor
                 const int q = c16v + tapoff;
                 int addr = (q * 4 + (g ^ (((q >> 2) & 1) << 1))) * 16 + 1024 * j;   // (q + 16) >> 2 has the parity of q >> 2
-                if (dz < 0) addr = zlo(j) ? zero_addr : addr;
-                if (dz > 0) addr = zhi(j) ? zero_addr : addr;
+                if (dz < 0) addr = zlo(j) ? sk::zero_of(zero_addr, addr) : addr;
+                if (dz > 0) addr = zhi(j) ? sk::zero_of(zero_addr, addr) : addr;
 #pragma unroll
                 for (int i = 0; i < R; ++i) dst[i] = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
             };
@@ -399,8 +399,8 @@ __global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
                 const int sy = (tytz >> 1) + py - 1, sz = (tytz & 1) + pz - 1;   // low-resolution offsets of this tap
                 const int q = c16v + 1 + (1 + sy) * Zl + sz;
                 int addr = (q * 4 + (g ^ (((q >> 2) & 1) << 1))) * 16 + 1024 * j;
-                addr = (sz < 0 && zlo(j)) ? zero_addr : addr;
-                addr = (sz > 0 && zhi(j)) ? zero_addr : addr;
+                addr = (sz < 0 && zlo(j)) ? sk::zero_of(zero_addr, addr) : addr;
+                addr = (sz > 0 && zhi(j)) ? sk::zero_of(zero_addr, addr) : addr;
 #pragma unroll
                 for (int i = 0; i < RL; ++i) dst[i] = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
             };
@@ -560,7 +560,7 @@ int make_upf_plan(UpfPlan& p, int Xt, int Yt, int Zt) {
     p.nposp = (4 * p.SUBP + over + 15) / 16 * 16;
     p.nposl = ((p.K + 2) * Zl + 2 + over + 15) / 16 * 16;
     if (p.nposp > 64 * kMaxDma || p.nposl > 64 * kMaxDmaL || p.nposl > p.nposp) return -1;
-    p.lds = (size_t)6 * (p.nposp + 1) * kPosBytes;
+    p.lds = (size_t)6 * (p.nposp + sk::kZeroPos) * kPosBytes;
     if (p.lds > 80 * 1024) return -1;
     p.npatch = (Yl + p.K - 1) / p.K;
     // x-chunks as conv3d.hip's make_plan: a function of the tile geometry only (batch-invariant bits)

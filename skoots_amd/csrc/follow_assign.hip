@@ -379,7 +379,11 @@ int sk_follow_assign(const void* vec4, const void* labels, int label_dtype, int3
     long long total = (long long)X * Y * (z_hi - z_lo);
     SK_CHECK_ARG(total / 256 < 0x7fffffffLL, "sk_follow_assign: volume too large for one launch");
     const int zspan = z_hi - z_lo;
-    if (label_dtype == SK_I32 && zspan % 2 == 0 && (win_hi - win_lo) % 2 == 0 && (z_lo - win_lo) % 2 == 0 && Z % 2 == 0 &&
+    // The two-voxel kernel answers a zero-vector voxel with the label at its own position.  That equals the reference's
+    // fp32 arithmetic (vector_to_embedding.py:109-130) only while the crop-local flat index is exact in fp32, i.e. for
+    // crops of at most 2^24 voxels (the production crop: 12.5 M); above that the reference's rounded index may hop to a
+    // voxel with a non-zero vector, which only the one-voxel kernel reproduces.
+    if (label_dtype == SK_I32 && p.nvox <= (1LL << 24) && zspan % 2 == 0 && (win_hi - win_lo) % 2 == 0 && (z_lo - win_lo) % 2 == 0 && Z % 2 == 0 &&
         z_lo % 2 == 0 && X <= 65535 && ((uintptr_t)vec4 & 15) == 0 && ((uintptr_t)labels & 7) == 0 && ((uintptr_t)out & 7) == 0) {
         const bool tiled = zspan % 16 == 0;
         const long long waves = tiled ? (long long)((Y + 7) / 8) * (zspan / 16) : ((long long)Y * (zspan / 2) + 63) / 64;

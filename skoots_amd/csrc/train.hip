@@ -2040,7 +2040,11 @@ __global__ void __launch_bounds__(256) interleave2_kernel(const t16* __restrict_
 // 2x2x2 sum pooling under an upsampled source, the heads' data gradient): the consumer is a GroupNorm backward that
 // reads a scaled 16-bit dz as it is (gn_bwd_*16_kernel<true>), so the fp32 tensor cost 4 B/element written once and
 // read twice.  The output scale is a power of two derived from the INPUT scales, so that the result cannot overflow:
-// out_scale (3 floats, written by the kernel) = [s, 1/s, bound].
+// out_scale (3 floats, written by the kernel) = [s, 1/s, bound on |dx| or NaN].  Slot [2] is a bound only where the
+// producer knows one (gn_bwd_*16: the GroupNorm-backward reduction yields it; heads_dgrad_h_kernel: 2^13 / s by
+// construction).  The interleave and the pooling below only know the absmax of the dy their INPUT was derived from --
+// W^T dy can exceed it by sum |W| --, so they write NaN ("unknown"): a consumer that trusted a number there would
+// mis-scale silently, a NaN it cannot miss.  Today's consumers (gn_bwd_*16_kernel<true>) read [1] only.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) interleave2_h_kernel(const t16* __restrict__ tens16, t16* __restrict__ out16, int B, int cx,
                                                             int cy, int cz, int C, const float* __restrict__ scale,
@@ -2054,7 +2058,7 @@ __global__ void __launch_bounds__(256) interleave2_h_kernel(const t16* __restric
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         out_scale[0] = s_out;
         out_scale[1] = 1.0f / s_out;
-        out_scale[2] = scale[2] + (add16 ? add_scale[2] : 0.0f);
+        out_scale[2] = __builtin_nanf("");   // unknown: see above
     }
     const int nq = C / 8;
     const long long ncoarse = (long long)B * cx * cy * cz * C;
@@ -2090,7 +2094,7 @@ __global__ void __launch_bounds__(256) sumpool2_hh_kernel(const t16* __restrict_
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         out_scale[0] = scale[0] * 0.125f;
         out_scale[1] = scale[1] * 8.0f;
-        out_scale[2] = scale[2] * 8.0f;
+        out_scale[2] = __builtin_nanf("");   // unknown: see interleave2_h_kernel
     }
     const int nq = C / 8;
     const long long n = (long long)B * cx * cy * cz * nq;

@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(256) gn_silu_split_kernel(t16* __restrict__ x,
             const float xv = (float)vh[j] + (float)vl[j];
             const float y = fmaf(ga[j], xv, gb[j]);
             const float sv = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
-            rh[j] = (t16)sv;
+            rh[j] = sk::round_t16(sv);   // the product rounded to fp32 first: the same bits wherever this activation is fused
             rl[j] = (t16)(sv - (float)rh[j]);
         }
         ph[0] = rh;

@@ -119,19 +119,22 @@ def label_slab(skeleton_win: Tensor, shape, slab, window, slabs, rank: int, comm
     sk_seam_union instead of the host DFS.  When a capacity is exceeded the overflow flag comes back set and the caller
     (ShardedVolume.run, after the stage's timing synchronisation) repeats the stage with :func:`_label_slab_sync`;
     ``sparse=False`` (dense label gather) and PAIR_CAP <= 0 take that path directly."""
-    if sparse is False or PAIR_CAP <= 0:
+    X, Y, Z = shape
+    zmax = max(b - a for a, b in slabs)
+    nnz_cap = max(1 << 16, (X * Y * zmax) // NNZ_DIV)
+    # limits of the sync-free encoding: a (position << 32 | label) entry carries the global position in 32 bits (the
+    # padding entries point at position X*Y*Z, the spare slot), and the union's lookup table is indexed by int32
+    fits = X * Y * Z < (1 << 32) - 1 and len(slabs) * nnz_cap + 1 < (1 << 31)
+    if sparse is False or PAIR_CAP <= 0 or not fits:
         full, total = _label_slab_sync(skeleton_win, shape, slab, window, slabs, rank, comm, sparse=sparse, profile=profile)
         dev = skeleton_win.device
         return full, torch.tensor(total, dtype=torch.int64, device=dev), torch.zeros((), dtype=torch.bool, device=dev)
-    X, Y, Z = shape
     dev = skeleton_win.device
     st = _ffi.stream_ptr(dev)
     zlo, zhi = slab
     zl = zhi - zlo
     w0 = window[0]
     world = len(slabs)
-    zmax = max(b - a for a, b in slabs)
-    nnz_cap = max(1 << 16, (X * Y * zmax) // NNZ_DIV)
     local = torch.zeros((X, Y, skeleton_win.shape[2]), dtype=torch.int32, device=dev)
     ws_bytes = _ffi.lib.sk_ccl_workspace_bytes(X * Y * zl)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -171,16 +174,17 @@ def label_slab(skeleton_win: Tensor, shape, slab, window, slabs, rank: int, comm
     _ffi.check(_ffi.lib.sk_relabel_lut_offset(_ffi.ptr(mine), mine.numel(), _ffi.ptr(lut), lut_size,
                                               _ffi.ptr(offsets[rank:rank + 1]), st))
     # every rank needs the full label volume (a 10-step follow ends up to ~165 planes away): fixed-size lists of
-    # (global position << 32 | label), -1 past a rank's count
+    # (global position << 32 | label); the entries past a rank's count point at position X*Y*Z -- a spare slot -- with
+    # label 0.  The position is an UNSIGNED 32-bit field (2048x2048x512 has positions up to 2^31 - 1; `fits` above
+    # guards the field's width), so no entry is ever recognised by its sign.
     valid = torch.arange(nnz_cap, device=dev) < cnt
     p = torch.where(valid, pos, torch.zeros_like(pos))
     xy, zz = torch.div(p, zl, rounding_mode="floor"), p % zl
-    packed = torch.where(valid, ((xy * Z + zz + zlo) << 32) | mine.reshape(-1)[p].to(torch.int64), torch.full_like(p, -1))
+    packed = torch.where(valid, ((xy * Z + zz + zlo) << 32) | mine.reshape(-1)[p].to(torch.int64),
+                         torch.full_like(p, (X * Y * Z) << 32 if X * Y * Z < (1 << 31) else ((X * Y * Z) << 32) - (1 << 64)))
     full = torch.zeros(X * Y * Z + 1, dtype=torch.int32, device=dev)       # + one slot that swallows the padding entries
     for part in comm.all_gather(packed, what="label_gather"):
-        ok = part >= 0
-        full.index_put_((torch.where(ok, part >> 32, torch.full_like(part, X * Y * Z)),),
-                        torch.where(ok, part & 0xFFFFFFFF, torch.zeros_like(part)).to(torch.int32))
+        full.index_put_(((part >> 32) & 0xFFFFFFFF,), (part & 0xFFFFFFFF).to(torch.int32))
     return full[:X * Y * Z].view(X, Y, Z), offsets[-1], overflow
 
 

@@ -289,6 +289,47 @@ def exchange_blocks(arrays: Sequence[Tensor], blocks, windows, rank: int, comm: 
             at += v.numel()
 
 
+def comm_budget(shape: Sequence[int], world: int, tile=(300, 300, 20), tile_overlap=(50, 50, 5), halo: int = HALO,
+                pair_cap: Optional[int] = None, nnz_div: Optional[int] = None) -> List[Dict[str, object]]:
+    """What every rank of a ``world``-rank run SENDS per step, per exchange tag, computed from the plans alone (no device, no
+    process group) -- the numbers ``Comm.stats()`` / bench.py's ``multi_gpu.comm_rank0_per_step`` of a real run are read
+    against.  Per rank: ``tiles``; ``block_exchange`` (bytes: what its tiles write into other ranks' slabs -- 8 B of
+    interleaved vector + 1 B of skeleton per voxel; ``peers``); ``label_seam_planes`` (one int32 plane to the rank below);
+    ``label_meta`` and ``label_gather`` (the two fixed-size all-gathers of :func:`lib.flood_fill.label_slab`: bytes x
+    (world - 1) receivers); ``vector_halo`` (bytes, ``planes`` per neighbour: the planes its neighbours' stage-3 crops
+    reach, :func:`assign_reach`).  ``renumber_allreduce`` depends on the label count and is not planned."""
+    from .lib import flood_fill
+    from .lib.eval import ASSIGN_CROP, ASSIGN_OVERLAP
+    X, Y, Z = (int(v) for v in shape)
+    plan, eff = tile_plan(shape, tile, tile_overlap, world, halo=halo)
+    slabs = slab_bounds(Z, world)
+    windows = [window_of(s_, Z, world, halo) for s_ in slabs]
+    out = [{"tiles": len(p), "block_exchange": 0, "block_peers": set(), "label_seam_planes": 0, "label_meta": 0,
+            "label_gather": 0, "vector_halo": 0, "vector_halo_planes": {}} for p in plan]
+    if world == 1:
+        for o in out:
+            o["block_peers"] = []
+        return out
+    for src, dst, (x0, x1, y0, y1, z0, z1) in block_plan(shape, eff, tile_overlap, plan):
+        out[src]["block_exchange"] += (x1 - x0) * (y1 - y0) * (z1 - z0) * (8 + 1)
+        out[src]["block_peers"].add(dst)
+    pair_cap = flood_fill.PAIR_CAP if pair_cap is None else pair_cap
+    nnz_div = flood_fill.NNZ_DIV if nnz_div is None else nnz_div
+    zmax = max(b - a for a, b in slabs)
+    nnz_cap = max(1 << 16, (X * Y * zmax) // nnz_div)
+    needs = assign_reach(shape, ASSIGN_CROP, ASSIGN_OVERLAP, slabs, windows)
+    for r, o in enumerate(out):
+        o["block_peers"] = sorted(o["block_peers"])
+        o["label_seam_planes"] = X * Y * 4 if r > 0 else 0
+        o["label_meta"] = (4 + 2 * pair_cap) * 4 * (world - 1)
+        o["label_gather"] = nnz_cap * 8 * (world - 1)
+        sends, _ = halo_plan(slabs, needs, r)
+        for q, lo, hi in sends:
+            o["vector_halo"] += X * Y * (hi - lo) * 8
+            o["vector_halo_planes"][q] = hi - lo
+    return out
+
+
 MAX_TILE_BATCH = 64   # tiles per network launch the kernels' launch plans are built for
 
 
@@ -394,15 +435,19 @@ class ShardedVolume:
         elif tile_batch is None:
             tile_batch = MAX_TILE_BATCH
         self.tile_batch_used = tile_batch
-        if model is not None:   # the extra contexts (activation buffers of the second, third ... stream) live across calls
-            cache = self.__dict__.setdefault("_ctx_cache", {})
-            extra = cache.setdefault(id(model), [])
+        if model is not None:
+            # The extra contexts (activation buffers of the second, third ... stream) live ON THE MODEL across calls: they
+            # hold its layer objects, so they die with it (a cache keyed by id(model) here could hand a later model with a
+            # recycled id the old model's weights) and their buffers are freed when fewer streams are asked for.
+            extra = model.__dict__.setdefault("_stream_ctxs", [])
+            del extra[max(0, n_streams - 1):]
             while len(extra) < n_streams - 1:
                 extra.append(model.clone_context())
             for c in extra:   # same weights object; follow the switches of the primary
+                assert c.enc0 is model.enc0 and c.dec0 is model.dec0, "a stream context must share its model's layers"
                 c.precision, c.fold_upsample, c.box_store, c.defer_activation = (model.precision, model.fold_upsample,
                                                                                 model.box_store, model.defer_activation)
-            ctxs = [model] + extra[:n_streams - 1]
+            ctxs = [model] + extra
         else:
             ctxs = [None]
         for c in ctxs:

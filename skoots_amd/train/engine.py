@@ -83,8 +83,11 @@ class TrainUNet:
 
     def __init__(self, state_dict: Dict[str, Tensor], device="cuda:0",
                  dims: Sequence[int] = (32, 64, 128, 64, 32), depths: Sequence[int] = (2, 2, 2, 2, 2),
-                 precision: str = "fp32"):
-        """``precision``: "fp32" (every kernel fp32; the parity mode), "bf16" (below, on bf16 tensors and bf16 matrix
+                 precision: str = "fp32", f16_grad_handoff: bool = True):
+        """``f16_grad_handoff=False``: single-reader data gradients travel as fp32 copies instead of scaled 16-bit tensors
+        (the hand-off is lossy by one 16-bit rounding per tensor: parameter gradients move by ~1e-4 of the largest one).
+
+        ``precision``: "fp32" (every kernel fp32; the parity mode), "bf16" (below, on bf16 tensors and bf16 matrix
         instructions: BASELINE configs[4]'s dtype) or "mixed" (fp32 master weights, GroupNorm,
         loss and optimizer; the convolutions of the forward pass, the data gradients and the weight gradients
         on the fp16 MFMA kernels with fp32 accumulation, output gradients scaled per tensor by a power of
@@ -102,7 +105,7 @@ class TrainUNet:
         # A/B switches of the mixed step (tools/bench_train.py sets them; defaults = the fast choices)
         self.fast_stem = True          # stem as an fp16-operand fast block
         self.fast_heads = True         # heads straight on the fp16 activation
-        self.f16_grad_handoff = True   # single-reader fp16 data gradients handed on without an fp32 copy
+        self.f16_grad_handoff = bool(f16_grad_handoff)   # single-reader fp16 data gradients handed on without an fp32 copy
         # tests only: a list here makes backward() record, per fast block, copies of exactly the 16-bit tensors its kernels
         # read and wrote (sources, raw output, incoming gradient, dy, data gradients, scales) next to the parameter
         # gradients they produced, so that every kernel of the step can be replayed in torch ON THE SAME OPERANDS

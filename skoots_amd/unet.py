@@ -163,6 +163,7 @@ class HipUNet:
         other._bufs = {}
         other.last_features = {}
         other.profile = None
+        other.__dict__.pop("_stream_ctxs", None)   # the primary's list of contexts (parallel.ShardedVolume.run) is not the clone's
         return other
 
     # -- reference-compatible construction ---------------------------------------------
@@ -240,9 +241,10 @@ class HipUNet:
             _ffi.check(ufn(arr[0].data, arr[0].c, arr[1].data, arr[1].c,
                            _ffi.ptr(layer.packed_upfold(arr[0].c, split)), _ffi.ptr(layer.bias), _ffi.ptr(out),
                            B, ox, oy, oz, layer.cout, _ffi.ptr(partial), _ffi.stream_ptr(self.device)))
-        elif store_box is not None and not split and layer.ksize == 3 and not activate:
+        elif store_box is not None and layer.ksize == 3 and not activate:
             box = (C.c_int32 * 6)(*[int(v) for v in store_box[0]], *[int(v) for v in store_box[1]])
-            _ffi.check(_ffi.lib.sk_conv3d_box(arr, len(srcs), _ffi.ptr(layer.packed(False)), _ffi.ptr(layer.bias),
+            bfn = _ffi.lib.sk_conv3d_box_split if split else _ffi.lib.sk_conv3d_box
+            _ffi.check(bfn(arr, len(srcs), _ffi.ptr(layer.packed(split)), _ffi.ptr(layer.bias),
                                               _ffi.ptr(out), B, ox, oy, oz, layer.cout, layer.ksize,
                                               _ffi.ptr(partial), _ffi.ptr(self.zeros), box, _ffi.stream_ptr(self.device)))
         else:
@@ -253,8 +255,9 @@ class HipUNet:
         if timed:
             e1.record(torch.cuda.current_stream(self.device))
             self.profile.events.append((e0, e1, layer.flops_per_out_voxel * B * ox * oy * oz, layer.name))
-            per_voxel = 2.0 * layer.cout * (arr[0].c * 27 + arr[1].c * 8) if fold else layer.flops_per_out_voxel   # x3 in split mode: bench.py
-            self.profile.executed_flops += per_voxel * B * ox * oy * oz
+            per_voxel = 2.0 * layer.cout * (arr[0].c * 27 + arr[1].c * 8) if fold else layer.flops_per_out_voxel
+            # split mode: three fp16 MFMA products (w_lo x_hi, w_hi x_hi, w_hi x_lo) per algorithmic product
+            self.profile.executed_flops += per_voxel * B * ox * oy * oz * (3 if split else 1)
         aff = self._norm_act(layer, out, partial, nblk, apply=activate)
         return out if activate else (out, aff)
 
@@ -269,12 +272,14 @@ class HipUNet:
             return out if want_raw else (out, None)
         B = t.shape[0]
         ox, oy, oz = out_shape
-        out = self._buf(tag, (B, ox, oy, oz, layer.cout))
+        split = self.split
+        out = self._buf(tag, (B, ox, oy, oz, layer.cout * (2 if split else 1)))
         nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, layer.cout, 2)
         partial = self._buf("partial", (B * nblk * (layer.cout // 4) * 2,), torch.float32)
-        _ffi.check(_ffi.lib.sk_conv3d_down_act(_ffi.ptr(t), _ffi.ptr(aff), _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
-                                               _ffi.ptr(out), B, ox, oy, oz, layer.cin, layer.cout, _ffi.ptr(partial),
-                                               _ffi.ptr(self.zeros), _ffi.stream_ptr(self.device)))
+        fn = _ffi.lib.sk_conv3d_down_act_split if split else _ffi.lib.sk_conv3d_down_act
+        _ffi.check(fn(_ffi.ptr(t), _ffi.ptr(aff), _ffi.ptr(layer.packed(split)), _ffi.ptr(layer.bias),
+                      _ffi.ptr(out), B, ox, oy, oz, layer.cin, layer.cout, _ffi.ptr(partial),
+                      _ffi.ptr(self.zeros), _ffi.stream_ptr(self.device)))
         aff_out = self._norm_act(layer, out, partial, nblk, apply=not want_raw)
         return (out, aff_out if want_raw else None)
 
@@ -335,6 +340,7 @@ class HipUNet:
         # reads an UPSAMPLED raw tensor +252 us for a 45 us pass over the low-resolution tensor; inside the single-chunk
         # 32->32 conv +188 us for a 345 us pass: kept).  ``keep_features`` and the split mode take the unfused path.
         fuse = self.defer_activation and not self.split and not keep_features
+        fuse_down = self.defer_activation and not keep_features   # the stride-2 convs activate their raw input in both fast modes
 
         def lds_act(nxt):   # does the consuming 3x3x3 conv activate a raw input in LDS at a profit?
             return fuse and nxt.ksize == 3 and nxt.cin == 32
@@ -355,7 +361,7 @@ class HipUNet:
         tags = ["L0b", "L0a"]
         for i, layer in enumerate(self.enc0[1:]):
             last = i == len(self.enc0) - 2
-            raw = (fuse and (self.down0.cin, self.down0.cout) == (32, 64)) if last else lds_act(self.enc0[i + 2])
+            raw = (fuse_down and (self.down0.cin, self.down0.cout) == (32, 64)) if last else lds_act(self.enc0[i + 2])
             a = block(layer, [(a, 0)], L0, "skip0" if last else tags[i % 2], raw)
             keep(layer.name, a)
         s0 = a
@@ -365,7 +371,7 @@ class HipUNet:
         tags = ["L1b", "L1a"]
         for i, layer in enumerate(self.enc1):
             last = i == len(self.enc1) - 1
-            raw = last and fuse and (self.down1.cin, self.down1.cout) == (64, 128)
+            raw = last and fuse_down and (self.down1.cin, self.down1.cout) == (64, 128)
             a = block(layer, [(a, 0)], L1, "skip1" if last else tags[i % 2], raw)
             keep(layer.name, a)
         s1 = a
@@ -374,15 +380,15 @@ class HipUNet:
         keep("down1", a)
         tags = ["L2b", "L2a"]
         for i, layer in enumerate(self.mid):
-            # the last one is read only by red1 (1x1x1, gather GEMM): activated on load there (split mode: not supported)
-            raw = self.defer_activation and not self.split and i == len(self.mid) - 1
+            # the last one is read only by red1 (1x1x1, gather GEMM): activated on load there (both fast modes)
+            raw = self.defer_activation and not keep_features and i == len(self.mid) - 1
             a = block(layer, [(a, 0)], L2, tags[i % 2], raw)
             keep(layer.name, a)
         r1 = block(self.red1, [(a, 0)], L2, "L2r", False)
         keep("red1", r1)
         tags = ["L1a", "L1b"]
         for i, layer in enumerate(self.dec1):
-            raw = self.defer_activation and not self.split and i == len(self.dec1) - 1  # last: consumed by red0
+            raw = self.defer_activation and not keep_features and i == len(self.dec1) - 1  # last: consumed by red0 (on load)
             src = [(s1, 0), (r1, 1)] if i == 0 else [(a, 0)]
             a = block(layer, src, L1, tags[i % 2], raw)
             keep(layer.name, a)

@@ -207,6 +207,38 @@ def test_assign_raw_matches_reference_before_renumber(sk, golden):
         assert np.array_equal(inst.cpu().numpy(), g["instance_raw"].astype(np.int32))
 
 
+def test_assign_on_a_crop_above_2_pow_24_voxels(sk):
+    """A stage-3 crop of more than 2^24 voxels (the reference's 500x500x50 has 12.5 M): the crop-local flat index is then
+    NOT exact in fp32 (vector_to_embedding.py:121-127 ravels in fp32), so a voxel with a zero vector can read the vector
+    of a NEIGHBOUR whose index rounds to the same float and hop away -- which the two-voxel kernel's shortcut ("zero
+    vector: the label at its own position") would miss.  sk_follow_assign must take the one-voxel kernel there
+    (round 4: `p.nvox <= 2^24` in the fast path's condition) and equal the oracle bit for bit.  Sparse field, vectors
+    only in the high-index corner of the volume where the rounding happens."""
+    # 17.0 M voxels > 2^24 = 16.8 M; one crop = the whole volume.  X*Y*Z = 2 (mod 4): the reference clamps the flat index
+    # to float(X*Y*Z - 1) (vector_to_embedding.py:125), which must round DOWN -- with X*Y*Z = 0 (mod 4) it rounds up to
+    # X*Y*Z and the reference's own `take` raises IndexError at the last voxel, i.e. such crops cannot run there at all
+    X, Y, Z = 263, 259, 250
+    assert X * Y * Z > 1 << 24 and (X * Y * Z) % 4 == 2
+    gen = torch.Generator().manual_seed(11)
+    vec = torch.zeros((3, X, Y, Z), dtype=torch.float16)
+    blk = (torch.rand((3, 12, 40, Z), generator=gen) * 2 - 1) * 0.2
+    keep = torch.rand((1, 12, 40, Z), generator=gen) > 0.5   # half of the voxels keep a vector, their z neighbours none
+    vec[:, X - 12:, Y - 40:, :] = (blk * keep).half()
+    labels = torch.zeros((X, Y, Z), dtype=torch.int32)
+    labels[X - 40:, Y - 80:, :] = torch.randint(1, 500, (40, 80, Z), generator=gen, dtype=torch.int32)
+    scale = (60, 60, 12)
+    emb = O.vector_to_embedding(torch.tensor(scale), vec.unsqueeze(0), N=O.FOLLOW_N)
+    want = O.index_skeleton_by_embed(labels.unsqueeze(0).unsqueeze(0), emb)[0, 0]
+    # the case the guard exists for does occur in this field: a zero-vector voxel whose answer is not its own label
+    zero = (vec == 0).all(dim=0)
+    assert int((zero & (want != labels))[X - 12:, Y - 40:].sum()) > 0
+    st = sk.E.VolumeState((X, Y, Z), DEV)
+    v = vec.to(DEV)
+    sk.ffi.check(sk.ffi.lib.sk_vec_interleave(sk.ffi.ptr(v), sk.ffi.ptr(st.vec4), X * Y * Z, sk.ffi.stream_ptr()))
+    inst = st.assign(scale, crop=(X, Y, Z), overlap=(0, 0, 0), labels=labels.to(DEV))
+    assert torch.equal(inst.cpu(), want.to(torch.int32))
+
+
 @pytest.mark.parametrize("shape", [(160, 144, 40), (530, 140, 58), (128, 128, 32)])
 def test_postmodel_vs_oracle_blobs(sk, shape):
     """Seeded blob field (SURVEY.md 8d workload generator) through stages 1-tail..renumber."""

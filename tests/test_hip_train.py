@@ -784,7 +784,7 @@ def test_train_step_256_cubed(precision):
         assert torch.equal(fast[0][1][k], fast[1][1][k]), f"{k} not deterministic"
     exact = grads_of("fp32", 1)[0]
     assert (fast[0][0] - exact[0]).abs().max().item() <= (1e-2 if precision == "bf16" else 2e-3)
-    rel = 0.25 if precision == "bf16" else 0.05
+    rel = 0.02 if precision == "bf16" else 0.005   # measured 0.6 % (bf16) and 0.07 % (mixed) of the tensor's max
     sample = ["enc0.0.conv.weight", "enc0.1.conv.weight", "enc1.1.conv.weight", "mid.0.conv.weight", "dec1.0.conv.weight",
               "dec0.0.conv.weight", "dec0.1.norm.weight", "dec0.1.conv.bias", "heads.weight", "red0.conv.weight"]
     for k in sample:

@@ -61,6 +61,12 @@ CONV_CASES = [
     (1, (16, 30, 22), [(32, 0)], 32, 3),
     (1, (9, 7, 18), [(32, 0)], 32, 3),
     (1, (5, 8, 23), [(32, 0)], 32, 3),
+    # COUT 32 on 8 x 16 rectangle patches (round 4: z > 40 keeps the six-plane ring): ragged rows (y % 8), a ragged z
+    # chunk (z % 16), two chunks with an upsampled source, batch 2, several x-chunks
+    (1, (9, 21, 48), [(32, 0)], 32, 3),
+    (2, (5, 8, 70), [(32, 0)], 32, 3),
+    (1, (6, 12, 44), [(32, 0), (32, 1)], 32, 3),
+    (1, (40, 9, 128), [(32, 0)], 32, 3),
 ]
 
 
@@ -164,6 +170,57 @@ def test_down_conv_with_fused_activation(U, B, osp, cin, cout):
     assert (_cf(got.cpu().float()) - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("B,osp,cin,cout", [(1, (6, 7, 10), 32, 64), (2, (5, 9, 5), 64, 128), (1, (13, 11, 10), 32, 64),
+                                            (1, (3, 4, 3), 64, 128), (1, (9, 16, 10), 64, 128)])
+def test_down_conv_with_fused_activation_split(U, B, osp, cin, cout):
+    """sk_conv3d_down_act_split (round 4): the split-precision stride-2 conv that activates its RAW [hi | lo] input in LDS
+    and writes the pair back.  The written-back tensor equals sk_groupnorm_silu_split's bit for bit; the conv output
+    agrees with the gather kernel's (sk_conv3d_split on the activated tensor: same operands, another summation order) to
+    fp32 accumulation noise and with a float64 conv of the activated operands to 2e-5; block counts past the tensor's
+    end, batch > 1 and both sub-blocks of a workgroup are covered by the shapes."""
+    from skoots_amd import _ffi
+    gen = torch.Generator().manual_seed(cin + cout + osp[0] + 1)
+    isp = tuple(2 * v for v in osp)
+    raw = U.split_pair(torch.randn((B,) + isp + (cin,), generator=gen) * 2).to(DEV)
+    aff = torch.stack([torch.rand((B, cin), generator=gen) + 0.5, torch.randn((B, cin), generator=gen) * 0.5], dim=1).to(DEV)
+    w = torch.randn((cout, cin, 2, 2, 2), generator=gen) / (cin * 8) ** 0.5
+    w = U.join_pair(U.split_pair(w.unsqueeze(-1))).squeeze(-1)
+    bias = (torch.randn(cout, generator=gen) * 0.1).to(DEV)
+    wp = U.pack_conv_weight(w, DEV, split=True)
+    zeros = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    st = _ffi.stream_ptr(torch.device(DEV))
+    act = raw.clone()
+    vox = isp[0] * isp[1] * isp[2]
+    _ffi.check(_ffi.lib.sk_groupnorm_silu_split(_ffi.ptr(act), _ffi.ptr(aff), B, vox, cin, st))
+    want, want_partial = U.conv3d([(act, 0)], wp, bias, cout, 2, osp, zeros, split=True)
+    x = raw.clone()
+    got = torch.empty((B,) + osp + (2 * cout,), dtype=torch.float16, device=DEV)
+    nblk = _ffi.lib.sk_conv3d_num_blocks(B, osp[0], osp[1], osp[2], cout, 2)
+    partial = torch.zeros((B, nblk, cout // 4, 2), dtype=torch.float32, device=DEV)
+    _ffi.check(_ffi.lib.sk_conv3d_down_act_split(_ffi.ptr(x), _ffi.ptr(aff), _ffi.ptr(wp), _ffi.ptr(bias), _ffi.ptr(got), B,
+                                                 osp[0], osp[1], osp[2], cin, cout, _ffi.ptr(partial), _ffi.ptr(zeros), st))
+    torch.cuda.synchronize()
+    assert torch.equal(x, act), "written-back activation differs from sk_groupnorm_silu_split"
+    g64, w64 = U.join_pair(got.cpu()).double(), U.join_pair(want.cpu()).double()
+    scale = max(1.0, w64.abs().max().item())
+    assert (g64 - w64).abs().max().item() <= 2e-6 * scale
+    assert torch.allclose(partial.sum(1), want_partial.sum(1), rtol=1e-5, atol=1e-4)
+    ref = F.conv3d(_cf(U.join_pair(act.cpu())).double(), w.double(), bias.cpu().double(), stride=2)
+    assert (_cf(g64) - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # the raw source of a 1x1x1 conv is activated on load by the split gather kernel (sk_conv3d_split, affine != NULL)
+    if cin == 64:
+        w1 = torch.randn((32, cin, 1, 1, 1), generator=gen) / cin ** 0.5
+        wp1, b1 = U.pack_conv_weight(w1, DEV, split=True), (torch.randn(32, generator=gen) * 0.1).to(DEV)
+        plain, _ = U.conv3d([(act, 0)], wp1, b1, 32, 1, isp, zeros, split=True)
+        fused = torch.empty_like(plain)
+        arr = (_ffi.ConvSrc * 1)()
+        arr[0].data, arr[0].c, arr[0].upsample, arr[0].affine = raw.data_ptr(), cin, 0, aff.data_ptr()
+        _ffi.check(_ffi.lib.sk_conv3d_split(arr, 1, _ffi.ptr(wp1), _ffi.ptr(b1), _ffi.ptr(fused), B, isp[0], isp[1], isp[2], 32, 1,
+                                            None, _ffi.ptr(zeros), st))
+        torch.cuda.synchronize()
+        assert torch.equal(fused, plain), "activation on load (split gather) differs from pass + plain conv"
+
+
 def _conv_ffi(srcs, wp, bias, out_shape, cout=32, box=None, affine=None, prefill=None):
     """sk_conv3d / sk_conv3d_box through the C ABI with everything the U.conv3d helper leaves out."""
     from skoots_amd import _ffi
@@ -188,11 +245,11 @@ def _conv_ffi(srcs, wp, bias, out_shape, cout=32, box=None, affine=None, prefill
     return out, partial
 
 
-@pytest.mark.parametrize("B,osp", [(1, (8, 12, 20)), (2, (37, 14, 20)), (1, (5, 9, 16)), (1, (6, 10, 10))])
+@pytest.mark.parametrize("B,osp", [(1, (8, 12, 20)), (2, (37, 14, 20)), (1, (5, 9, 16)), (1, (6, 10, 10)), (1, (4, 11, 48))])
 def test_conv_activates_a_raw_source_in_lds(U, B, osp):
     """A RAW source (sk_conv_src.affine != NULL) is activated by the staging lanes in LDS -- silu(a*x + b), the
     arithmetic of sk_groupnorm_silu op for op -- so the conv over it must equal, BIT FOR BIT, the conv over the tensor
-    the separate pass produces.  Covers conv3_px_kernel (z 16 / 20) and conv3_m16_kernel (z 10)."""
+    the separate pass produces.  Covers conv3_px_kernel (z 16 / 20) and conv3_m16_kernel (z 10; z 48: rectangle patches)."""
     from skoots_amd import _ffi
     gen = torch.Generator().manual_seed(osp[0] * 31 + osp[2])
     x = torch.randn((B,) + osp + (32,), generator=gen).half().to(DEV)
@@ -211,12 +268,13 @@ def test_conv_activates_a_raw_source_in_lds(U, B, osp):
 
 
 @pytest.mark.parametrize("osp,box", [((12, 30, 20), (3, 4, 2, 9, 25, 17)), ((37, 14, 20), (0, 0, 0, 37, 14, 20)),
-                                     ((9, 12, 20), (9, 0, 0, 9, 12, 20)), ((8, 12, 10), (2, 2, 2, 6, 9, 8))])
+                                     ((9, 12, 20), (9, 0, 0, 9, 12, 20)), ((8, 12, 10), (2, 2, 2, 6, 9, 8)),
+                                     ((6, 9, 48), (1, 2, 5, 5, 8, 41)), ((10, 40, 24), (0, 3, 1, 7, 33, 24))])
 def test_conv_store_box(U, osp, box):
     """sk_conv3d_box: the voxels inside the box hold exactly what the plain launch stores, the GroupNorm partial sums
-    are those of the WHOLE tile (bit-identical to the plain launch), and a kernel that honours the box (conv3_px_kernel:
-    first three cases, the third with an empty box) leaves the voxels outside it untouched; the last case runs on a kernel that
-    stores everything, which the contract allows."""
+    are those of the WHOLE tile (bit-identical to the plain launch), and the voxels outside the box stay untouched:
+    conv3_px_kernel (z = 20: first three cases, the third with an empty box) and, since round 4, conv3_m16_kernel --
+    linear patches (z = 10, 24) and rectangle patches (z = 48)."""
     gen = torch.Generator().manual_seed(osp[0] + 7 * osp[1])
     x = torch.randn((2,) + osp + (32,), generator=gen).half().to(DEV)
     w = torch.randn((32, 32, 3, 3, 3), generator=gen) / (32 * 27) ** 0.5
@@ -226,10 +284,39 @@ def test_conv_store_box(U, osp, box):
     assert torch.equal(pbox, pfull)
     x0, y0, z0, x1, y1, z1 = box
     assert torch.equal(got[:, x0:x1, y0:y1, z0:z1], full[:, x0:x1, y0:y1, z0:z1])
-    if osp[2] == 20:   # the plane-streaming kernel: nothing outside the box is written
-        outside = torch.ones(osp, dtype=torch.bool, device=DEV)
-        outside[x0:x1, y0:y1, z0:z1] = False
-        assert bool((got[:, outside] == 7.0).all())
+    outside = torch.ones(osp, dtype=torch.bool, device=DEV)
+    outside[x0:x1, y0:y1, z0:z1] = False
+    assert bool((got[:, outside] == 7.0).all())
+
+
+@pytest.mark.parametrize("osp,box", [((12, 30, 20), (3, 4, 2, 9, 25, 17)), ((8, 12, 10), (2, 2, 2, 6, 9, 8))])
+def test_conv_store_box_split(U, osp, box):
+    """sk_conv3d_box_split: as test_conv_store_box on [hi | lo] tensors (the last block's conv of precision="split")."""
+    from skoots_amd import _ffi
+    import ctypes as C
+    gen = torch.Generator().manual_seed(osp[0] + 5 * osp[2])
+    B = 2
+    x = U.split_pair(torch.randn((B,) + osp + (32,), generator=gen)).to(DEV)
+    w = torch.randn((32, 32, 3, 3, 3), generator=gen) / (32 * 27) ** 0.5
+    wp, bias = U.pack_conv_weight(w, DEV, split=True), (torch.randn(32, generator=gen) * 0.1).to(DEV)
+    zeros = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    full, pfull = U.conv3d([(x, 0)], wp, bias, 32, 3, osp, zeros, split=True)
+    ox, oy, oz = osp
+    out = torch.full((B, ox, oy, oz, 64), 7.0, dtype=torch.float16, device=DEV)
+    nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, 32, 3)
+    partial = torch.zeros((B, nblk, 8, 2), dtype=torch.float32, device=DEV)
+    arr = (_ffi.ConvSrc * 1)()
+    arr[0].data, arr[0].c, arr[0].upsample, arr[0].affine = x.data_ptr(), 32, 0, None
+    _ffi.check(_ffi.lib.sk_conv3d_box_split(arr, 1, _ffi.ptr(wp), _ffi.ptr(bias), _ffi.ptr(out), B, ox, oy, oz, 32, 3,
+                                            _ffi.ptr(partial), _ffi.ptr(zeros), (C.c_int32 * 6)(*box),
+                                            _ffi.stream_ptr(torch.device(DEV))))
+    torch.cuda.synchronize()
+    assert torch.equal(partial, pfull)
+    x0, y0, z0, x1, y1, z1 = box
+    assert torch.equal(out[:, x0:x1, y0:y1, z0:z1], full[:, x0:x1, y0:y1, z0:z1])
+    outside = torch.ones(osp, dtype=torch.bool, device=DEV)
+    outside[x0:x1, y0:y1, z0:z1] = False
+    assert bool((out[:, outside] == 7.0).all())
 
 
 def test_conv_exact_integer_layout(U):

@@ -201,6 +201,51 @@ def test_assign_reach_covers_the_owning_crops():
                     assert a <= own[z] and own[z] + eff[2] <= b
 
 
+def test_eight_rank_plan_at_2048x2048x512_and_its_byte_budget():
+    """BASELINE configs[3] -- 2048x2048x512 on 8 ranks -- has never run on hardware (no 8-GPU node was available to any
+    round).  This pins what the first run will be read against: the whole plan (tile plan, block plan, stage-3 reach,
+    halo plan) at the real size and the bytes every rank sends per step under every exchange tag
+    (parallel.comm_budget; DESIGN.md section 7 quotes these numbers).  xGMI moves ~153 GB/s per link and neighbour."""
+    shape, world = (2048, 2048, 512), 8
+    plan, eff = P.tile_plan(shape, (300, 300, 20), (50, 50, 5), world)
+    assert eff == [300, 300, 20]
+    assert sorted(len(p) for p in plan) == [637] * 4 + [638] * 4 and sum(len(p) for p in plan) == 5100
+    assert len({o for p in plan for o in p}) == 5100                     # every distinct tile of the reference grid, once
+    assert 5100 == len(cropper.distinct_origins(shape, [300, 300, 20], (50, 50, 5)))
+    assert cropper.get_total_num_crops((1,) + shape, [300, 300, 20], (50, 50, 5)) == 6292                                       # what the reference's generator emits (SURVEY 8a)
+    slabs = P.slab_bounds(512, world)
+    windows = [P.window_of(s, 512, world) for s in slabs]
+    for r, tiles in enumerate(plan):                                      # a rank's tiles lie inside its window
+        assert all(windows[r][0] <= z and z + 20 <= windows[r][1] for (_, _, z) in tiles)
+    budget = P.comm_budget(shape, world)
+    MiB = 1 << 20
+    assert [b["tiles"] for b in budget] == [len(p) for p in plan]
+    # stage 1: a rank hands 36-176 MiB of (vector, skeleton) boxes to one or two NEIGHBOUR ranks only
+    for r, b in enumerate(budget):
+        assert 35 * MiB <= b["block_exchange"] <= 176 * MiB, (r, b["block_exchange"] / MiB)
+        assert b["block_peers"] and all(abs(q - r) == 1 for q in b["block_peers"])
+    total_blocks = sum(b["block_exchange"] for b in budget)
+    assert 1.0 * 1024 * MiB < total_blocks < 1.2 * 1024 * MiB            # 1.09 GiB per step over the whole job
+    # the blocks delivered + the voxels a rank keeps cover every written voxel of every slab exactly once
+    blocks = P.block_plan(shape, eff, (50, 50, 5), plan)
+    assert sum((b[2][1] - b[2][0]) * (b[2][3] - b[2][2]) * (b[2][5] - b[2][4]) for b in blocks) * 9 == total_blocks
+    # stage 2: one 16 MiB int32 plane to the rank below, two fixed-size all-gathers
+    assert [b["label_seam_planes"] for b in budget] == [0] + [16 * MiB] * 7
+    assert all(b["label_meta"] == (4 + 2 * 16384) * 4 * 7 for b in budget)
+    assert all(b["label_gather"] == (2048 * 2048 * 64 // 64) * 8 * 7 for b in budget)   # 32 MiB per receiver
+    # stage 3: 8-42 planes of interleaved vectors per neighbour (32 MiB a plane), at most 2.4 GiB per rank
+    for r, b in enumerate(budget):
+        assert set(b["vector_halo_planes"]) == {q for q in (r - 1, r + 1) if 0 <= q < world}
+        assert all(8 <= n <= 42 for n in b["vector_halo_planes"].values()), b["vector_halo_planes"]
+        assert b["vector_halo"] == 32 * MiB * sum(b["vector_halo_planes"].values()) <= 2368 * MiB
+    # per-rank total and the time it costs at one xGMI link per neighbour (153 GB/s): well under 3 % of a ~0.45 s stage 1
+    worst = max(b["block_exchange"] + b["label_seam_planes"] + b["vector_halo"] for b in budget)
+    assert worst / 153e9 < 0.02
+    # one rank plans nothing
+    solo = P.comm_budget((1024, 1024, 256), 1)
+    assert solo[0]["tiles"] == 625 and solo[0]["block_exchange"] == 0 and solo[0]["vector_halo"] == 0
+
+
 def test_halo_plan_is_symmetric():
     slabs = P.slab_bounds(512, 8)
     wins = [P.window_of(s, 512, 8) for s in slabs]
