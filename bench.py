@@ -316,6 +316,26 @@ def box_probe(dev):
         if rep:
             hbm = max(hbm, 2.0 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9)
     del src, dst
+    # the same copy over 16 GiB (the split precision's full-resolution tensors are 14.7 GB each): a box whose large
+    # allocations are mapped with small page fragments streams them slower than the 1 GiB figure says
+    hbm_big = 0.0
+    try:
+        src = torch.empty((8, 1 << 29), dtype=torch.float32, device=dev)   # 16 GiB
+        dst = torch.empty_like(src)
+        for rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
+            for i in range(8):   # 2 GiB per copy call
+                dst[i].copy_(src[i])
+            e1.record(torch.cuda.current_stream(dev))
+            e1.synchronize()
+            if rep:
+                hbm_big = max(hbm_big, 2.0 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del src, dst
+    except RuntimeError as e:   # a smaller device
+        log(f"16 GiB copy probe skipped: {e}")
+        hbm_big = None
+    torch.cuda.empty_cache()
     nominal = 1950.0   # the rotating-operand loop on the boxes of round 3 (1 975; round 1's register loop on random data: 1 900)
     r = rates[1] / nominal
     return {"mfma_probe_tflops": round(best, 1), "mfma_probe_varying_operands_tflops": round(rates[1], 1),
@@ -323,6 +343,7 @@ def box_probe(dev):
                      "pseudo-random fragments in rotation (the clock a kernel on real data gets)",
             "vs_nominal_1950": round(r, 3), "band": "slow" if r < 0.97 else ("fast" if r > 1.03 else "typical"),
             "hbm_copy_GBps": round(hbm, 1), "hbm_probe": "torch device-to-device copy of 1 GiB, read + write bytes / time",
+            "hbm_copy_16GiB_GBps": None if hbm_big is None else round(hbm_big, 1),
             "device": torch.cuda.get_device_name(dev)}
 
 

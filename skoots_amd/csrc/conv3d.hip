@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                 for (int p = 0; p < P; ++p) {
                     const int q = q_row[p] + tapoff;
                     int addr = (q * 4 + ((ks * 2 + h) ^ ((q >> 2) & 3))) * 16;
-                    if (dz < 0) addr = zlo[p] ? sk::zero_of(zero_addr, addr) : addr;
+                    if (dz < 0) addr = zlo[p] ? sk::zero_of(zero_addr, addr) : addr;   // COUT 64 (this lambda's kernel variant)
                     if (dz > 0) addr = zhi[p] ? sk::zero_of(zero_addr, addr) : addr;
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
@@ -404,8 +404,10 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
                 const int tapoff = (dydz / 3 - 1) * pitch + dz;
                 const int q = q_row[p] + tapoff;
                 int addr = (q * 4 + ((ks * 2 + h) ^ ((q >> 2) & 3))) * 16;
-                if (dz < 0) addr = zlo[p] ? sk::zero_of(zero_addr, addr) : addr;
-                if (dz > 0) addr = zhi[p] ? sk::zero_of(zero_addr, addr) : addr;
+                // (COUT 128, this path: the shared zero line -- the bank-matched window measured +2.4 % time here although it
+                // takes the conflict share from 0.35 to 0.03: profiles/r04_conv_sq_counters_zero_window_*.json)
+                if (dz < 0) addr = zlo[p] ? zero_addr : addr;
+                if (dz > 0) addr = zhi[p] ? zero_addr : addr;
 #pragma unroll
                 for (int i = 0; i < R; ++i) dst[i] = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
             };
@@ -2185,37 +2187,36 @@ __global__ void __launch_bounds__(256, 2) down2_act_kernel(DownArgs a) {
 // w_hi x_lo, w_hi x_hi -- exactly as in gather_gemm_kernel<.., SPLIT>, which ran these layers until round 3 behind a
 // separate gn_silu_split pass over the skip tensor (read + write of 14.7 GB per 64 production tiles for enc0.1's
 // output).  Here the RAW tensor comes in and is activated while it is staged, as in down2_act_kernel:
-//   * a staged row = the two z-adjacent input voxels of an output voxel = 2 x [hi | lo] = RB = 8 CIN bytes (256 | 512);
-//     a stage buffer (one (dx, dy)) holds NV = 32 KiB / RB rows; a workgroup runs kSub such sub-blocks one after the
-//     other so that it owns the same 256 | 128 output voxels as a down2_act_kernel workgroup (same partial-sum rows:
-//     sk_conv3d_num_blocks);
-//   * 16-byte chunk c of row n sits at chunk slot c ^ (n & 15): every 16-lane group of the B-fragment reads (16
-//     consecutive rows, one chunk index) covers the 64 banks for 256-byte rows (once) and for 512-byte rows;
-//   * the hi chunk and the lo chunk of the same 8 channels of a voxel are CPH chunk slots apart in the SAME row, i.e.
-//     staged by lanes l and l ^ CPH of the same LDS-DMA instruction: after its own counted vmcnt wait a lane reads both
-//     (no barrier), computes silu(a (hi + lo) + b) with gn_silu_split_kernel's arithmetic, op for op, and writes back
-//     the half it staged -- hi' = fp16(s) or lo' = fp16(s - hi') -- to LDS and to the tensor (the decoder's skip conv
-//     reads it activated).  Both lanes of a pair evaluate the same expression: the kernel is bound by its HBM stream.
+//   * a stage (one (dx, dy)) holds the two z-adjacent input voxels of NV output voxels as TWO images of 16 KiB -- the hi
+//     halves and the lo halves, each with down2_act_kernel's row layout (rows of 4 CIN bytes = 128 | 256, 16-byte chunk
+//     c of row n at chunk slot c ^ g(n): conflict-free ds_read_b128 lane groups);
+//   * LDS-DMA instruction t of a wave fills slots 64 t .. 64 t + 63 and the lo image lies 16 instructions behind the hi
+//     image, so a lane's slot of instruction t + 16 is the lo half of the SAME eight channels of the same voxel as its
+//     slot of instruction t: after its own counted vmcnt wait a lane holds both halves of the values it staged and
+//     evaluates silu(a (hi + lo) + b) ONCE (gn_silu_split_kernel's arithmetic, op for op), writes hi' = fp16(s) and
+//     lo' = fp16(s - hi') back to LDS and to the tensor (the decoder's skip conv reads it activated);
+//   * a workgroup runs kSub sub-blocks of NV = 128 | 64 output voxels one after the other, so that it owns the same
+//     256 | 128 output voxels -- the same partial-sum rows -- as a down2_act_kernel workgroup (sk_conv3d_num_blocks).
 // ------------------------------------------------------------------------------------------
 template <int COUT, int CIN>
 __global__ void __launch_bounds__(256, 2) down2_act_split_kernel(DownArgs a) {
     constexpr int NT = COUT / 32;
     constexpr int VB = 4 * CIN;                // bytes per voxel line [hi | lo]
-    constexpr int RB = 2 * VB;                 // bytes per staged row (256 | 512)
-    constexpr int CPR = RB / 16;               // chunks per row (16 | 32)
-    constexpr int CPV = VB / 16;               // chunks per voxel (8 | 16)
-    constexpr int CPH = CPV / 2;               // chunks per half: the hi / lo partner of a chunk is CPH slots away (4 | 8)
-    constexpr int NV = 32768 / RB;             // output voxels per sub-block (128 | 64)
+    constexpr int RBH = 4 * CIN;               // bytes per row of ONE image: two voxels x CIN fp16 (128 | 256)
+    constexpr int CPR = RBH / 16;              // chunks per image row (8 | 16)
+    constexpr int CPVH = CIN / 8;              // chunks per voxel and half (4 | 8)
+    constexpr int kImage = 16384;              // bytes per image: NV rows
+    constexpr int NV = kImage / RBH;           // output voxels per sub-block (128 | 64)
     constexpr int kSub = 2;                    // sub-blocks per workgroup: 256 | 128 output voxels, as down2_act_kernel
     constexpr int WN = NT / 2;                 // wave groups along cout (1 | 2)
     constexpr int NTW = NT / WN;               // cout tiles per wave (2)
     constexpr int PV = (NV / 32) / (4 / WN);   // column tiles per wave (1)
     constexpr int NKS = CIN / 16;              // K steps per input voxel and half
-    constexpr int kStage = 32768;
+    constexpr int kStage = 2 * kImage;
     constexpr int kOvs = COUT * 4;             // bytes per output voxel line [hi | lo]
     static_assert((CIN == 32 && COUT == 64) || (CIN == 64 && COUT == 128), "the two stride-2 layers of the network");
     static_assert(PV == 1 && NTW == 2, "one column tile, two cout tiles per wave");
-    extern __shared__ __attribute__((aligned(16))) char dlds[];   // [2][32 KiB] stages + 4 epilogue pads
+    extern __shared__ __attribute__((aligned(16))) char dlds[];   // [2 stages][hi image | lo image] + 4 epilogue pads
     __shared__ float red[4 * 2 * 16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
@@ -2227,14 +2228,16 @@ __global__ void __launch_bounds__(256, 2) down2_act_split_kernel(DownArgs a) {
     char* outb = a.out + (long long)b * nvox * kOvs;
     const bool raw = a.affine != nullptr;
     const char* wlo = a.wpk + (long long)(8 * NKS) * NT * 1024;   // the lo fragments follow the 8 taps x NKS hi steps
+    // swizzle term of image row n (down2_act_kernel's): 128-byte rows alternate bank halves, 256-byte rows start at bank 0
+    auto gsw = [](int n) { return CPR == 8 ? ((n >> 1) & 7) : (n & 15); };
 
-    // this thread's slots of a stage: slot = tid + 256 j -> row n_j = tid / CPR + (256 / CPR) j, chunk slot cs = tid % CPR
-    const int cs = tid % CPR;
-    auto row_of = [&](int j) { return tid / CPR + (256 / CPR) * j; };
-    auto csrc_of = [&](int j) { return cs ^ (row_of(j) & 15); };   // source chunk of slot j (swizzle on the source side)
+    // this thread's slots of an image: slot = tid + 256 j (j < 4) -> row n_j = tid / CPR + (256 / CPR) j, chunk slot tid % CPR;
+    // the swizzle term is the same for every j, hence one source chunk: voxel dz = csrc / CPVH of the row, channel octet csrc % CPVH
+    const int csrc = (tid % CPR) ^ gsw(tid / CPR);
+    const int src_off = (csrc / CPVH) * VB + (csrc % CPVH) * 16;   // byte offset of the hi chunk in the two-voxel row; lo: + VB / 2
     float ga[8], gb[8];
     if (raw) {
-        const int c0 = (csrc_of(0) % CPH) * 8;   // the 8 channels of this thread's chunks: the same for every j, hi or lo
+        const int c0 = (csrc % CPVH) * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             ga[j] = a.affine[(long long)b * 2 * CIN + c0 + j];
@@ -2252,10 +2255,10 @@ __global__ void __launch_bounds__(256, 2) down2_act_split_kernel(DownArgs a) {
     for (int sub = 0; sub < kSub; ++sub) {
         const long long v0 = ((long long)blk * kSub + sub) * NV;
         if (v0 >= nvox) break;   // block-uniform
-        long long vin[8];        // input voxel index of tap (0, 0, 0) of row n_j, or -1 beyond the tensor
+        long long vin[4];        // input voxel index of tap (0, 0, 0) of row n_j, or -1 beyond the tensor
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const long long v = v0 + row_of(j);
+        for (int j = 0; j < 4; ++j) {
+            const long long v = v0 + tid / CPR + (256 / CPR) * j;
             if (v < nvox) {
                 const int zo = (int)(v % a.Zo);
                 const long long t = v / a.Zo;
@@ -2269,10 +2272,12 @@ __global__ void __launch_bounds__(256, 2) down2_act_split_kernel(DownArgs a) {
             const long long toff = ((long long)(st >> 1) * Yi + (st & 1)) * Zi;   // (dx, dy)
             char* lbase = dlds + (st & 1) * kStage;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const char* g = vin[j] >= 0 ? inb + (vin[j] + toff) * VB + csrc_of(j) * 16 : a.zeros + lane * 16;
-                dma16(g, lbase + (w + 4 * j) * 1024);
-            }
+            for (int part = 0; part < 2; ++part)      // the hi image, then the lo image 16 instructions behind it
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const char* g = vin[j] >= 0 ? inb + (vin[j] + toff) * VB + src_off + part * (VB / 2) : a.zeros + lane * 16;
+                    dma16(g, lbase + part * kImage + (w + 4 * j) * 1024);
+                }
         };
         f32x16 acc[NTW];
 #pragma unroll
@@ -2309,41 +2314,38 @@ __global__ void __launch_bounds__(256, 2) down2_act_split_kernel(DownArgs a) {
             if (raw) {
                 const long long toff = ((long long)(st >> 1) * Yi + (st & 1)) * Zi;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int slot = tid + 256 * j;
-                    half8* lp = reinterpret_cast<half8*>(buf + slot * 16);
-                    const half8 own = *lp;
-                    const half8 oth = *reinterpret_cast<const half8*>(buf + (slot ^ CPH) * 16);
-                    const int csrc = csrc_of(j);
-                    const bool is_lo = (csrc / CPH) & 1;
-                    half8 r;
+                for (int j = 0; j < 4; ++j) {
+                    half8* lph = reinterpret_cast<half8*>(buf + (tid + 256 * j) * 16);
+                    half8* lpl = reinterpret_cast<half8*>(buf + kImage + (tid + 256 * j) * 16);
+                    const half8 vh = *lph, vl = *lpl;
+                    half8 rh, rl;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {   // gn_silu_split_kernel's arithmetic, op for op
-                        const float vh = is_lo ? (float)oth[e] : (float)own[e];
-                        const float vl = is_lo ? (float)own[e] : (float)oth[e];
-                        const float y = fmaf(ga[e], vh + vl, gb[e]);
+                        const float y = fmaf(ga[e], (float)vh[e] + (float)vl[e], gb[e]);
                         const float sv = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
-                        const t16 rh = sk::round_t16(sv);
-                        const t16 rl = (t16)(sv - (float)rh);
-                        r[e] = is_lo ? rl : rh;
+                        rh[e] = sk::round_t16(sv);
+                        rl[e] = (t16)(sv - (float)rh[e]);
                     }
-                    *lp = r;
-                    if (a.writeback && vin[j] >= 0)
-                        *reinterpret_cast<half8*>(inb + (vin[j] + toff) * VB + csrc * 16) = r;
+                    *lph = rh;
+                    *lpl = rl;
+                    if (a.writeback && vin[j] >= 0) {
+                        char* g = inb + (vin[j] + toff) * VB + src_off;
+                        *reinterpret_cast<half8*>(g) = rh;
+                        *reinterpret_cast<half8*>(g + VB / 2) = rl;
+                    }
                 }
             }
             __syncthreads();
             // K steps of the stage: (dz, ks); weight step index = st * 2 NKS + dz * NKS + ks
             const int n = 32 * wm + col;
-            const char* rowp = buf + n * RB;
-            const int sw = n & 15;
+            const char* rowp = buf + n * RBH;
+            const int sw = gsw(n);
 #pragma unroll
             for (int k = 0; k < 2 * NKS; ++k) {
                 if (k + 1 < 2 * NKS) wload(st * 2 * NKS + k + 1, wf[(k + 1) & 1]);
-                const int dz = k / NKS, ks = k % NKS;
-                const int chi = dz * CPV + 2 * ks + h, clo = chi + CPH;
-                const half8 bh = *reinterpret_cast<const half8*>(rowp + ((chi ^ sw) * 16));
-                const half8 bl = *reinterpret_cast<const half8*>(rowp + ((clo ^ sw) * 16));
+                const int coff = ((2 * k + h) ^ sw) * 16;   // chunk (dz, ks, h) of the row = 2 k + h, as in down2_act_kernel
+                const half8 bh = *reinterpret_cast<const half8*>(rowp + coff);
+                const half8 bl = *reinterpret_cast<const half8*>(rowp + kImage + coff);
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
                     acc[nt] = SK_MFMA_32x32x16_T16(wf[k & 1][nt][1], bh, acc[nt], 0, 0, 0);

@@ -174,14 +174,23 @@ class HipUNet:
 
     # -- buffers -----------------------------------------------------------------------
     def _buf(self, tag: str, shape: Tuple[int, ...], dtype=torch.float16) -> Tensor:
-        key = (tag, shape, dtype)
+        """Activation / scratch buffer ``tag``: ONE allocation per tag that only ever grows; a smaller request (the last
+        tile batch of a volume -- 49 of 64 tiles at 1024x1024x256 --, another layer's partial sums) is a view of it.
+        Rounds 1-3 re-allocated a tag whenever its shape changed: every step freed and re-requested tens of GB through
+        torch's caching allocator, whose blocks had meanwhile been split for other tags -- the first steps after a
+        precision switch then called hipMalloc inside the step (2 calls, ~480 ms on some boxes: what made the
+        split-precision figure of the driver's line read 170 where the steady state is 215 Mvox/s)."""
+        n = 1
+        for v in shape:
+            n *= int(v)
+        key = (tag, dtype)
         t = self._bufs.get(key)
-        if t is None:
-            for k in [k for k in self._bufs if k[0] == tag]:
-                del self._bufs[k]
-            t = torch.empty(shape, dtype=dtype, device=self.device)
+        if t is None or t.numel() < n:
+            self._bufs.pop(key, None)
+            t = None   # release the old block before asking for the larger one
+            t = torch.empty(n, dtype=dtype, device=self.device)
             self._bufs[key] = t
-        return t
+        return t[:n].view(shape)
 
     # -- layer launchers ---------------------------------------------------------------
     def _norm_act(self, layer: _ConvLayer, x: Tensor, partial: Tensor, nblk: int, apply: bool = True) -> Tensor:
@@ -311,7 +320,8 @@ class HipUNet:
                       mean: float, std: float, keep_features: bool = False, out_box=None) -> Tensor:
         """image (X, Y, Z) fp16 on the GPU; B tile origins; tile extents (w, h, d).
         ``out_box`` = (lo, hi) tile-local: only that box of the 5-channel output is evaluated (every
-        conv still covers the whole tile -- its GroupNorm statistics need it -- but the heads do not)."""
+        conv still covers the whole tile -- its GroupNorm statistics need it -- but the heads do not).
+        The result is a view of this context's output buffer: valid until the next ``forward_tiles`` call on it."""
         _ffi.require_gpu(image, "image")
         if image.dtype != torch.float16 or image.ndim != 3:
             raise ValueError("image must be an (X, Y, Z) fp16 tensor")

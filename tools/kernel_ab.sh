@@ -12,12 +12,13 @@ set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 KERNELS=${KERNELS:-'conv3_|stem_|gather_|gn_silu|heads'}
 TILE=${TILE:-300,300,20}
+BATCH=${BATCH:-8}
 cd /tmp && export TMPDIR=/tmp
 for LIB in "$@"; do
     case "$LIB" in /*) ;; *) LIB="$ROOT/$LIB" ;; esac
     TAG=$(basename "$LIB" .so)_$RANDOM
     SKOOTS_HIP_LIB="$LIB" rocprofv3 --kernel-trace --stats -d /tmp/kernel_ab -o "$TAG" -- \
-        python3 "$ROOT/tools/bench_conv.py" --tile "$TILE" --batch 8 --iters 6 --warmup 2 > /dev/null 2>&1
+        python3 "$ROOT/tools/bench_conv.py" --tile "$TILE" --batch $BATCH --iters 6 --warmup 2 > /dev/null 2>&1
     python3 - "$TAG" "$KERNELS" <<'PY'
 import glob, re, sqlite3, sys
 tag, pat = sys.argv[1], re.compile(sys.argv[2])
