@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-box", action="store_true", help="evaluate the heads on the whole tile (the pipeline evaluates the scatter's box: "
+                    "interior +- the dilation reach, 28 %% of a 300x300x20 tile)")
     ap.add_argument("--no-fold", action="store_true", help="decoder convs on the direct kernel (sk_conv3d) instead of sk_conv3d_upfold")
     args = ap.parse_args()
     from skoots_amd import unet
@@ -33,15 +35,18 @@ def main():
     vol = torch.randint(0, 256, (tile[0], tile[1], tile[2] + args.batch - 1), generator=g, device=dev,
                         dtype=torch.uint8).to(torch.float16)
     origins = [(0, 0, b) for b in range(args.batch)]
+    box = None
+    if not args.no_box and all(t > 2 * o for t, o in zip(tile, (50, 50, 5))):   # as skoots_amd.parallel.ShardedVolume.run
+        box = ([o - r for o, r in zip((50, 50, 5), (3, 3, 1))], [t - o + r for t, o, r in zip(tile, (50, 50, 5), (3, 3, 1))])
     for _ in range(args.warmup):
-        model.forward_tiles(vol, origins, tile, 127.5, 73.9)
+        model.forward_tiles(vol, origins, tile, 127.5, 73.9, out_box=box)
     torch.cuda.synchronize()
     prof = unet.ConvProfile()
     model.profile = prof
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(args.iters):
-        model.forward_tiles(vol, origins, tile, 127.5, 73.9)
+        model.forward_tiles(vol, origins, tile, 127.5, 73.9, out_box=box)
     e1.record()
     torch.cuda.synchronize()
     model.profile = None
@@ -55,7 +60,7 @@ def main():
         d[2] += 1
     layers = {k: {"ms": round(v[0] / v[2], 4), "tflops": round(v[1] / v[0] / 1e9, 1)} for k, v in per.items()}
     conv_ms, conv_fl, n = prof.totals()
-    out = {"tile": tile, "batch": args.batch, "forward_ms": round(total_ms, 3),
+    out = {"tile": tile, "batch": args.batch, "out_box": box, "forward_ms": round(total_ms, 3),
            "forward_tflops": round(model.flops_per_tile_voxel() * vox / total_ms / 1e9, 1),
            "mvox_per_s_tile_voxels": round(vox / total_ms / 1e3, 1),
            "conv3_ms": round(conv_ms / args.iters, 3), "conv3_tflops": round(conv_fl / conv_ms / 1e9, 1),
