@@ -547,6 +547,16 @@ int sk_mask_iou(const int32_t* gt, const int32_t* pred, int64_t n, const int32_t
  * next to its line: devices differ, so figures from two boxes compare only beside them.  scratch: >= 512 KiB. */
 int sk_mfma_probe(void* scratch, size_t scratch_bytes, int iters, int vary_operands, double* flops, void* stream);
 
+/* CU-masked streams (round 4 experiment, tools/cu_*_probe.py; no reference counterpart: the reference runs everything on
+ * the default stream of one device, eval.py:57; NOT used by the product path -- DESIGN.md section 8 records why).
+ * sk_stream_create_cu_mask wraps hipExtStreamCreateWithCUMask (the stream must belong to the HIP runtime instance the
+ * kernels are launched from): bit i of the little-endian word array enables a compute unit; on MI355X bit 8 c + x is
+ * compute unit c of XCD x, and an XCD with no bit set gets all its CUs.  sk_debug_where launches n_blocks one-wave
+ * workgroups that each record (XCC id, HW id register) after spinning spin_cycles: which CUs a mask really selects. */
+int sk_stream_create_cu_mask(const uint32_t* mask_words, int n_words, void** stream_out);
+int sk_stream_destroy(void* stream);
+int sk_debug_where(unsigned* out, int n_blocks, int spin_cycles, void* stream);
+
 /* Phase-timing builds (-DSK_TIMING, tools/conv_phase_timing.py) dump per-wave cycle sums of the conv kernels into
  * this device buffer, [4096 workgroups][4 waves][16 slots] int64 (bytes must cover all of it); NULL detaches it.
  * The release library stores the pointer and never writes through it. */

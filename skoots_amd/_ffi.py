@@ -49,6 +49,9 @@ _SIGS = {
     "sk_abi_version": (i32, []),
     "sk_mfma_probe": (i32, [vp, sz, i32, i32, C.POINTER(C.c_double), vp]),
     "sk_debug_set_timing_buffer": (i32, [vp, sz]),
+    "sk_stream_create_cu_mask": (i32, [C.POINTER(C.c_uint32), i32, C.POINTER(vp)]),
+    "sk_stream_destroy": (i32, [vp]),
+    "sk_debug_where": (i32, [vp, i32, i32, vp]),
     "sk_vec_interleave": (i32, [vp, vp, i64, vp]),
     "sk_vec_deinterleave": (i32, [vp, vp, i64, vp]),
     "sk_vector_to_embedding": (i32, [vp, i32, vp, i32, i32, i32, fp, i32, vp]),

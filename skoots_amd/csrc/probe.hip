@@ -55,3 +55,45 @@ extern "C" int sk_mfma_probe(void* scratch, size_t scratch_bytes, int iters, int
     if (flops) *flops = (double)kBlocks * 4 * iters * 8 * (2.0 * 16 * 16 * 32);
     return SK_OK;
 }
+
+// ---- CU-masked streams (round 4 experiment: tools/cu_mask_probe.py, cu_overlap_probe.py, cu_queue_probe.py) ----------------
+// The eval step is 75 % MFMA-bound convs that fill every CU's registers and LDS, and 25 % HBM-bound passes that cannot
+// co-reside with a conv workgroup.  Two HIP streams with disjoint CU masks let the passes of one tile batch run beside the
+// convs of another -- measured, and not adopted (the "passes" are not cheap enough on a small CU share).
+// hipExtStreamCreateWithCUMask is the runtime's own API; it lives here so that the stream belongs to the HIP runtime
+// instance the kernels are launched from.
+namespace {
+__global__ void where_kernel(unsigned* out, int spin) {
+    // one record per workgroup: XCC id | hardware id (cu / sh / se); a short spin keeps the workgroups resident side by side
+    unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+    unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
+    long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < spin) {
+    }
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = xcc;
+        out[2 * blockIdx.x + 1] = hw;
+    }
+}
+}  // namespace
+
+extern "C" int sk_stream_create_cu_mask(const uint32_t* mask_words, int n_words, void** stream_out) {
+    SK_CHECK_ARG(mask_words && n_words > 0 && stream_out, "sk_stream_create_cu_mask: bad arguments");
+    hipStream_t s = nullptr;
+    SK_CHECK_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask_words));
+    *stream_out = (void*)s;
+    return SK_OK;
+}
+
+extern "C" int sk_stream_destroy(void* stream) {
+    SK_CHECK_ARG(stream, "sk_stream_destroy: NULL stream");
+    SK_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+    return SK_OK;
+}
+
+extern "C" int sk_debug_where(unsigned* out, int n_blocks, int spin_cycles, void* stream) {
+    SK_CHECK_ARG(out && n_blocks > 0, "sk_debug_where: bad arguments");
+    where_kernel<<<n_blocks, 64, 0, (hipStream_t)stream>>>(out, spin_cycles);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
