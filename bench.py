@@ -577,16 +577,17 @@ def eval_main(args, rank, world, local):
         comm_stats = sv.comm.stats()
         tiles = sv.tiles_this_rank
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            cdev = dev if backend == "nccl" else torch.device("cpu")   # the gloo rehearsal reduces host tensors
+            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
             # per-rank tile counts and communication time (max over ranks: the slowest rank sets the step time)
-            tl = torch.tensor([tiles], dtype=torch.int64, device=dev)
+            tl = torch.tensor([tiles], dtype=torch.int64, device=cdev)
             gathered = [torch.zeros_like(tl) for _ in range(world)]
             dist.all_gather(gathered, tl)
             tiles = [int(v.item()) for v in gathered]
             keys = sorted(comm_stats)
-            cms = torch.tensor([comm_stats[k]["ms"] for k in keys], dtype=torch.float64, device=dev)
+            cms = torch.tensor([comm_stats[k]["ms"] for k in keys], dtype=torch.float64, device=cdev)
             dist.all_reduce(cms, op=dist.ReduceOp.MAX)
             for k, v in zip(keys, cms.tolist()):
                 comm_stats[k]["ms_max_over_ranks"] = round(v, 3)

@@ -55,6 +55,35 @@ def test_eval_line_contract(precision):
     assert tr["dtype"] == "bf16" and tr["steps"] == 2 and tr["ms_per_step"] > 0 and tr["value"] > 0
     assert tr["roofline"]["bound"] == "mfma" and tr["roofline"]["achieved"] > 0
     assert tr["config"]["precision"] == "bf16" and all(0 < v < 3 for v in tr["config"]["losses"][:3])
+    # BASELINE configs[1] in the same line: one 512x512x128 tile through the conv + GN/SiLU stack, its own roofline
+    c1 = d["also"]["conv_c1"]
+    assert c1["forward_ms"] > 0 and c1["dtype"] == "f16" and "512x512x128" in c1["metric"]
+    assert c1["roofline"]["bound"] == "mfma" and 0.05 < c1["roofline"]["frac"] < 1.0 and 0.05 < c1["roofline"]["encoder_frac"] < 1.0
+    assert {"enc0.1", "enc1.0", "mid.0", "dec1.0", "dec0.0", "dec0.1"} <= set(c1["roofline"]["layers"])
+    # the timed steps allocate nothing on the device (grow-only activation buffers) and the line says so
+    assert sp["allocator_in_timed_steps"]["device_mallocs"] == 0 and len(sp["step_ms_min_max"]) == 2
+    assert d["config"]["inject_layout"] == "contiguous per-tile blocks"
+
+
+def test_eval_line_two_ranks_gloo_rehearsal():
+    """`python bench.py --gpus 2` without a launcher, rehearsed on the one-GPU box: two rank processes share the device and
+    exchange through gloo (SKOOTS_DIST_BACKEND=gloo).  Rank 0 prints ONE line for the 2-rank job: the Z-sharded pipeline
+    with its per-rank tile counts and per-exchange accounting, the per-rank contiguous injection, max-over-ranks timing."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SKOOTS_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--shape",
+                        "512,512,128", "--no-cpu-baseline", "--no-parity", "--tile-batch", "16"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["instances"] > 0
+    mg = d["multi_gpu"]
+    assert mg["rccl_ranks"] == 2 and mg["backend"] == "gloo" and len(mg["tiles_per_rank"]) == 2
+    assert abs(mg["tiles_per_rank"][0] - mg["tiles_per_rank"][1]) <= 1 and sum(mg["slab_planes"]) == 128
+    assert {"block_exchange", "label_seam_planes", "label_meta", "label_gather", "vector_halo"} <= set(mg["comm_rank0_per_step"])
+    assert "also" not in d   # the extra legs belong to the N = 1 line
 
 
 def test_eval_line_two_streams_keeps_a_roofline():
