@@ -2443,6 +2443,9 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
         // +13-20 % time).  COUT 64 / 128 (conv3_kernel, 32-column operands): 4 x 32.
         p.mode = 1;
         p.TZ = cout == 32 ? 16 : 32;
+#ifdef SK_TUNING
+        if (getenv("SK_CONV_RECT_4X32")) p.TZ = 32;   // A/B: rounds 1-3's rectangles for COUT 32 as well
+#endif
         p.nzc = (Zt + p.TZ - 1) / p.TZ;
         p.pitch = p.TZ + 2;
         int TY = kPatch / p.TZ;
@@ -2507,7 +2510,7 @@ int launch_conv3_m16(const Conv3Args& a, const Plan& p, hipStream_t stream) {
 }
 
 // conv3_px_kernel is built for the plane geometry of the production tile: linear mode with 176 positions per plane
-// (Zt 16 .. 22: 128 + 2 Zt + 2 positions, at least one padding position left for the taps' zero position).  The first
+// (Zt 16 .. 20: 128 + 2 Zt + 2 positions plus six padding positions -- bias, GroupNorm coefficients, the 256-byte zero window).  The first
 // kPxResidentHalfRows half tap rows (3 fragments each) in registers, the other 18 - that in LDS: 4 plane slots (44 KiB) +
 // 12 half rows (36 KiB) = 80 KiB, two workgroups per CU.  (7 resident half rows, 77 KiB: 18 spilled registers, two scratch
 // reloads per step: enc0.1 5.15 -> 5.92 ms per 64 tiles.)

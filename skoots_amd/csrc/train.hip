@@ -1570,7 +1570,13 @@ __device__ __forceinline__ half8_t wx_join(fp16x4_t lo, fp16x4_t hi) {
 // ("+a"), the rest to VGPRs ("+v"): 256 + 176, leaving 80 VGPRs for fragments and addresses.  What the compiler no
 // longer knows about these instructions: nothing reads an accumulator before the s_nop block ahead of the epilogue, and a
 // tap's MFMAs are nine instructions apart.
+// INVARIANT (not checkable by the compiler, pinned by tests/test_hip_train.py::test_conv_wgrad16x_exact_on_integer_operands,
+// which runs in the default GPU suite): between two MFMAs on the same accumulator lie the eight MFMAs of the other taps
+// of its dx group (SK_WX_M is issued in the fixed order (dy, dz) = (0,0) .. (2,2) per x tap), i.e. >= 8 x 16 pass-cycles
+// -- more than the 16-pass latency of v_mfma_f32_32x32x16 --, and nothing reads an accumulator before the s_nop block ahead
+// of the epilogue.  Reordering the group bodies or changing kWxAgprTaps must keep both.
 constexpr int kWxAgprTaps = 16;
+static_assert(kWxAgprTaps >= 0 && kWxAgprTaps <= 27, "27 tap accumulators: 16 in AGPRs + 11 in VGPRs = 432 registers");
 #ifdef SK_WX_AGPR_LAST   // experiment: the LAST 16 taps in AGPRs instead of the first 16
 #define SK_WX_AGPR_OF(i) ((i) >= 27 - kWxAgprTaps)
 #else

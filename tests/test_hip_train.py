@@ -335,6 +335,50 @@ def test_conv_wgrad_f16(ffi, B, osp, srcdef, cout, ksize):
 
 
 @pytest.mark.parametrize("twin", [False, True])
+@pytest.mark.parametrize("B,osp,srcdef,cout", [(1, (7, 16, 16), [(32, 0)], 32), (1, (12, 32, 16), [(32, 0), (32, 1)], 32),
+                                               (1, (20, 16, 32), [(64, 0)], 64)])
+def test_conv_wgrad16x_exact_on_integer_operands(ffi, B, osp, srcdef, cout, twin):
+    """wgrad16x_kernel (y % 16 == 0 and z % 16 == 0) multiplies through hand-written `asm volatile` MFMAs whose hazard spacing
+    the compiler cannot check (27 accumulators pinned to AGPRs / VGPRs, an s_nop block ahead of the epilogue: a tap's MFMAs
+    are nine instructions apart).  Small-integer operands make every product and every partial sum exact in 16-bit operands
+    and fp32 accumulators, so the weight and bias gradients must equal torch's BIT FOR BIT, in the fp16 build and in the
+    bf16 twin: a read of an accumulator that is still in flight, a swapped tap or a dropped plane cannot hide behind a
+    tolerance."""
+    gen = torch.Generator().manual_seed(cout + osp[0])
+    t16 = torch.bfloat16 if twin else torch.float16
+    sfx = "_bf16" if twin else ""
+    srcs_cpu, srcs_dev = [], []
+    for c, up in srcdef:
+        sp = tuple(v // 2 for v in osp) if up else osp
+        t = torch.randint(-2, 3, (B, c) + sp, generator=gen).float()
+        srcs_cpu.append((t, up))
+        srcs_dev.append((_cl(t).to(t16).to(DEV), up))
+    cin = sum(c for c, _ in srcdef)
+    w = torch.zeros((cout, cin, 3, 3, 3), requires_grad=True)
+    bias = torch.zeros(cout, requires_grad=True)
+    x = torch.cat([F.interpolate(t, scale_factor=2, mode="nearest") if up else t for t, up in srcs_cpu], dim=1)
+    y = F.conv3d(x, w, bias, padding=1)
+    dy = (torch.randint(-2, 3, y.shape, generator=gen) * (torch.rand(y.shape, generator=gen) < 0.5)).float()
+    y.backward(dy)
+    dy16 = _cl(dy).to(t16).to(DEV)
+    scale = torch.tensor([1.0, 1.0, 2.0], device=DEV)   # dy16 = dy * 1
+    arr = (ffi.ConvSrc * len(srcs_dev))()
+    for i, (t, up) in enumerate(srcs_dev):
+        arr[i].data, arr[i].affine, arr[i].c, arr[i].upsample = t.data_ptr(), None, t.shape[-1], up
+    dw, dbias = torch.full(w.shape, 7.0, device=DEV), torch.full((cout,), 7.0, device=DEV)
+    ox, oy, oz = osp
+    st = ffi.stream_ptr(torch.device(DEV))
+    ws = torch.empty(int(getattr(ffi.lib, "sk_train_conv_wgrad_workspace_floats" + sfx)(B, ox, oy, oz, cout, cin, 3)), device=DEV)
+    zero_page = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    ffi.check(getattr(ffi.lib, "sk_train_conv_wgrad_f16" + sfx)(arr, len(srcs_dev), ffi.ptr(dy16), ffi.ptr(scale), B, ox, oy, oz,
+                                                               cout, 3, ffi.ptr(dw), ffi.ptr(dbias), ffi.ptr(ws),
+                                                               ffi.ptr(zero_page), st))
+    torch.cuda.synchronize()
+    assert torch.equal(dw.cpu(), w.grad), (dw.cpu() - w.grad).abs().max()
+    assert torch.equal(dbias.cpu(), bias.grad)
+
+
+@pytest.mark.parametrize("twin", [False, True])
 @pytest.mark.parametrize("B,osp", [(2, (5, 6, 16)), (1, (9, 4, 32)), (1, (40, 12, 16)), (2, (4, 5, 6))])
 def test_stem_wgrad_f16(ffi, B, osp, twin):
     """sk_train_stem_wgrad_f16 (the training step's stem: fp32 image x scaled 16-bit dy) against torch autograd on the
