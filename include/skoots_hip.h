@@ -275,6 +275,15 @@ int sk_conv3d_num_blocks(int B, int ox, int oy, int oz, int cout, int ksize);
 int64_t sk_conv3d_pack_weight_host(const float* w_host, int cout, int cin, int ksize,
                                    void* dst_host);
 
+/* One-pass stem (round 4): sk_conv3d_stem's normalisation + the conv ONCE, storing the RAW fp16 result (B, Xt, Yt, Zt, 32)
+ * next to its GroupNorm partial sums -- for a consumer that activates a raw source itself (sk_conv3d with
+ * sk_conv_src.affine: the single-chunk 32 -> 32 conv in LDS).  HipUNet.stem_single_pass selects it; the default stays the
+ * two-pass form (statistics, then apply), which measured the same time end to end. */
+int sk_conv3d_stem_raw(const void* image, int X, int Y, int Z, const int32_t* origins_host, int B, int Xt,
+                       int Yt, int Zt, float mean, float stdv, const float* weight, const float* bias,
+                       int cout, void* out_raw, float* gn_partial, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 /* Stem: first conv of the network (Cin = 1), fused with its GroupNorm + SiLU by running the
  * (cheap) conv twice instead of writing a raw tensor and re-reading it.
  * sk_conv3d_stem: cuts B tiles of extent (Xt,Yt,Zt) at origins_host[3*b..] out of the (X,Y,Z)

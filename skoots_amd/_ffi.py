@@ -85,6 +85,7 @@ _SIGS = {
     "sk_conv3d_upfold_num_blocks": (i32, [i32, i32, i32, i32]),
     "sk_conv3d_pack_weight_upfold_host": (i64, [fp, i32, i32, i32, vp]),
     "sk_conv3d_stem": (i32, [vp, i32, i32, i32, ip, i32, i32, i32, i32, f32, f32, vp, vp, i32, vp, vp, sz, vp]),
+    "sk_conv3d_stem_raw": (i32, [vp, i32, i32, i32, ip, i32, i32, i32, i32, f32, f32, vp, vp, i32, vp, vp, vp, sz, vp]),
     "sk_conv3d_stem_apply": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
     "sk_conv3d_stem_num_blocks": (i32, [i32, i32, i32]),
     "sk_conv3d_stem_workspace_bytes": (sz, [i32, i32, i32, i32]),
@@ -144,7 +145,7 @@ _SIGS = {
 # exported with the suffix _bf16, same signatures
 BF16_TWINS = (
     "sk_conv3d", "sk_conv3d_box", "sk_conv3d_box_split", "sk_conv3d_down_act", "sk_conv3d_down_act_split", "sk_conv3d_num_blocks", "sk_conv3d_pack_weight_host", "sk_conv3d_pack_weight_split_host",
-    "sk_conv3d_split", "sk_conv3d_stem", "sk_conv3d_stem_apply", "sk_conv3d_stem_apply_split",
+    "sk_conv3d_split", "sk_conv3d_stem", "sk_conv3d_stem_raw", "sk_conv3d_stem_apply", "sk_conv3d_stem_apply_split",
     "sk_conv3d_stem_num_blocks", "sk_conv3d_stem_workspace_bytes", "sk_groupnorm_finalize",
     "sk_groupnorm_finalize_stats", "sk_groupnorm_silu", "sk_groupnorm_silu_split", "sk_heads", "sk_heads_split",
     "sk_baked_embed_to_prob", "sk_train_absmax_scale", "sk_train_adamw", "sk_train_cast_f16_f32",

@@ -597,6 +597,30 @@ int sk_conv3d_stem(const void* image, int X, int Y, int Z, const int32_t* origin
     return SK_OK;
 }
 
+// One-pass form (round 4, measured against the two-pass form: DESIGN.md section 8): normalise, then the conv ONCE with the
+// raw fp16 result stored next to its statistics (stem_kernel<2>, the training path's mode); the consumer (the single-chunk
+// 32 -> 32 conv) activates the raw tensor in LDS.
+int sk_conv3d_stem_raw(const void* image, int X, int Y, int Z, const int32_t* origins_host, int B, int Xt,
+                       int Yt, int Zt, float mean, float stdv, const float* weight, const float* bias,
+                       int cout, void* out_raw, float* gn_partial, void* workspace, size_t workspace_bytes, void* stream) {
+    SK_CHECK_ARG(gn_partial && out_raw, "sk_conv3d_stem_raw: NULL output");
+    StemArgs a{};
+    int rc = fill_stem_args(a, image, X, Y, Z, origins_host, B, Xt, Yt, Zt, mean, stdv, weight, bias, cout,
+                            workspace, workspace_bytes);
+    if (rc) return rc;
+    a.partial = gn_partial;
+    a.out = (t16*)out_raw;
+    dim3 g1(Xt + 2, B);
+    stem_norm_kernel<<<g1, 256, 0, (hipStream_t)stream>>>(a);
+    SK_CHECK_ARG(Zt % 2 == 0 && stem_lds_bytes(Yt, Zt) <= 60 * 1024, "sk_conv3d_stem_raw: tile depth %d unsupported", Zt);
+    if (stem_lds_bytes(Yt, Zt) > 40 * 1024)
+        SK_CHECK_HIP(hipFuncSetAttribute((const void*)stem_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)stem_lds_bytes(Yt, Zt)));
+    stem_kernel<2><<<(unsigned)(a.nblk * B), 256, stem_lds_bytes(Yt, Zt), (hipStream_t)stream>>>(a);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
 static int stem_apply_impl(int B, int Xt, int Yt, int Zt, const float* weight, const float* bias,
                            const float* affine, void* out, int cout, const void* workspace, void* stream, bool split) {
     SK_CHECK_ARG(weight && bias && affine && out && workspace, "sk_conv3d_stem_apply: NULL pointer");

@@ -150,6 +150,7 @@ class HipUNet:
         self.defer_activation = True  # single-consumer tensors stay RAW and are activated on load (tools/ A/B switch)
         self.fold_upsample = True     # decoder convs: nearest-upsample folded into the weights (sk_conv3d_upfold; tools/ A/B switch)
         self.box_store = True         # with an out_box the last conv stores only the box the heads read (sk_conv3d_box; tools/ A/B switch)
+        self.stem_single_pass = False  # tools/ A/B switch: stem conv once (raw + statistics), enc0.1 activates it in LDS (fp16 mode)
 
     @property
     def split(self) -> bool:
@@ -293,7 +294,7 @@ class HipUNet:
         return (out, aff_out if want_raw else None)
 
     def _stem(self, layer: _ConvLayer, image: Tensor, origins, tile, mean: float, std: float,
-              tag: str = "L0a") -> Tensor:
+              tag: str = "L0a", raw: bool = False):
         """First block (Cin = 1): normalise + conv statistics, GroupNorm finalize, then the conv again
         with the affine + SiLU fused into its epilogue: the raw tensor is never written."""
         B = len(origins)
@@ -306,6 +307,11 @@ class HipUNet:
         ws_bytes = _ffi.lib.sk_conv3d_stem_workspace_bytes(B, xt, yt, zt)
         ws = self._buf("stem_ws", (ws_bytes,), torch.uint8)
         st = _ffi.stream_ptr(self.device)
+        if raw:   # one pass: the raw result + its statistics; the consumer activates
+            _ffi.check(_ffi.lib.sk_conv3d_stem_raw(_ffi.ptr(image), X, Y, Z, org, B, xt, yt, zt, mean, std,
+                                                   _ffi.ptr(layer.weight), _ffi.ptr(layer.bias), layer.cout, _ffi.ptr(out),
+                                                   _ffi.ptr(partial), _ffi.ptr(ws), ws_bytes, st))
+            return out, self._norm_act(layer, out, partial, nblk, apply=False)
         _ffi.check(_ffi.lib.sk_conv3d_stem(_ffi.ptr(image), X, Y, Z, org, B, xt, yt, zt, mean, std,
                                            _ffi.ptr(layer.weight), _ffi.ptr(layer.bias), layer.cout,
                                            _ffi.ptr(partial), _ffi.ptr(ws), ws_bytes, st))
@@ -365,8 +371,10 @@ class HipUNet:
             out = self._conv(layer, flat, shape, tag, activate=not want_raw, store_box=store_box)
             return out if want_raw else (out, None)
 
-        a = (self._stem(self.enc0[0], image, origins, L0, float(mean), float(std),
-                        "skip0" if len(self.enc0) == 1 else "L0a"), None)
+        stem_raw = self.stem_single_pass and len(self.enc0) > 1 and lds_act(self.enc0[1])
+        a = self._stem(self.enc0[0], image, origins, L0, float(mean), float(std),
+                       "skip0" if len(self.enc0) == 1 else "L0a", raw=stem_raw)
+        a = a if stem_raw else (a, None)
         keep("enc0.0", a)
         tags = ["L0b", "L0a"]
         for i, layer in enumerate(self.enc0[1:]):

@@ -125,6 +125,25 @@ def test_network_with_and_without_fold():
     assert (a.float() - b.float()).pow(2).mean().sqrt().item() <= 5e-4
 
 
+def test_network_with_one_pass_stem():
+    """HipUNet.stem_single_pass (round 4 A/B switch): the stem conv runs once, stores the raw fp16 result with its statistics
+    (sk_conv3d_stem_raw) and enc0.1 activates it in LDS.  Against the default two-pass stem (statistics, then the conv again
+    with the activation in its epilogue) the raw tensor is rounded to fp16 once more: the outputs differ by fp16 rounding
+    noise, inside the mode's distance from the fp32 oracle."""
+    from skoots_amd import unet as U
+    model = U.smoke_model(DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    vol = torch.randint(0, 256, (64, 64, 24), generator=g, device=DEV, dtype=torch.uint8).to(torch.float16)
+    origins = [(0, 0, 0), (4, 0, 4)]
+    a = model.forward_tiles(vol, origins, (60, 64, 20), 127.5, 73.9).clone()
+    model.stem_single_pass = True
+    b = model.forward_tiles(vol, origins, (60, 64, 20), 127.5, 73.9).clone()
+    model.stem_single_pass = False
+    assert not torch.equal(a, b)   # the switch took another path
+    assert (a.float() - b.float()).abs().max().item() <= 5e-3
+    assert (a.float() - b.float()).pow(2).mean().sqrt().item() <= 5e-4
+
+
 @pytest.mark.parametrize("shape", [(1, (8, 12, 20), 32, 32, 32), (2, (12, 14, 20), 32, 32, 32), (1, (14, 22, 10), 64, 64, 64),
                                    (1, (8, 8, 12), 32, 64, 32)])
 def test_upfold_split_vs_float64(shape):
