@@ -101,7 +101,11 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
     // per-wave transpose pad (2 KiB): the 32 x 32 (channel, voxel) result tile leaves the MFMA layout as whole 64-byte
     // voxel lines, 16 B per lane -- one store instruction writes 1 KiB contiguous (the tile's 32 voxels are contiguous
     // in the output).  8-byte stores straight from the MFMA layout ran the apply pass at 43 % of the write bandwidth.
-    __shared__ __attribute__((aligned(16))) char tpad[MODE == 0 ? 16 : 4 * 2048];
+    // (MODE 3: 4 KiB per wave -- both halves of the 32 [hi | lo] voxel lines, so that a store instruction writes eight WHOLE
+    // 128-byte lines; writing the hi halves and the lo halves in separate instructions left every line half-written between
+    // them and ran the split apply pass at 3.7 TB/s against 4.6 for the fp16 one)
+    constexpr int kPadW = MODE == 3 ? 4096 : 2048;
+    __shared__ __attribute__((aligned(16))) char tpad[MODE == 0 ? 16 : 4 * kPadW];
     extern __shared__ __attribute__((aligned(16))) unsigned int stem_lds[];  // [3][rows+2][Zt+2] halves
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
@@ -230,21 +234,40 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
                     r[k] = yv * __builtin_amdgcn_rcpf(1.0f + __expf(-yv));
                 }
             }
-            char* pad = tpad + w * 2048;
-            const int rv = lane >> 2, rc = lane & 3;    // read-back role: voxel (0..15), 16-byte chunk of its line
+            char* pad = tpad + w * kPadW;
             // the tile's 32 voxels are contiguous in the output: voxel index v0t + c, c = 0..31
             const long long v0t = ((long long)x * a.Yt + y0) * a.Zt + (long long)t * 32;
             t16* ob = a.out + ((long long)b * nvox + v0t) * kOutC;
+            if constexpr (MODE == 3) {
+                // pad: [voxel 32][hi 64 B | lo 64 B], 16-byte chunk c of voxel v at slot c ^ (v & 7); read back as whole lines:
+                // lane = (voxel 8 k + (lane >> 3), chunk lane & 7)
 #pragma unroll
-            for (int part = 0; part < (MODE == 3 ? 2 : 1); ++part) {
+                for (int part = 0; part < 2; ++part)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        half4v hv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const t16 hi = (t16)r[4 * q + j];
+                            hv[j] = part == 0 ? hi : (t16)(r[4 * q + j] - (float)hi);
+                        }
+                        *reinterpret_cast<half4v*>(pad + col * 128 + (((4 * part + q) ^ (col & 7)) * 16) + 8 * h) = hv;
+                    }
+                const int lv = lane >> 3, lc = lane & 7;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int vv = 8 * k + lv;
+                    const half8 line = *reinterpret_cast<const half8*>(pad + vv * 128 + ((lc ^ (vv & 7)) * 16));
+                    if (t * 32 + vv < nloc)
+                        __builtin_nontemporal_store(line, reinterpret_cast<half8*>(reinterpret_cast<char*>(ob + (long long)vv * kOutC) + lc * 16));
+                }
+            } else {
+                const int rv = lane >> 2, rc = lane & 3;    // read-back role: voxel (0..15), 16-byte chunk of its line
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     half4v hv;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const t16 hi = (t16)r[4 * q + j];
-                        hv[j] = part == 0 ? hi : (t16)(r[4 * q + j] - (float)hi);
-                    }
+                    for (int j = 0; j < 4; ++j) hv[j] = (t16)r[4 * q + j];
                     *reinterpret_cast<half4v*>(pad + col * 64 + ((q ^ ((col >> 1) & 3)) * 16) + 8 * h) = hv;
                 }
 #pragma unroll
@@ -252,7 +275,7 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
                     const int vv = rv + 16 * hh;
                     const half8 line = *reinterpret_cast<const half8*>(pad + vv * 64 + ((rc ^ ((vv >> 1) & 3)) * 16));
                     if (t * 32 + vv < nloc)
-                        __builtin_nontemporal_store(line, reinterpret_cast<half8*>(reinterpret_cast<char*>(ob + (long long)vv * kOutC) + part * 64 + rc * 16));
+                        __builtin_nontemporal_store(line, reinterpret_cast<half8*>(reinterpret_cast<char*>(ob + (long long)vv * kOutC) + rc * 16));
                 }
             }
         }
