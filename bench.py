@@ -612,7 +612,8 @@ def eval_main(args, rank, world, local):
                 "value": round(voxels / (dt / steps) / 1e6, 3), "unit": "Mvoxels/s",
                 "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": {"fp16": "f16", "split": "f16 hi+lo pairs (3 MFMA products, f32 accumulate)", "fp32": "f32"}[precision],
+                "dtype": {"fp16": "f16", "split": "f16 hi+lo pairs (3 MFMA products, f32 accumulate)",
+                          "mix8": "f16 hi+lo pairs; the 32->32 convs: f16 product + block-scaled fp8 correction product", "fp32": "f32"}[precision],
                 "data": "synthetic",
                 "config": {"workload": f"{X}x{Y}x{Z} fp16 volume, 300x300x20 tiles (margin 50,50,5), "
                                        f"U-Net dims [32,64,128,64,32] depths [2,2,2,2,2], N=10 follow, "
@@ -847,7 +848,7 @@ def main():
                          "file, so only launch tails overlap) -- not the default: overlapped launches make rocprofv3's per-kernel "
                          "durations of the same command incomparable with `roofline`, which is then taken in one extra single-stream step")
     ap.add_argument("--no-fold", action="store_true", help="A/B: decoder convs on the direct kernels instead of sk_conv3d_upfold")
-    ap.add_argument("--precision", choices=["fp16", "split", "fp32", "bf16", "mixed"], default=None,
+    ap.add_argument("--precision", choices=["fp16", "split", "mix8", "fp32", "bf16", "mixed"], default=None,
                     help="eval: fp16 (default) | split (<= 1e-3 vs fp32) | fp32; train: bf16 (default) | mixed (fp16) | fp32")
     ap.add_argument("--no-also", action="store_true",
                     help="N = 1 fp16 eval line only: skip the `also` legs (split precision on the same volume, one bf16 training leg)")
@@ -877,8 +878,8 @@ def main():
         if args.precision not in ("bf16", "mixed", "fp32"):
             raise SystemExit(f"--precision {args.precision} is an eval precision; train takes bf16 | mixed | fp32")
         return train_main(args, rank, world, local)
-    if args.precision not in ("fp16", "split", "fp32"):
-        raise SystemExit(f"--precision {args.precision} is a training precision; eval takes fp16 | split | fp32")
+    if args.precision not in ("fp16", "split", "mix8", "fp32"):
+        raise SystemExit(f"--precision {args.precision} is a training precision; eval takes fp16 | split | mix8 | fp32")
     eval_main(args, rank, world, local)
 
 

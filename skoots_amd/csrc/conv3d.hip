@@ -32,6 +32,8 @@
 //     sk_groupnorm_finalize (deterministic, no float atomics).
 #include <stdlib.h>
 
+#include <cmath>
+
 #include <type_traits>
 #include <vector>
 
@@ -74,6 +76,7 @@ struct Conv3Args {
     int mode;           // 0: linear (y,z) ranges (small Zt), 1: TY x TZ rectangles
     int TZ, nzc;
     int pitch, nposp;
+    int w8_off, w8_scale, wpk_bytes;   // MIX8: byte offset of the fp8 fragments in wpk, E8M0 scale word of the weights, bytes of wpk
     int jstep;          // conv3_m16_kernel: region positions from a lane's voxel c16 to voxel 16 + c16 of its column tile (16 | pitch)
     // act[i] != NULL: source i is the RAW output of its producing conv and act[i] (B, 2, C_i) the affine of its GroupNorm:
     // every lane applies silu(a*x + b) to the chunks it staged itself, in LDS, once its own LDS-DMA has landed -- the
@@ -652,7 +655,11 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
 // load as heavily as the matrix pipe.  Two rows fit next to the six-plane ring of the production
 // tile (80 256 B: still two workgroups per CU): 12 of the 36 weight loads per wave and step become LDS reads,
 // enc0.1 0.677 -> 0.655 ms, dec0.1 0.867 -> 0.848 ms per 8 tiles (tools/layer_ab.py).
-template <int COUT, int XS, int RES = 0, bool SPLIT = false, int WL = 0>
+// MIX8 (round 4, precision "mix8"; needs SPLIT for the output format): a logical chunk is an fp16 phase (x_hi w_hi) and ONE fp8 phase
+// that carries both cross terms -- K = [x8 | x_lo8] . [w_lo8 | w8] of TWO tap rows per v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3
+// operands at twice the fp16 rate, nine tap rows as five pairs) -- instead of split's three fp16 phases.  The source voxel line is
+// [hi fp16 (32) | x8 (32) | lo8 (32)], 128 bytes as a split line, so staging is unchanged; see sk_conv3d_mix8.
+template <int COUT, int XS, int RES = 0, bool SPLIT = false, int WL = 0, bool MIX8 = false>
 __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     constexpr int NT = COUT / 32;
     constexpr int P = NT;            // column tiles per wave
@@ -897,7 +904,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     // weight fragments through a buffer resource: wave-uniform byte offset in an SGPR + the constant lane * 16 in one VGPR
     // (no 64-bit address arithmetic in the tap loop)
     auto wbase = [&](int ch) { return (unsigned)((ch * (9 * 2 * 3 * NT) + wn) * 1024); };
-    const __amdgpu_buffer_rsrc_t wrsrc = sk::make_rsrc(a.wpk, (unsigned)(a.nchunks * (9 * 2 * 3 * NT) * 1024));
+    const __amdgpu_buffer_rsrc_t wrsrc = sk::make_rsrc(a.wpk, MIX8 ? (unsigned)a.wpk_bytes : (unsigned)(a.nchunks * (9 * 2 * 3 * NT) * 1024));
     const unsigned wlane = lane * 16;
     auto wload = [&](unsigned off) {
         return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, __builtin_amdgcn_readfirstlane(off), 0));
@@ -988,7 +995,57 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
             // takes 2.1x its MFMA cycles -- 2x is the share of the pipe when the co-resident wave multiplies too, the
             // rest is a wave that has the SIMD to itself exposing one LDS latency per body.  dec0.0 (two chunks):
             // 1.316 -> 1.228 ms per 8 tiles (-6.7 %); the single-chunk layers keep RES = 2 (resident rows beat it, +3 %).
-            if constexpr (RES == 0 && NT == 1) {
+            const bool f8phase = MIX8 && (a.chinfo[ch] & 4u);
+            if (f8phase) {
+                if constexpr (MIX8) {
+                    typedef int v8i __attribute__((ext_vector_type(8)));
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    // this lane's K block of an instruction: g >> 1 = which tap row of the pair, g & 1 = x8 (0) | lo8 (1):
+                    // 32 contiguous bytes of the staged position (two 16-byte slots; the plane swizzle exchanges the 32-byte halves)
+                    const int halfsel = (g & 1) * 2;
+                    const int sa = a.w8_scale, sb = 0x70707070;   // E8M0: weights 2^-b (host), activations 2^-15
+#pragma unroll 1
+                    for (int rp = 0; rp < 5; ++rp) {
+                        const int rr = min(2 * rp + (g >> 1), 8);   // (the tenth row does not exist: its weights are zero)
+                        const int dz = rr % 3 - 1;
+                        const int tapoff = (rr / 3 - 1) * pitch + dz;
+                        const unsigned wrp = (unsigned)a.w8_off + (unsigned)(rp * 6) * 2048u + wlane * 2;
+                        // the six weight fragments of the row pair (both cout halves x three x taps: 48 registers), then plane by plane
+                        v8i af[2][3];
+#pragma unroll
+                        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) {
+                                const unsigned wo = wrp + (unsigned)((i2 * 3 + d) * 2048);
+                                const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wo, 0, 0);
+                                const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wo + 16, 0, 0);
+                                af[i2][d] = v8i{(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+                            }
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int qj = q_row[0] + tapoff + j * a.jstep;
+                            int addr = (qj * 4 + (halfsel ^ (((qj >> 2) & 1) << 1))) * 16;
+                            if (dz < 0 && zlo(0, j)) addr = sk::zero_of(zero_addr, addr);
+                            if (dz > 0 && zhi(0, j)) addr = sk::zero_of(zero_addr, addr);
+#pragma unroll
+                            for (int i = 0; i < R; ++i) {
+                                const u32x4 lo4 = *reinterpret_cast<const u32x4*>(lds + pslot[i] + addr);
+                                const u32x4 hi4 = *reinterpret_cast<const u32x4*>(lds + pslot[i] + addr + 16);
+                                const v8i bf = v8i{(int)lo4[0], (int)lo4[1], (int)lo4[2], (int)lo4[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+#pragma unroll
+                                for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                                    for (int d = 0; d < 3; ++d) {
+                                        const int o = i - d;
+                                        if (o >= 0 && o < XS)
+                                            acc[0][o][i2][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i2][d], bf, acc[0][o][i2][j], 0, 0,
+                                                                                                               0, sa, 0, sb);
+                                    }
+                            }
+                        }
+                    }
+                }
+            } else if constexpr (RES == 0 && NT == 1) {
                 half8 bb[2][2][R];
                 auto load_row = [&](int dydz, half8 (&dst)[2][R]) {
                     const int dz = dydz % 3 - 1;
@@ -2496,9 +2553,12 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
     return 0;
 }
 
-template <int XS, int RES = 0, bool SPLIT = false, int WL = 0>
+// mix8 weight image (sk_conv3d_pack_weight_mix8_host): the 54 fp16 fragments of w_hi, then 30 fp8 fragments of 2 KiB
+constexpr int kMix8Fp16Bytes = 54 * 1024, kMix8Fp8Bytes = 5 * 2 * 3 * 2048;
+
+template <int XS, int RES = 0, bool SPLIT = false, int WL = 0, bool MIX8 = false>
 int launch_conv3_m16(const Conv3Args& a, const Plan& p, hipStream_t stream) {
-    auto kern = conv3_m16_kernel<32, XS, RES, SPLIT, WL>;
+    auto kern = conv3_m16_kernel<32, XS, RES, SPLIT, WL, MIX8>;
     const size_t lds = p.lds + (RES > 0 ? WL * 6144 : 0);   // the ring + the tap rows kept in LDS behind it
     if (lds > 48 * 1024)
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2659,7 +2719,8 @@ static int launch_down2(const void* in, const float* affine, int writeback, cons
 
 static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,
                        int B, int ox, int oy, int oz, int cout, int ksize, float* gn_partial,
-                       void* zeros, void* stream_, const bool split, const int* store_box = nullptr) {
+                       void* zeros, void* stream_, const bool split, const int* store_box = nullptr,
+                       const bool mix8 = false, const int w8_scale_exp = 0) {
     hipStream_t stream = (hipStream_t)stream_;
     const int lanes = split ? 2 : 1;   // fp16 values per logical channel in a voxel line: [hi | lo]
     SK_CHECK_ARG(srcs && weight && bias && out, "sk_conv3d: NULL pointer");
@@ -2709,6 +2770,9 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
             SK_CHECK_ARG(a.nchunks + (split ? 3 : 1) <= kMaxChunks, "sk_conv3d: too many input channels (%d)", cin);
             if (!split) {
                 a.chinfo[a.nchunks++] = (unsigned)si | (off << 8);
+            } else if (mix8) {   // [hi fp16 | x8 | lo8] lines: the fp16 phase, then ONE fp8 phase over the 64 bytes behind the hi halves
+                a.chinfo[a.nchunks++] = (unsigned)si | (off << 8);
+                a.chinfo[a.nchunks++] = (unsigned)si | 4u | (lo_off << 8);
             } else {
                 a.chinfo[a.nchunks++] = (unsigned)si | (off << 8);
                 a.chinfo[a.nchunks++] = (unsigned)si | 2u | (off << 8);
@@ -2755,6 +2819,15 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
                 SK_CHECK_ARG(a.box_lo[k] >= 0 && a.box_lo[k] <= a.box_hi[k], "sk_conv3d_box: bad box on axis %d", k);
             }
             a.has_box = 1;
+        }
+        if (mix8) {
+            SK_CHECK_ARG(split && cout == 32 && cin == 32 && n_src == 1 && !srcs[0].upsample,
+                         "sk_conv3d_mix8: one plain 32-channel source, 32 output channels");
+            SK_CHECK_ARG(w8_scale_exp >= 0 && w8_scale_exp < 64, "sk_conv3d_mix8: bad weight scale exponent %d", w8_scale_exp);
+            a.w8_off = kMix8Fp16Bytes;
+            a.wpk_bytes = kMix8Fp16Bytes + kMix8Fp8Bytes;
+            a.w8_scale = 0x01010101 * (127 - w8_scale_exp);
+            return p.xs == 3 ? launch_conv3_m16<3, 0, true, 0, true>(a, p, stream) : launch_conv3_m16<4, 0, true, 0, true>(a, p, stream);
         }
         if (split) {
             if (cout == 32) return p.xs == 3 ? launch_conv3_m16<3, 0, true>(a, p, stream) : launch_conv3_m16<4, 0, true>(a, p, stream);
@@ -2849,6 +2922,78 @@ int sk_conv3d_down_act(void* in_raw, const float* affine, const void* weight, co
                        int ox, int oy, int oz, int cin, int cout, float* gn_partial, void* zeros, void* stream) {
     SK_CHECK_ARG(affine, "sk_conv3d_down_act: affine is NULL (use sk_conv3d for an activated input)");
     return launch_down2(in_raw, affine, 1, weight, bias, out, B, ox, oy, oz, cin, cout, gn_partial, zeros, (hipStream_t)stream);
+}
+
+// OCP e4m3fn of a float, round to nearest even, saturating at +-448
+static uint8_t f32_to_e4m3(float v) {
+    const uint8_t sgn = std::signbit(v) ? 0x80 : 0x00;
+    float a = std::fabs(v);
+    if (!(a == a)) return 0x7F;
+    if (a >= 448.0f) return sgn | 0x7E;
+    if (a < 0.0009765625f) return sgn;                              // below half of the smallest subnormal 2^-9
+    int e;
+    (void)std::frexp(a, &e);                                        // a = m * 2^e, m in [0.5, 1)
+    e -= 1;                                                         // a in [2^e, 2^(e+1))
+    if (e < -6) {                                                   // subnormal: units of 2^-9
+        const int q = (int)std::nearbyint(a * 512.0f);
+        return sgn | (uint8_t)(q >= 8 ? 0x08 : q);
+    }
+    int m = (int)std::nearbyint((a / std::ldexp(1.0f, e) - 1.0f) * 8.0f);
+    if (m == 8) {
+        m = 0;
+        ++e;
+    }
+    if (e > 8) return sgn | 0x7E;
+    const int code = ((e + 7) << 3) | m;
+    return sgn | (uint8_t)(code > 0x7E ? 0x7E : code);
+}
+
+int64_t sk_conv3d_pack_weight_mix8_host(const float* w, int cout, int cin, void* dst, int* scale_exp) {
+    // precision "mix8", 3x3x3, 32 -> 32: [w_hi as sk_conv3d_pack_weight_host packs it (54 KiB)] [fp8 fragments (60 KiB)].
+    // fp8 fragment (tap-row pair rp = 0..4, cout half i, x tap dx): lane l holds, for cout 16 i + (l & 15), the 32 bytes of K
+    // block g = l >> 4:  g 0: e4m3(2^(b+11) w_lo) of row 2 rp | g 1: e4m3(2^b w) of row 2 rp | g 2, 3: the same of row 2 rp + 1
+    // (zeros for the tenth row); byte j = input channel j.  b = *scale_exp: the largest power of two with 2^b max|w| <= 240.
+    if (cout != 32 || cin != 32) {
+        sk::set_error("sk_conv3d_pack_weight_mix8_host: cout = cin = 32 only (got %d, %d)", cout, cin);
+        return SK_ERR_ARG;
+    }
+    const int64_t total = kMix8Fp16Bytes + kMix8Fp8Bytes;
+    if (!dst) return total;
+    const int64_t n = (int64_t)cout * cin * 27;
+    std::vector<float> hi(n);
+    float wmax = 0.0f;
+    for (int64_t i = 0; i < n; ++i) {
+        hi[i] = (float)((t16)(w[i]));
+        wmax = std::fmax(wmax, std::fabs(w[i]));
+    }
+    int b = 0;
+    while (b < 40 && std::ldexp(wmax, b + 1) <= 240.0f) ++b;
+    if (scale_exp) *scale_exp = b;
+    const int64_t got = sk_conv3d_pack_weight_host(hi.data(), cout, cin, 3, dst);
+    if (got != kMix8Fp16Bytes) return SK_ERR_ARG;
+    uint8_t* o = (uint8_t*)dst + kMix8Fp16Bytes;
+    auto W = [&](int co, int ci, int kx, int row) { return (int64_t)((co * cin + ci) * 3 + kx) * 9 + row; };   // (ky, kz) = row / 3, row % 3
+    int64_t f = 0;
+    for (int rp = 0; rp < 5; ++rp)
+        for (int i = 0; i < 2; ++i)
+            for (int dx = 0; dx < 3; ++dx, ++f)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 32; ++j) {
+                        const int g = l >> 4, row = 2 * rp + (g >> 1), co = 16 * i + (l & 15);
+                        uint8_t v = 0;
+                        if (row < 9) {
+                            const int64_t idx = W(co, j, dx, row);
+                            v = (g & 1) ? f32_to_e4m3(std::ldexp(w[idx], b)) : f32_to_e4m3(std::ldexp(w[idx] - hi[idx], b + 11));
+                        }
+                        o[f * 2048 + l * 32 + j] = v;
+                    }
+    return total;
+}
+
+int sk_conv3d_mix8(const sk_conv_src* srcs, int n_src, const void* weight, int weight_scale_exp, const float* bias, void* out,
+                   int B, int ox, int oy, int oz, int cout, float* gn_partial, void* zeros, const int* store_box, void* stream) {
+    return conv3d_impl(srcs, n_src, weight, bias, out, B, ox, oy, oz, cout, 3, gn_partial, zeros, stream, true, store_box, true,
+                       weight_scale_exp);
 }
 
 int sk_conv3d_down_act_split(void* in_raw, const float* affine, const void* weight, const float* bias, void* out, int B,

@@ -92,11 +92,12 @@ static int stem_rows(int Yt, int Zt) {
 
 // MODE 0: statistics only; 1: recompute + affine + SiLU, store the activation; 2 (training, mixed precision):
 // statistics AND the raw fp16 result in one pass (the backward needs the raw tensor anyway); 3: as 1, but the
-// activation is stored as a split pair [hi (32) | lo (32)] per voxel (value = hi + lo, precision "split")
+// activation is stored as a split pair [hi (32) | lo (32)] per voxel (value = hi + lo, precision "split"); 4: as 3, but the
+// line is [hi fp16 (32) | x8 (32) | lo8 (32)] -- e4m3(16 x) and e4m3(2^15 (x - hi)) -- for a precision "mix8" consumer
 template <int MODE>
 __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
     constexpr bool STATS = MODE == 0 || MODE == 2;
-    constexpr int kOutC = MODE == 3 ? 64 : 32;   // halves per output voxel line
+    constexpr int kOutC = (MODE == 3 || MODE == 4) ? 64 : 32;   // halves per output voxel line
     __shared__ float red[4 * 16];
     // per-wave transpose pad (2 KiB): the 32 x 32 (channel, voxel) result tile leaves the MFMA layout as whole 64-byte
     // voxel lines, 16 B per lane -- one store instruction writes 1 KiB contiguous (the tile's 32 voxels are contiguous
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
     // (MODE 3: 4 KiB per wave -- both halves of the 32 [hi | lo] voxel lines, so that a store instruction writes eight WHOLE
     // 128-byte lines; writing the hi halves and the lo halves in separate instructions left every line half-written between
     // them and ran the split apply pass at 3.7 TB/s against 4.6 for the fp16 one)
-    constexpr int kPadW = MODE == 3 ? 4096 : 2048;
+    constexpr int kPadW = (MODE == 3 || MODE == 4) ? 4096 : 2048;
     __shared__ __attribute__((aligned(16))) char tpad[MODE == 0 ? 16 : 4 * kPadW];
     extern __shared__ __attribute__((aligned(16))) unsigned int stem_lds[];  // [3][rows+2][Zt+2] halves
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -238,11 +239,11 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
             // the tile's 32 voxels are contiguous in the output: voxel index v0t + c, c = 0..31
             const long long v0t = ((long long)x * a.Yt + y0) * a.Zt + (long long)t * 32;
             t16* ob = a.out + ((long long)b * nvox + v0t) * kOutC;
-            if constexpr (MODE == 3) {
+            if constexpr (MODE == 3 || MODE == 4) {
                 // pad: [voxel 32][hi 64 B | lo 64 B], 16-byte chunk c of voxel v at slot c ^ (v & 7); read back as whole lines:
                 // lane = (voxel 8 k + (lane >> 3), chunk lane & 7)
 #pragma unroll
-                for (int part = 0; part < 2; ++part)
+                for (int part = 0; part < (MODE == 3 ? 2 : 1); ++part)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         half4v hv;
@@ -253,6 +254,25 @@ __global__ void __launch_bounds__(256) stem_kernel(StemArgs a) {
                         }
                         *reinterpret_cast<half4v*>(pad + col * 128 + (((4 * part + q) ^ (col & 7)) * 16) + 8 * h) = hv;
                     }
+                if constexpr (MODE == 4) {   // x8 = e4m3(16 x): chunks 4, 5; lo8 = e4m3(2^15 (x - hi)): chunks 6, 7; byte = channel 8 q + 4 h + j
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float xs[4], ls[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = r[4 * q + j];
+                            xs[j] = fminf(fmaxf(v * 16.0f, -448.0f), 448.0f);
+                            ls[j] = fminf(fmaxf((v - (float)(t16)v) * 32768.0f, -448.0f), 448.0f);
+                        }
+                        int px = 0, pl = 0;
+                        px = __builtin_amdgcn_cvt_pk_fp8_f32(xs[0], xs[1], px, false);
+                        px = __builtin_amdgcn_cvt_pk_fp8_f32(xs[2], xs[3], px, true);
+                        pl = __builtin_amdgcn_cvt_pk_fp8_f32(ls[0], ls[1], pl, false);
+                        pl = __builtin_amdgcn_cvt_pk_fp8_f32(ls[2], ls[3], pl, true);
+                        *reinterpret_cast<int*>(pad + col * 128 + (((4 + (q >> 1)) ^ (col & 7)) * 16) + 8 * (q & 1) + 4 * h) = px;
+                        *reinterpret_cast<int*>(pad + col * 128 + (((6 + (q >> 1)) ^ (col & 7)) * 16) + 8 * (q & 1) + 4 * h) = pl;
+                    }
+                }
                 const int lv = lane >> 3, lc = lane & 7;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -435,6 +455,51 @@ __global__ void __launch_bounds__(256) gn_silu_split_kernel(t16* __restrict__ x,
         }
         ph[0] = rh;
         ph[vpc] = rl;
+    }
+}
+
+// precision "mix8": raw split line [hi (32) | lo16 (32)] in, activated [hi fp16 (32) | x8 (32) | lo8 (32)] out, in place (C = 32).
+// The four lanes of a voxel sit in one wave and every lane loads before any lane stores: the x8 / lo8 bytes of one lane overwrite
+// raw lo halves that ANOTHER lane of the same voxel has already read.
+__global__ void __launch_bounds__(256) gn_silu_mix8_kernel(t16* __restrict__ x, const float* __restrict__ affine, long long nvox_per_batch) {
+    constexpr int C = 32;
+    const int b = blockIdx.y;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // (voxel, octet)
+    const long long stride = (long long)gridDim.x * 256;           // multiple of 4
+    const int o = (int)(i & 3);
+    float ga[8], gb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ga[j] = affine[((long long)b * 2) * C + 8 * o + j];
+        gb[j] = affine[((long long)b * 2 + 1) * C + 8 * o + j];
+    }
+    char* base = reinterpret_cast<char*>(x) + (long long)b * nvox_per_batch * 128;
+    for (; i < nvox_per_batch * 4; i += stride) {
+        char* line = base + (i >> 2) * 128;
+        const half8 vh = *reinterpret_cast<const half8*>(line + 16 * o);
+        const half8 vl = *reinterpret_cast<const half8*>(line + 64 + 16 * o);
+        half8 rh;
+        float xs[8], ls[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {   // gn_silu_split_kernel's arithmetic up to the split
+            const float xv = (float)vh[j] + (float)vl[j];
+            const float y = fmaf(ga[j], xv, gb[j]);
+            const float sv = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+            rh[j] = sk::round_t16(sv);
+            xs[j] = fminf(fmaxf(sv * 16.0f, -448.0f), 448.0f);
+            ls[j] = fminf(fmaxf((sv - (float)rh[j]) * 32768.0f, -448.0f), 448.0f);
+        }
+        int px[2] = {0, 0}, pl[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            px[k] = __builtin_amdgcn_cvt_pk_fp8_f32(xs[4 * k], xs[4 * k + 1], px[k], false);
+            px[k] = __builtin_amdgcn_cvt_pk_fp8_f32(xs[4 * k + 2], xs[4 * k + 3], px[k], true);
+            pl[k] = __builtin_amdgcn_cvt_pk_fp8_f32(ls[4 * k], ls[4 * k + 1], pl[k], false);
+            pl[k] = __builtin_amdgcn_cvt_pk_fp8_f32(ls[4 * k + 2], ls[4 * k + 3], pl[k], true);
+        }
+        *reinterpret_cast<half8*>(line + 16 * o) = rh;
+        *reinterpret_cast<int2*>(line + 64 + 8 * o) = make_int2(px[0], px[1]);
+        *reinterpret_cast<int2*>(line + 96 + 8 * o) = make_int2(pl[0], pl[1]);
     }
 }
 
@@ -645,7 +710,7 @@ int sk_conv3d_stem_raw(const void* image, int X, int Y, int Z, const int32_t* or
 }
 
 static int stem_apply_impl(int B, int Xt, int Yt, int Zt, const float* weight, const float* bias,
-                           const float* affine, void* out, int cout, const void* workspace, void* stream, bool split) {
+                           const float* affine, void* out, int cout, const void* workspace, void* stream, bool split, bool mix8 = false) {
     SK_CHECK_ARG(weight && bias && affine && out && workspace, "sk_conv3d_stem_apply: NULL pointer");
     SK_CHECK_ARG(cout == 32 && B >= 1 && B <= kStemMaxB, "sk_conv3d_stem_apply: bad cout / batch");
     StemArgs a{};
@@ -660,7 +725,7 @@ static int stem_apply_impl(int B, int Xt, int Yt, int Zt, const float* weight, c
     a.out = (t16*)out;
     a.nblk = sk_conv3d_stem_num_blocks(Xt, Yt, Zt);
     a.rows = stem_rows(Yt, Zt);
-    auto kern = split ? stem_kernel<3> : stem_kernel<1>;
+    auto kern = mix8 ? stem_kernel<4> : (split ? stem_kernel<3> : stem_kernel<1>);
     if (stem_lds_bytes(Yt, Zt) > 40 * 1024)
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)stem_lds_bytes(Yt, Zt)));
@@ -677,6 +742,11 @@ int sk_conv3d_stem_apply(int B, int Xt, int Yt, int Zt, const float* weight, con
 int sk_conv3d_stem_apply_split(int B, int Xt, int Yt, int Zt, const float* weight, const float* bias,
                                const float* affine, void* out, int cout, const void* workspace, void* stream) {
     return stem_apply_impl(B, Xt, Yt, Zt, weight, bias, affine, out, cout, workspace, stream, true);
+}
+
+int sk_conv3d_stem_apply_mix8(int B, int Xt, int Yt, int Zt, const float* weight, const float* bias,
+                              const float* affine, void* out, int cout, const void* workspace, void* stream) {
+    return stem_apply_impl(B, Xt, Yt, Zt, weight, bias, affine, out, cout, workspace, stream, true, true);
 }
 
 // ---- training, mixed precision: the stem as a fast block -------------------------------------------------------
@@ -776,6 +846,15 @@ int sk_groupnorm_silu_split(void* x, const float* affine, int B, int64_t voxels,
     long long nvec = voxels * (C / 8);
     dim3 grid(sk::stream_grid(nvec, 256, 4), B);
     gn_silu_split_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((t16*)x, affine, C, nvec);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
+int sk_groupnorm_silu_mix8(void* x, const float* affine, int B, int64_t voxels, int C, void* stream) {
+    SK_CHECK_ARG(x && affine, "sk_groupnorm_silu_mix8: NULL pointer");
+    SK_CHECK_ARG(C == 32, "sk_groupnorm_silu_mix8: C must be 32 (got %d)", C);
+    dim3 grid(sk::stream_grid(voxels * 4, 256, 4), B);
+    gn_silu_mix8_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((t16*)x, affine, (long long)voxels);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }

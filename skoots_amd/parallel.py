@@ -431,7 +431,7 @@ class ShardedVolume:
         n_streams = max(1, int(streams)) if model is not None else 1
         if model is not None:   # None / too large a request: clamped to the tile count and the free device memory
             tile_batch = pick_tile_batch(len(origins), eff, dev, contexts=n_streams,
-                                         split=getattr(model, "precision", "fp16") == "split", requested=tile_batch)
+                                         split=getattr(model, "precision", "fp16") in ("split", "mix8"), requested=tile_batch)
         elif tile_batch is None:
             tile_batch = MAX_TILE_BATCH
         self.tile_batch_used = tile_batch

@@ -24,7 +24,7 @@ from . import _ffi
 
 GN_GROUPS = 8
 GN_EPS = 1e-5
-PRECISIONS = ("fp16", "split", "fp32")
+PRECISIONS = ("fp16", "split", "mix8", "fp32")
 
 
 class _ConvLayer:
@@ -64,6 +64,14 @@ class _ConvLayer:
     @property
     def weight(self) -> Tensor:
         return self.packed(False)
+
+    def packed_mix8(self) -> Tuple[Tensor, int]:
+        """Weight image of ``sk_conv3d_mix8`` (fp16 fragments of w_hi + block-scaled fp8 fragments of w_lo and w) and its
+        fp8 scale exponent; packed on first use."""
+        t = self._packed.get("mix8")
+        if t is None:
+            t = self._packed["mix8"] = pack_conv_weight_mix8(self._w_cpu, self._device)
+        return t
 
     def packed_upfold(self, c_skip: int, split: bool = False) -> Tensor:
         """Fragments of ``sk_conv3d_upfold`` / ``sk_conv3d_upfold_split`` (decoder conv, the nearest-upsample of the last
@@ -113,8 +121,10 @@ class HipUNet:
         """``precision``: "fp16" (fast path: fp16 MFMA operands, fp32 accumulation -- what the reference's fp16
         autocast does, eval.py:142; max-abs ~5e-3 against an fp32 forward), "split" (activations and weights as
         fp16 hi + lo pairs, three fp16 MFMAs per product: max-abs <= 1e-3 against fp32, BASELINE.json's tolerance,
-        at ~1/3 of the fast path's speed) or "fp32" (every layer on the exact-fp32 matrix instruction; the parity
-        reference of the other two, ~1/11 of the fast path's speed)."""
+        at ~1/3 of the fast path's speed), "mix8" ("split" whose 32 -> 32 3x3x3 convs -- enc0.1.., dec0.1.. -- take their two
+        correction products w_lo x and w x_lo as one block-scaled fp8 matrix product, sk_conv3d_mix8: the corrections are
+        2^-11 of the result, so e4m3's 2^-4 keeps them to ~2^-15; every other layer as "split") or "fp32" (every layer on
+        the exact-fp32 matrix instruction; the parity reference of the others, ~1/11 of the fast path's speed)."""
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {PRECISIONS}")
         self.precision = precision
@@ -154,7 +164,11 @@ class HipUNet:
 
     @property
     def split(self) -> bool:
-        return self.precision == "split"
+        return self.precision in ("split", "mix8")   # tensors are [hi | lo] pairs
+
+    @property
+    def mix8(self) -> bool:
+        return self.precision == "mix8"
 
     def clone_context(self) -> "HipUNet":
         """Same weights, separate activation buffers: lets two tile batches be in flight on two
@@ -194,7 +208,7 @@ class HipUNet:
         return t[:n].view(shape)
 
     # -- layer launchers ---------------------------------------------------------------
-    def _norm_act(self, layer: _ConvLayer, x: Tensor, partial: Tensor, nblk: int, apply: bool = True) -> Tensor:
+    def _norm_act(self, layer: _ConvLayer, x: Tensor, partial: Tensor, nblk: int, apply: bool = True, mix_out: bool = False) -> Tensor:
         """GroupNorm statistics -> per-channel affine; ``apply`` runs the fused affine + SiLU pass in
         place.  With ``apply=False`` the tensor stays RAW and the (single) consumer applies the affine
         on load (gather GEMM / heads: every element is read exactly once there)."""
@@ -207,11 +221,13 @@ class HipUNet:
                                                   _ffi.ptr(aff), st))
         if apply:
             fn = _ffi.lib.sk_groupnorm_silu_split if self.split else _ffi.lib.sk_groupnorm_silu
+            if mix_out:   # the consumer is sk_conv3d_mix8: [hi | x8 | lo8] lines
+                fn = _ffi.lib.sk_groupnorm_silu_mix8
             _ffi.check(fn(_ffi.ptr(x), _ffi.ptr(aff), B, vox, layer.cout, st))
         return aff
 
     def _conv(self, layer: _ConvLayer, srcs: List[Tuple], out_shape: Tuple[int, int, int],
-              tag: str, activate: bool = True, store_box=None):
+              tag: str, activate: bool = True, store_box=None, mix_in: bool = False, mix_out: bool = False):
         """srcs: [(tensor, upsample flag[, affine])].  Returns the activated output, or
         (raw output, affine) when ``activate`` is False.  ``store_box`` = (lo, hi): the only reader of the output looks at
         this box of it (the heads, with an ``out_box``): the conv may leave the rest unwritten (sk_conv3d_box; its
@@ -246,7 +262,16 @@ class HipUNet:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
-        if fold:
+        if mix_in:   # precision "mix8": the source holds [hi | x8 | lo8] lines
+            assert len(srcs) == 1 and layer.ksize == 3 and layer.cin == layer.cout == 32 and arr[0].affine is None and not fold
+            wimg, wexp = layer.packed_mix8()
+            box = None
+            if store_box is not None and not activate:
+                box = (C.c_int32 * 6)(*[int(v) for v in store_box[0]], *[int(v) for v in store_box[1]])
+            _ffi.check(_ffi.lib.sk_conv3d_mix8(arr, 1, _ffi.ptr(wimg), wexp, _ffi.ptr(layer.bias), _ffi.ptr(out), B, ox, oy, oz,
+                                               layer.cout, _ffi.ptr(partial), _ffi.ptr(self.zeros), box,
+                                               _ffi.stream_ptr(self.device)))
+        elif fold:
             ufn = _ffi.lib.sk_conv3d_upfold_split if split else _ffi.lib.sk_conv3d_upfold
             _ffi.check(ufn(arr[0].data, arr[0].c, arr[1].data, arr[1].c,
                            _ffi.ptr(layer.packed_upfold(arr[0].c, split)), _ffi.ptr(layer.bias), _ffi.ptr(out),
@@ -268,7 +293,7 @@ class HipUNet:
             per_voxel = 2.0 * layer.cout * (arr[0].c * 27 + arr[1].c * 8) if fold else layer.flops_per_out_voxel
             # split mode: three fp16 MFMA products (w_lo x_hi, w_hi x_hi, w_hi x_lo) per algorithmic product
             self.profile.executed_flops += per_voxel * B * ox * oy * oz * (3 if split else 1)
-        aff = self._norm_act(layer, out, partial, nblk, apply=activate)
+        aff = self._norm_act(layer, out, partial, nblk, apply=activate, mix_out=mix_out and activate)
         return out if activate else (out, aff)
 
     def _down(self, layer: _ConvLayer, src, out_shape, tag: str, want_raw: bool):
@@ -294,7 +319,7 @@ class HipUNet:
         return (out, aff_out if want_raw else None)
 
     def _stem(self, layer: _ConvLayer, image: Tensor, origins, tile, mean: float, std: float,
-              tag: str = "L0a", raw: bool = False):
+              tag: str = "L0a", raw: bool = False, mix_out: bool = False):
         """First block (Cin = 1): normalise + conv statistics, GroupNorm finalize, then the conv again
         with the affine + SiLU fused into its epilogue: the raw tensor is never written."""
         B = len(origins)
@@ -317,6 +342,8 @@ class HipUNet:
                                            _ffi.ptr(partial), _ffi.ptr(ws), ws_bytes, st))
         aff = self._norm_act(layer, out, partial, nblk, apply=False)
         fn = _ffi.lib.sk_conv3d_stem_apply_split if self.split else _ffi.lib.sk_conv3d_stem_apply
+        if mix_out:
+            fn = _ffi.lib.sk_conv3d_stem_apply_mix8
         _ffi.check(fn(B, xt, yt, zt, _ffi.ptr(layer.weight), _ffi.ptr(layer.bias),
                       _ffi.ptr(aff), _ffi.ptr(out), layer.cout, _ffi.ptr(ws), st))
         return out
@@ -365,22 +392,32 @@ class HipUNet:
             if keep_features:
                 feats[name] = (t[0] if isinstance(t, tuple) else t).clone()
 
-        def block(layer, srcs, shape, tag, want_raw, store_box=None):
+        def block(layer, srcs, shape, tag, want_raw, store_box=None, mix_in=False, mix_out=False):
             """srcs: [((tensor, affine | None), upsample)]; returns (tensor, affine | None)."""
             flat = [(t, up, aff) for (t, aff), up in srcs]
-            out = self._conv(layer, flat, shape, tag, activate=not want_raw, store_box=store_box)
+            out = self._conv(layer, flat, shape, tag, activate=not want_raw, store_box=store_box, mix_in=mix_in, mix_out=mix_out)
             return out if want_raw else (out, None)
 
+        # precision "mix8": an activated 32-channel L0 tensor whose only reader is a 32 -> 32 3x3x3 conv is stored as
+        # [hi | x8 | lo8] lines and that conv runs sk_conv3d_mix8 (keep_features wants plain pairs: the split path then)
+        mix8 = self.mix8 and not keep_features
+
+        def mixes(nxt):
+            return mix8 and nxt.ksize == 3 and nxt.cin == 32 and nxt.cout == 32
+
         stem_raw = self.stem_single_pass and len(self.enc0) > 1 and lds_act(self.enc0[1])
+        a_mix = len(self.enc0) > 1 and mixes(self.enc0[1])
         a = self._stem(self.enc0[0], image, origins, L0, float(mean), float(std),
-                       "skip0" if len(self.enc0) == 1 else "L0a", raw=stem_raw)
+                       "skip0" if len(self.enc0) == 1 else "L0a", raw=stem_raw, mix_out=a_mix)
         a = a if stem_raw else (a, None)
         keep("enc0.0", a)
         tags = ["L0b", "L0a"]
         for i, layer in enumerate(self.enc0[1:]):
             last = i == len(self.enc0) - 2
             raw = (fuse_down and (self.down0.cin, self.down0.cout) == (32, 64)) if last else lds_act(self.enc0[i + 2])
-            a = block(layer, [(a, 0)], L0, "skip0" if last else tags[i % 2], raw)
+            nxt_mix = not last and not raw and mixes(self.enc0[i + 2])
+            a = block(layer, [(a, 0)], L0, "skip0" if last else tags[i % 2], raw, mix_in=a_mix, mix_out=nxt_mix)
+            a_mix = nxt_mix
             keep(layer.name, a)
         s0 = a
         a = self._down(self.down0, s0, L1, "L1a", False)   # activates s0 in place when it came in raw
@@ -413,13 +450,16 @@ class HipUNet:
         r0 = block(self.red0, [(a, 0)], L1, "L1r", False)
         keep("red0", r0)
         tags = ["L0a", "L0b"]
+        a_mix = False
         for i, layer in enumerate(self.dec0):
             last = i == len(self.dec0) - 1
             raw = (self.defer_activation and last) or (not last and lds_act(self.dec0[i + 1]))  # last: consumed by the heads
             src = [(s0, 0), (r0, 1)] if i == 0 else [(a, 0)]
             # the last conv's raw output is read by the heads alone, and with an out_box only inside it
             sbox = out_box if (last and raw and out_box is not None and not keep_features and self.box_store) else None
-            a = block(layer, src, L0, tags[i % 2], raw, store_box=sbox)
+            nxt_mix = not last and not raw and mixes(self.dec0[i + 1])
+            a = block(layer, src, L0, tags[i % 2], raw, store_box=sbox, mix_in=a_mix, mix_out=nxt_mix)
+            a_mix = nxt_mix
             keep(layer.name, a)
         a, aff = a
         out5 = self._buf("out5", (B, 5, xt, yt, zt))
@@ -582,6 +622,52 @@ def pack_conv_weight(weight: Tensor, device, split: bool = False) -> Tensor:
     buf = np.empty(nbytes, dtype=np.uint8)
     fn(fpt, cout, cin, k, buf.ctypes.data_as(C.c_void_p))
     return torch.from_numpy(buf).to(device)
+
+
+def pack_conv_weight_mix8(weight: Tensor, device) -> Tuple[Tensor, int]:
+    """(32, 32, 3, 3, 3) fp32 -> (weight image of ``sk_conv3d_mix8`` on the device, its fp8 scale exponent)."""
+    w = weight.detach().float().cpu().contiguous().numpy()
+    fpt = w.ctypes.data_as(C.POINTER(C.c_float))
+    nbytes = _ffi.lib.sk_conv3d_pack_weight_mix8_host(fpt, w.shape[0], w.shape[1], None, None)
+    if nbytes < 0:
+        _ffi.check(int(nbytes))
+    buf = np.empty(nbytes, dtype=np.uint8)
+    exp = C.c_int32(0)
+    _ffi.lib.sk_conv3d_pack_weight_mix8_host(fpt, w.shape[0], w.shape[1], buf.ctypes.data_as(C.c_void_p), C.byref(exp))
+    return torch.from_numpy(buf).to(device), int(exp.value)
+
+
+def mix8_line(hi: Tensor, x8: Tensor, lo8: Tensor) -> Tensor:
+    """The mix8 voxel line from its three parts: hi (..., 32) fp16, x8 and lo8 (..., 32) float8_e4m3fn (the CODES are
+    stored: x8 stands for 16 x, lo8 for 2^15 (x - hi)) -> (..., 64) fp16-typed tensor [hi | x8 | lo8]."""
+    b = torch.cat([hi.contiguous().view(torch.uint8), x8.contiguous().view(torch.uint8), lo8.contiguous().view(torch.uint8)], dim=-1)
+    return b.contiguous().view(torch.float16)
+
+
+def mix8_of(x: Tensor) -> Tensor:
+    """fp32 (..., 32) -> its mix8 line (host restatement of sk_groupnorm_silu_mix8's store)."""
+    hi = x.half()
+    x8 = (x * 16.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    lo8 = ((x - hi.float()) * 32768.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return mix8_line(hi, x8, lo8)
+
+
+def conv3d_mix8(src: Tensor, packed_weight: Tensor, scale_exp: int, bias: Tensor, out_shape: Sequence[int], zeros: Tensor,
+                store_box=None, out: Optional[Tensor] = None):
+    """Raw 3x3x3 32 -> 32 conv of precision "mix8": src (B, x, y, z, 64) mix8 lines -> ((B, x, y, z, 64) split pair, gn_partial)."""
+    _ffi.require_gpu(src, "src")
+    B, dev = src.shape[0], src.device
+    ox, oy, oz = (int(v) for v in out_shape)
+    if out is None:
+        out = torch.empty((B, ox, oy, oz, 64), dtype=torch.float16, device=dev)
+    nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, 32, 3)
+    partial = torch.zeros((B, nblk, 8, 2), dtype=torch.float32, device=dev)
+    arr = (_ffi.ConvSrc * 1)()
+    arr[0].data, arr[0].c, arr[0].upsample, arr[0].affine = src.data_ptr(), 32, 0, None
+    box = (C.c_int32 * 6)(*[int(v) for v in store_box]) if store_box is not None else None
+    _ffi.check(_ffi.lib.sk_conv3d_mix8(arr, 1, _ffi.ptr(packed_weight), int(scale_exp), _ffi.ptr(bias), _ffi.ptr(out), B, ox, oy, oz,
+                                       32, _ffi.ptr(partial), _ffi.ptr(zeros), box, _ffi.stream_ptr(dev)))
+    return out, partial
 
 
 def split_pair(x: Tensor) -> Tensor:

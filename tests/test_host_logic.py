@@ -198,7 +198,7 @@ def test_cfg_to_model_refuses_networks_it_does_not_implement():
 
 def test_precision_names_are_validated():
     from skoots_amd.unet import HipUNet, PRECISIONS
-    assert PRECISIONS == ("fp16", "split", "fp32")
+    assert PRECISIONS == ("fp16", "split", "mix8", "fp32")
     with pytest.raises(ValueError, match="precision"):
         HipUNet({}, "cuda:0", precision="bf16")
 
