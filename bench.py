@@ -22,7 +22,8 @@ north_star tolerance) or "fp32" (exact-fp32 MFMA).  Every line states its own me
 ``--config train``: BASELINE configs[4], one training step on a synthetic 256^3 crop (see train_measure).
 
 The default N = 1 line (what the driver runs) carries three measurements from ONE process: ``value`` = the fp16 eval
-path (BASELINE's dtype), ``also.split`` = the same volume at the precision that meets north_star's 1e-3 tolerance
+path (BASELINE's dtype), ``also.split`` (and ``also.mix8``, its variant with fp8 correction products in the two 32 -> 32 convs)
+= the same volume at the precision that meets north_star's 1e-3 tolerance
 (value, ms_per_step, roofline, parity_vs_fp32_mode measured live) and ``also.train_bf16`` = configs[4] (ms_per_step,
 Mvoxels/s trained, roofline); ``--no-also`` prints the first alone.  ``box`` = a bare-MFMA-loop probe of this device:
 boxes differ by ~6 % under matrix load, figures from two boxes compare only beside it.
@@ -676,6 +677,12 @@ def eval_main(args, rank, world, local):
         also["split"]["stage_ms"] = sp["config"]["stage_ms"]
         also["split"]["step_ms_min_max"] = sp["config"]["step_ms_min_max"]
         also["split"]["allocator_in_timed_steps"] = sp["config"]["allocator_in_timed_steps"]
+        # "split" with the 32 -> 32 convs' correction products on the block-scaled fp8 matrix instruction (sk_conv3d_mix8)
+        mx = measure("mix8", args.also_steps, 1, args.streams)
+        also["mix8"] = {k: mx[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "parity_vs_fp32_mode") if k in mx}
+        also["mix8"]["layers"] = {k: v for k, v in mx["roofline"]["layers"].items() if k in ("enc0.1", "dec0.1")}
+        also["mix8"]["split_layers"] = {k: v for k, v in sp["roofline"]["layers"].items() if k in ("enc0.1", "dec0.1")}
+        also["mix8"]["step_ms_min_max"] = mx["config"]["step_ms_min_max"]
     if rank == 0:
         line["box"] = probe
         if not args.no_cpu_baseline and world == 1:

@@ -1004,14 +1004,9 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                     // 32 contiguous bytes of the staged position (two 16-byte slots; the plane swizzle exchanges the 32-byte halves)
                     const int halfsel = (g & 1) * 2;
                     const int sa = a.w8_scale, sb = 0x70707070;   // E8M0: weights 2^-b (host), activations 2^-15
-#pragma unroll 1
-                    for (int rp = 0; rp < 5; ++rp) {
-                        const int rr = min(2 * rp + (g >> 1), 8);   // (the tenth row does not exist: its weights are zero)
-                        const int dz = rr % 3 - 1;
-                        const int tapoff = (rr / 3 - 1) * pitch + dz;
+                    // the six weight fragments of a tap-row pair (both cout halves x three x taps: 48 registers)
+                    auto wload8 = [&](int rp, v8i (&af)[2][3]) {
                         const unsigned wrp = (unsigned)a.w8_off + (unsigned)(rp * 6) * 2048u + wlane * 2;
-                        // the six weight fragments of the row pair (both cout halves x three x taps: 48 registers), then plane by plane
-                        v8i af[2][3];
 #pragma unroll
                         for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -1021,6 +1016,11 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                                 const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wo + 16, 0, 0);
                                 af[i2][d] = v8i{(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
                             }
+                    };
+                    auto mma8 = [&](int rp, const v8i (&af)[2][3]) {
+                        const int rr = min(2 * rp + (g >> 1), 8);   // (the tenth row does not exist: its weights are zero)
+                        const int dz = rr % 3 - 1;
+                        const int tapoff = (rr / 3 - 1) * pitch + dz;
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const int qj = q_row[0] + tapoff + j * a.jstep;
@@ -1043,6 +1043,14 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
                                     }
                             }
                         }
+                    };
+                    // (one body per pair, not unrolled: hipcc hoists the next pair's loads when it is, at 42 spilled registers for
+                    // XS = 4, and the launch takes the same time -- profiles/r04_ab_mix8_variants.txt; nor does XS = 3 pay: +4.5 %)
+#pragma unroll 1
+                    for (int rp = 0; rp < 5; ++rp) {
+                        v8i af[2][3];
+                        wload8(rp, af);
+                        mma8(rp, af);
                     }
                 }
             } else if constexpr (RES == 0 && NT == 1) {

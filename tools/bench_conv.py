@@ -25,12 +25,13 @@ def main():
     ap.add_argument("--no-box", action="store_true", help="evaluate the heads on the whole tile (the pipeline evaluates the scatter's box: "
                     "interior +- the dilation reach, 28 %% of a 300x300x20 tile)")
     ap.add_argument("--one-pass-stem", action="store_true", help="A/B: sk_conv3d_stem_raw + in-LDS activation in enc0.1 (HipUNet.stem_single_pass)")
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "split", "mix8"])
     ap.add_argument("--no-fold", action="store_true", help="decoder convs on the direct kernel (sk_conv3d) instead of sk_conv3d_upfold")
     args = ap.parse_args()
     from skoots_amd import unet
     dev = torch.device("cuda", 0)
     tile = tuple(int(v) for v in args.tile.split(","))
-    model = unet.smoke_model(dev)
+    model = unet.HipUNet(unet.random_state_dict(), dev, precision=args.precision)
     model.fold_upsample = not args.no_fold
     model.stem_single_pass = args.one_pass_stem
     g = torch.Generator(device=dev).manual_seed(0)

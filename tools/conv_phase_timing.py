@@ -59,6 +59,26 @@ def main():
         names = NAMES_PX if (cout == 32 and len(srcdef) == 1 and ext[2] == 20) else NAMES[:7]
         out[name] = {"cycles_per_wave": round(tot), **{n: round(v / tot, 4) for n, v in zip(names, m.tolist())}}
         print(name, json.dumps(out[name]), flush=True)
+    # the 32 -> 32 layer of the tolerance-meeting precisions on conv3_m16_kernel: split (three fp16 phases) and mix8 (fp16 + fp8 phase)
+    ext = (300, 300, 20)
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn((B,) + ext + (32,), generator=g, device=dev)
+    w = torch.randn((32, 32, 3, 3, 3)) / (32 * 27) ** 0.5
+    bias = torch.zeros(32, device=dev)
+    xs, xm = unet.split_pair(x), unet.mix8_of(x.cpu()).to(dev)
+    wps, (wpm, wexp) = unet.pack_conv_weight(w, dev, split=True), unet.pack_conv_weight_mix8(w, dev)
+    for name, fn in (("32->32 split (enc0.1 / dec0.1)", lambda: unet.conv3d([(xs, 0)], wps, bias, 32, 3, ext, zeros, split=True)),
+                     ("32->32 mix8 (enc0.1 / dec0.1)", lambda: unet.conv3d_mix8(xm, wpm, wexp, bias, ext, zeros))):
+        for it in range(2):
+            dbg.zero_()
+            fn()
+            torch.cuda.synchronize()
+        d = dbg.double()
+        used = d.sum(dim=(1, 2)) > 0
+        m = d[used].mean(dim=(0, 1))
+        tot = m.sum().item()
+        out[name] = {"cycles_per_wave": round(tot), **{n: round(v / tot, 4) for n, v in zip(NAMES[:7], m.tolist())}}
+        print(name, json.dumps(out[name]), flush=True)
     _ffi.check(_ffi.lib.sk_debug_set_timing_buffer(None, 0))   # detach before `dbg` can be freed
     print(json.dumps(out))
 
