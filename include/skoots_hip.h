@@ -338,24 +338,25 @@ int sk_conv3d_split(const sk_conv_src* srcs, int n_src, const void* weight, cons
  * expanded 3*cin contraction; ksize 1 / 2: hi fragments then lo fragments).  Bytes needed / written. */
 int64_t sk_conv3d_pack_weight_split_host(const float* w_host, int cout, int cin, int ksize,
                                          void* dst_host);
-/* Precision "mix8" (round 4), 3x3x3 32 -> 32 only: the split conv's two correction products (w_lo x, w x_lo) as ONE
- * block-scaled fp8 matrix product (v_mfma_scale_f32_16x16x128_f8f6f4, K = 128 = two tap rows x {w_lo . x8, w . lo8}) next
- * to the fp16 product w_hi x_hi -- ~1.45 instead of 3 MFMA passes per tap.  src: ONE activated source of 64-half lines
- * [hi fp16 (32) | x8 = e4m3(16 x) (32 bytes) | lo8 = e4m3(2^15 (x - hi)) (32 bytes)] (written by
- * sk_conv3d_stem_apply_mix8 / sk_groupnorm_silu_mix8); weight + weight_scale_exp from sk_conv3d_pack_weight_mix8_host;
- * out / gn_partial / zero_page / store_box as sk_conv3d_box_split (out is a RAW split pair [hi | lo]).  Error of the
- * corrections: 2^-4 relative on terms that are 2^-11 of the result (tools/fp8_correction_study.py). */
+/* Precision "mix8" (round 4), 3x3x3, C -> C with C = 32 | 64 | 128: the split conv's two correction products (w_lo x, w x_lo) as
+ * ONE block-scaled fp8 matrix product next to the fp16 product w_hi x_hi -- C = 32: v_mfma_scale_f32_16x16x128_f8f6f4, K = 128 =
+ * two tap rows x {w_lo . x8, w . lo8} (conv3_m16_kernel); C = 64 | 128: v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 = one tap x
+ * {w_lo . x8, w . lo8} per 32-channel chunk (conv3_kernel) -- 2 to 2.1 instead of 3 MFMA passes per tap.
+ * src: ONE activated source of 2 C-half lines [hi fp16 (C) | per 32-channel chunk: x8 = e4m3(16 x) (32 bytes) | lo8 =
+ * e4m3(2^15 (x - hi)) (32 bytes)] (written by sk_conv3d_stem_apply_mix8 / sk_groupnorm_silu_mix8); weight + weight_scale_exp from
+ * sk_conv3d_pack_weight_mix8_host; out / gn_partial / zero_page / store_box as sk_conv3d_box_split (out is a RAW split pair
+ * [hi | lo]).  Error of the corrections: 2^-4 relative on terms that are 2^-11 of the result (tools/fp8_correction_study.py). */
 int sk_conv3d_mix8(const sk_conv_src* srcs, int n_src, const void* weight, int weight_scale_exp, const float* bias,
                    void* out, int B, int ox, int oy, int oz, int cout, float* gn_partial, void* zero_page,
                    const int* store_box, void* stream);
-/* HOST: torch-layout fp32 weight (32, 32, 3, 3, 3) -> [fp16 fragments of w_hi | fp8 fragments of (w_lo 2^(b+11), w 2^b)];
+/* HOST: torch-layout fp32 weight (C, C, 3, 3, 3) -> [fp16 fragments of w_hi | fp8 fragments of (w_lo 2^(b+11), w 2^b)];
  * *scale_exp = b, the largest power of two with 2^b max|w| <= 240.  Bytes needed / written. */
 int64_t sk_conv3d_pack_weight_mix8_host(const float* w_host, int cout, int cin, void* dst_host, int* scale_exp);
 /* sk_conv3d_stem_apply storing the mix8 line [hi | x8 | lo8]: out (B, Xt, Yt, Zt, 64 halves). */
 int sk_conv3d_stem_apply_mix8(int B, int Xt, int Yt, int Zt, const float* weight, const float* bias,
                               const float* affine, void* out, int cout, const void* workspace,
                               void* stream);
-/* GroupNorm affine + SiLU in place, RAW split pair [hi | lo] in -> mix8 line [hi | x8 | lo8] out (C = 32). */
+/* GroupNorm affine + SiLU in place, RAW split pair [hi | lo] in -> mix8 line out (C = 32 | 64 | 128). */
 int sk_groupnorm_silu_mix8(void* x, const float* affine, int B, int64_t voxels, int C, void* stream);
 /* sk_conv3d_stem_apply storing the activation as a split pair: out (B, Xt, Yt, Zt, 64). */
 int sk_conv3d_stem_apply_split(int B, int Xt, int Yt, int Zt, const float* weight, const float* bias,

@@ -136,7 +136,10 @@ __device__ __forceinline__ void dma16(const char* g, char* lds_wave_base) {
 // (Keeping chunk 0's rows resident in a two-chunk layer, selected at run time per phase, spills: 1.8x slower;
 // requesting a whole row of streamed fragments two bodies ahead instead of one measured 4 % slower.)
 // Measured A/B on one device: -4..5 % time on enc0.1 / dec0.1.
-template <int COUT, int XS, int RES = 0, bool SPLIT = false>
+// MIX8 (precision "mix8", SPLIT tensors): the phases of a step alternate between a logical chunk's fp16 product (its hi
+// halves against w_hi) and ONE block-scaled fp8 product over K = 64 = [x8 (32) | lo8 (32)] . [w_lo | w] per tap
+// (v_mfma_scale_f32_32x32x64_f8f6f4: lanes 0-31 hold K 0-31, lanes 32-63 K 32-63 of their row / column) -- see conv3_m16_kernel.
+template <int COUT, int XS, int RES = 0, bool SPLIT = false, bool MIX8 = false>
 __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     constexpr int NT = COUT / 32;
     constexpr int P = NT;            // column tiles per wave
@@ -314,8 +317,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
     // weight fragment index: (((ch*9 + dydz)*2 + ks)*3 + d)*NT + nt
     // weight fragments through a buffer resource: wave-uniform byte offset in an SGPR + the constant lane * 16 in one VGPR
     // (no 64-bit address arithmetic in the tap loop)
-    auto wbase = [&](int ch) { return (unsigned)((ch * (9 * 2 * 3 * NT) + wn) * 1024); };
-    const __amdgpu_buffer_rsrc_t wrsrc = sk::make_rsrc(a.wpk, (unsigned)(a.nchunks * (9 * 2 * 3 * NT) * 1024));
+    auto wbase = [&](int ch) { return (unsigned)(((MIX8 ? ch >> 1 : ch) * (9 * 2 * 3 * NT) + wn) * 1024); };   // MIX8: phases 2 k, 2 k + 1 = chunk k
+    const __amdgpu_buffer_rsrc_t wrsrc = sk::make_rsrc(a.wpk, MIX8 ? (unsigned)a.wpk_bytes : (unsigned)(a.nchunks * (9 * 2 * 3 * NT) * 1024));
     const unsigned wlane = lane * 16;
     auto wload = [&](unsigned off) {
         return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, __builtin_amdgcn_readfirstlane(off), 0));
@@ -341,7 +344,13 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
 
     int step = 0, k = 0, ch = ch0, rot = 0;   // k: position of the phase in its step's chunk order
     SK_T_DECL
-    for (int ph = 0; ph < nphases; ++ph) {
+    // MIX8: the phases of a step strictly alternate (fp16, fp8): the loop runs over pairs with the kind a compile-time value --
+    // a run-time branch between two bodies that both own all 128 accumulator registers costs copies and spills at the joins
+    constexpr int kSub = MIX8 ? 2 : 1;
+    for (int ph0 = 0; ph0 < nphases; ph0 += kSub)
+#pragma unroll
+    for (int sub = 0; sub < kSub; ++sub) {
+        const int ph = ph0 + sub;
         const int x0 = xa + step * XS;
         if (k == 0) {
             f32x16 binit;
@@ -396,7 +405,52 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(Conv3Args a) {
             // (24 MFMAs) ahead -- -3.7 % time on COUT 64 and 128 (tools/kernel_ab.sh, round 2); the 16x16x32 kernel
             // below loses 4 % with the same barrier and keeps the free schedule.
             constexpr int kTapUnroll = (NT <= 2) ? 9 : 1;
-            if constexpr (NT == 4) {
+            const bool f8phase = MIX8 && sub == 1;   // (= a.chinfo[ch] & 4: the host lists a chunk's phases in this order, no `alt`)
+            if (f8phase) {
+                if constexpr (MIX8) {
+                    typedef int v8i __attribute__((ext_vector_type(8)));
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const int sa = a.w8_scale, sb = 0x70707070;   // E8M0: weights 2^-b (host), activations 2^-15
+                    // fp8 fragment ((chunk, dydz, d), cout tile): 2 KiB, lane l = 32 bytes: row l & 31, K block l >> 5
+                    const unsigned w8 = (unsigned)a.w8_off + (unsigned)(((ch >> 1) * 27) * NT + wn) * 2048u + wlane * 2;
+#pragma unroll 1
+                    for (int dydz = 0; dydz < 9; ++dydz) {
+                        const int dz = dydz % 3 - 1;
+                        const int tapoff = (dydz / 3 - 1) * pitch + dz;
+                        v8i af[3];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            const unsigned wo = w8 + (unsigned)((dydz * 3 + d) * NT) * 2048u;
+                            const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wo, 0, 0);
+                            const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wo + 16, 0, 0);
+                            af[d] = v8i{(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+                        }
+#pragma unroll
+                        for (int p = 0; p < P; ++p) {
+                            const int q = q_row[p] + tapoff;
+                            // this lane's K block: h = 0 the x8 bytes (chunks 0, 1 of the staged 64), h = 1 the lo8 bytes (chunks 2, 3)
+                            int addr0 = (q * 4 + ((2 * h) ^ ((q >> 2) & 3))) * 16;
+                            int addr1 = (q * 4 + ((2 * h + 1) ^ ((q >> 2) & 3))) * 16;
+                            if ((dz < 0 && zlo[p]) || (dz > 0 && zhi[p])) {
+                                addr0 = sk::zero_of(zero_addr, addr0);
+                                addr1 = sk::zero_of(zero_addr, addr1);
+                            }
+#pragma unroll
+                            for (int i = 0; i < R; ++i) {
+                                const u32x4 lo4 = *reinterpret_cast<const u32x4*>(lds + pslot[i] + addr0);
+                                const u32x4 hi4 = *reinterpret_cast<const u32x4*>(lds + pslot[i] + addr1);
+                                const v8i bf = v8i{(int)lo4[0], (int)lo4[1], (int)lo4[2], (int)lo4[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+#pragma unroll
+                                for (int d = 0; d < 3; ++d) {
+                                    const int o = i - d;
+                                    if (o >= 0 && o < XS)
+                                        acc[p][o] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[d], bf, acc[p][o], 0, 0, 0, sa, 0, sb);
+                                }
+                            }
+                        }
+                    }
+                }
+            } else if constexpr (NT == 4) {
             // COUT 128 (measured: -6 % on the 128 -> 128 layers, nothing on COUT 64, tools/layer_ab.py) -- B fragments one body ahead: a body = (dydz, ks, p) = R fragments (one per staged plane) feeding 3 XS MFMAs.
             // The compiler's own schedule requests a fragment one or two MFMAs before its first use (`ds_read ;
             // s_waitcnt lgkmcnt(1) ; v_mfma` all along the tap loop): a wave that has the SIMD to itself then waits out
@@ -2561,8 +2615,12 @@ int make_plan(Plan& p, int Xt, int Yt, int Zt, int cout, int B) {
     return 0;
 }
 
-// mix8 weight image (sk_conv3d_pack_weight_mix8_host): the 54 fp16 fragments of w_hi, then 30 fp8 fragments of 2 KiB
+// mix8 weight image (sk_conv3d_pack_weight_mix8_host): the fp16 fragments of w_hi (54 KiB per 32 x 32 channels), then fp8
+// fragments of 2 KiB -- 32 -> 32 (conv3_m16_kernel, K = 128 = two tap rows): 5 row pairs x 2 cout halves x 3 x taps;
+// wider (conv3_kernel, K = 64 = one tap): per 32-channel chunk 27 taps x cout / 32 tiles
 constexpr int kMix8Fp16Bytes = 54 * 1024, kMix8Fp8Bytes = 5 * 2 * 3 * 2048;
+inline int mix8_fp16_bytes(int cout, int cin) { return (cout / 32) * (cin / 32) * kMix8Fp16Bytes; }
+inline int mix8_fp8_bytes(int cout, int cin) { return cout == 32 ? kMix8Fp8Bytes : (cin / 32) * 27 * (cout / 32) * 2048; }
 
 template <int XS, int RES = 0, bool SPLIT = false, int WL = 0, bool MIX8 = false>
 int launch_conv3_m16(const Conv3Args& a, const Plan& p, hipStream_t stream) {
@@ -2602,9 +2660,9 @@ int launch_conv3_px(const Conv3Args& a, const Plan& p, hipStream_t stream) {
     return SK_OK;
 }
 
-template <int COUT, int XS, int RES = 0, bool SPLIT = false>
+template <int COUT, int XS, int RES = 0, bool SPLIT = false, bool MIX8 = false>
 int launch_conv3(const Conv3Args& a, const Plan& p, hipStream_t stream) {
-    auto kern = conv3_kernel<COUT, XS, RES, SPLIT>;
+    auto kern = conv3_kernel<COUT, XS, RES, SPLIT, MIX8>;
     if (p.lds > 48 * 1024)
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)p.lds));
@@ -2829,13 +2887,15 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
             a.has_box = 1;
         }
         if (mix8) {
-            SK_CHECK_ARG(split && cout == 32 && cin == 32 && n_src == 1 && !srcs[0].upsample,
-                         "sk_conv3d_mix8: one plain 32-channel source, 32 output channels");
+            SK_CHECK_ARG(split && cin == cout && n_src == 1 && !srcs[0].upsample,
+                         "sk_conv3d_mix8: one plain source with as many channels as the output (32 | 64 | 128)");
             SK_CHECK_ARG(w8_scale_exp >= 0 && w8_scale_exp < 64, "sk_conv3d_mix8: bad weight scale exponent %d", w8_scale_exp);
-            a.w8_off = kMix8Fp16Bytes;
-            a.wpk_bytes = kMix8Fp16Bytes + kMix8Fp8Bytes;
+            a.w8_off = mix8_fp16_bytes(cout, cin);
+            a.wpk_bytes = a.w8_off + mix8_fp8_bytes(cout, cin);
             a.w8_scale = 0x01010101 * (127 - w8_scale_exp);
-            return p.xs == 3 ? launch_conv3_m16<3, 0, true, 0, true>(a, p, stream) : launch_conv3_m16<4, 0, true, 0, true>(a, p, stream);
+            if (cout == 32) return p.xs == 3 ? launch_conv3_m16<3, 0, true, 0, true>(a, p, stream) : launch_conv3_m16<4, 0, true, 0, true>(a, p, stream);
+            if (cout == 64) return p.xs == 3 ? launch_conv3<64, 3, 0, true, true>(a, p, stream) : launch_conv3<64, 4, 0, true, true>(a, p, stream);
+            return launch_conv3<128, 2, 0, true, true>(a, p, stream);
         }
         if (split) {
             if (cout == 32) return p.xs == 3 ? launch_conv3_m16<3, 0, true>(a, p, stream) : launch_conv3_m16<4, 0, true>(a, p, stream);
@@ -2957,15 +3017,19 @@ static uint8_t f32_to_e4m3(float v) {
 }
 
 int64_t sk_conv3d_pack_weight_mix8_host(const float* w, int cout, int cin, void* dst, int* scale_exp) {
-    // precision "mix8", 3x3x3, 32 -> 32: [w_hi as sk_conv3d_pack_weight_host packs it (54 KiB)] [fp8 fragments (60 KiB)].
-    // fp8 fragment (tap-row pair rp = 0..4, cout half i, x tap dx): lane l holds, for cout 16 i + (l & 15), the 32 bytes of K
-    // block g = l >> 4:  g 0: e4m3(2^(b+11) w_lo) of row 2 rp | g 1: e4m3(2^b w) of row 2 rp | g 2, 3: the same of row 2 rp + 1
-    // (zeros for the tenth row); byte j = input channel j.  b = *scale_exp: the largest power of two with 2^b max|w| <= 240.
-    if (cout != 32 || cin != 32) {
-        sk::set_error("sk_conv3d_pack_weight_mix8_host: cout = cin = 32 only (got %d, %d)", cout, cin);
+    // precision "mix8", 3x3x3, C -> C (C = 32 | 64 | 128): [w_hi as sk_conv3d_pack_weight_host packs it] [fp8 fragments of 2 KiB].
+    // b = *scale_exp: the largest power of two with 2^b max|w| <= 240; w_lo = w - fp16(w).
+    // C = 32 (conv3_m16_kernel, v_mfma_scale_f32_16x16x128): fragment (tap-row pair rp = 0..4, cout half i, x tap dx): lane l
+    // holds, for cout 16 i + (l & 15), the 32 bytes of K block g = l >> 4:  g 0: e4m3(2^(b+11) w_lo) of row 2 rp | g 1:
+    // e4m3(2^b w) of row 2 rp | g 2, 3: the same of row 2 rp + 1 (zeros for the tenth row); byte j = input channel j.
+    // C = 64 | 128 (conv3_kernel, v_mfma_scale_f32_32x32x64): fragment (((chunk k, row dydz, x tap dx), cout tile nt): lane l
+    // holds, for cout 32 nt + (l & 31), K block l >> 5: 0: e4m3(2^(b+11) w_lo), 1: e4m3(2^b w); byte j = input channel 32 k + j.
+    if (cout != cin || !(cout == 32 || cout == 64 || cout == 128)) {
+        sk::set_error("sk_conv3d_pack_weight_mix8_host: cout = cin = 32 | 64 | 128 (got %d, %d)", cout, cin);
         return SK_ERR_ARG;
     }
-    const int64_t total = kMix8Fp16Bytes + kMix8Fp8Bytes;
+    const int64_t f16b = mix8_fp16_bytes(cout, cin);
+    const int64_t total = f16b + mix8_fp8_bytes(cout, cin);
     if (!dst) return total;
     const int64_t n = (int64_t)cout * cin * 27;
     std::vector<float> hi(n);
@@ -2978,23 +3042,39 @@ int64_t sk_conv3d_pack_weight_mix8_host(const float* w, int cout, int cin, void*
     while (b < 40 && std::ldexp(wmax, b + 1) <= 240.0f) ++b;
     if (scale_exp) *scale_exp = b;
     const int64_t got = sk_conv3d_pack_weight_host(hi.data(), cout, cin, 3, dst);
-    if (got != kMix8Fp16Bytes) return SK_ERR_ARG;
-    uint8_t* o = (uint8_t*)dst + kMix8Fp16Bytes;
-    auto W = [&](int co, int ci, int kx, int row) { return (int64_t)((co * cin + ci) * 3 + kx) * 9 + row; };   // (ky, kz) = row / 3, row % 3
-    int64_t f = 0;
-    for (int rp = 0; rp < 5; ++rp)
-        for (int i = 0; i < 2; ++i)
-            for (int dx = 0; dx < 3; ++dx, ++f)
-                for (int l = 0; l < 64; ++l)
-                    for (int j = 0; j < 32; ++j) {
-                        const int g = l >> 4, row = 2 * rp + (g >> 1), co = 16 * i + (l & 15);
-                        uint8_t v = 0;
-                        if (row < 9) {
-                            const int64_t idx = W(co, j, dx, row);
-                            v = (g & 1) ? f32_to_e4m3(std::ldexp(w[idx], b)) : f32_to_e4m3(std::ldexp(w[idx] - hi[idx], b + 11));
+    if (got != f16b) return SK_ERR_ARG;
+    uint8_t* o = reinterpret_cast<uint8_t*>(dst) + f16b;
+    // torch layout (co, ci, dx, dy, dz); row = dy * 3 + dz
+    auto W = [&](int co, int ci, int dx, int row) { return (((int64_t)co * cin + ci) * 3 + dx) * 9 + row; };
+    auto lo8 = [&](int64_t idx) { return f32_to_e4m3(std::ldexp(w[idx] - hi[idx], b + 11)); };
+    auto w8 = [&](int64_t idx) { return f32_to_e4m3(std::ldexp(w[idx], b)); };
+    if (cout == 32) {
+        for (int rp = 0; rp < 5; ++rp)
+            for (int i = 0; i < 2; ++i)
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int f = (rp * 2 + i) * 3 + dx;
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 32; ++j) {
+                            const int g = l >> 4, row = 2 * rp + (g >> 1), co = 16 * i + (l & 15);
+                            uint8_t v = 0;
+                            if (row < 9) v = (g & 1) ? w8(W(co, j, dx, row)) : lo8(W(co, j, dx, row));
+                            o[f * 2048 + l * 32 + j] = v;
                         }
-                        o[f * 2048 + l * 32 + j] = v;
-                    }
+                }
+        return total;
+    }
+    const int NT = cout / 32;
+    for (int k = 0; k < cin / 32; ++k)
+        for (int row = 0; row < 9; ++row)
+            for (int dx = 0; dx < 3; ++dx)
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int64_t f = ((int64_t)((k * 9 + row) * 3 + dx)) * NT + nt;
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 32; ++j) {
+                            const int64_t idx = W(32 * nt + (l & 31), 32 * k + j, dx, row);
+                            o[f * 2048 + l * 32 + j] = (l >> 5) ? w8(idx) : lo8(idx);
+                        }
+                }
     return total;
 }
 

@@ -458,26 +458,28 @@ __global__ void __launch_bounds__(256) gn_silu_split_kernel(t16* __restrict__ x,
     }
 }
 
-// precision "mix8": raw split line [hi (32) | lo16 (32)] in, activated [hi fp16 (32) | x8 (32) | lo8 (32)] out, in place (C = 32).
-// The four lanes of a voxel sit in one wave and every lane loads before any lane stores: the x8 / lo8 bytes of one lane overwrite
-// raw lo halves that ANOTHER lane of the same voxel has already read.
+// precision "mix8": raw split line [hi (C) | lo16 (C)] in, activated [hi fp16 (C) | per 32-channel chunk: x8 (32 bytes) | lo8 (32 bytes)]
+// out, in place (C = 32 | 64 | 128; the line keeps its 4 C bytes).  The four lanes of a 32-channel chunk sit in one wave and
+// every lane loads before any lane stores: the x8 / lo8 bytes of one lane overwrite raw lo halves that ANOTHER lane of the same
+// chunk has already read.
+template <int C>
 __global__ void __launch_bounds__(256) gn_silu_mix8_kernel(t16* __restrict__ x, const float* __restrict__ affine, long long nvox_per_batch) {
-    constexpr int C = 32;
+    constexpr int kOct = C / 8;   // lanes per voxel
     const int b = blockIdx.y;
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // (voxel, octet)
-    const long long stride = (long long)gridDim.x * 256;           // multiple of 4
-    const int o = (int)(i & 3);
+    const long long stride = (long long)gridDim.x * 256;           // multiple of kOct
+    const int o = (int)(i % kOct);
     float ga[8], gb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         ga[j] = affine[((long long)b * 2) * C + 8 * o + j];
         gb[j] = affine[((long long)b * 2 + 1) * C + 8 * o + j];
     }
-    char* base = reinterpret_cast<char*>(x) + (long long)b * nvox_per_batch * 128;
-    for (; i < nvox_per_batch * 4; i += stride) {
-        char* line = base + (i >> 2) * 128;
+    char* base = reinterpret_cast<char*>(x) + (long long)b * nvox_per_batch * (4 * C);
+    for (; i < nvox_per_batch * kOct; i += stride) {
+        char* line = base + (i / kOct) * (4 * C);
         const half8 vh = *reinterpret_cast<const half8*>(line + 16 * o);
-        const half8 vl = *reinterpret_cast<const half8*>(line + 64 + 16 * o);
+        const half8 vl = *reinterpret_cast<const half8*>(line + 2 * C + 16 * o);
         half8 rh;
         float xs[8], ls[8];
 #pragma unroll
@@ -497,9 +499,10 @@ __global__ void __launch_bounds__(256) gn_silu_mix8_kernel(t16* __restrict__ x, 
             pl[k] = __builtin_amdgcn_cvt_pk_fp8_f32(ls[4 * k], ls[4 * k + 1], pl[k], false);
             pl[k] = __builtin_amdgcn_cvt_pk_fp8_f32(ls[4 * k + 2], ls[4 * k + 3], pl[k], true);
         }
+        char* part8 = line + 2 * C + 64 * (o >> 2) + 8 * (o & 3);
         *reinterpret_cast<half8*>(line + 16 * o) = rh;
-        *reinterpret_cast<int2*>(line + 64 + 8 * o) = make_int2(px[0], px[1]);
-        *reinterpret_cast<int2*>(line + 96 + 8 * o) = make_int2(pl[0], pl[1]);
+        *reinterpret_cast<int2*>(part8) = make_int2(px[0], px[1]);
+        *reinterpret_cast<int2*>(part8 + 32) = make_int2(pl[0], pl[1]);
     }
 }
 
@@ -852,9 +855,10 @@ int sk_groupnorm_silu_split(void* x, const float* affine, int B, int64_t voxels,
 
 int sk_groupnorm_silu_mix8(void* x, const float* affine, int B, int64_t voxels, int C, void* stream) {
     SK_CHECK_ARG(x && affine, "sk_groupnorm_silu_mix8: NULL pointer");
-    SK_CHECK_ARG(C == 32, "sk_groupnorm_silu_mix8: C must be 32 (got %d)", C);
-    dim3 grid(sk::stream_grid(voxels * 4, 256, 4), B);
-    gn_silu_mix8_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((t16*)x, affine, (long long)voxels);
+    SK_CHECK_ARG(C == 32 || C == 64 || C == 128, "sk_groupnorm_silu_mix8: C must be 32, 64 or 128 (got %d)", C);
+    dim3 grid(sk::stream_grid(voxels * (C / 8), 256, 4), B);
+    auto kern = C == 32 ? gn_silu_mix8_kernel<32> : (C == 64 ? gn_silu_mix8_kernel<64> : gn_silu_mix8_kernel<128>);
+    kern<<<grid, 256, 0, (hipStream_t)stream>>>((t16*)x, affine, (long long)voxels);
     SK_CHECK_LAUNCH();
     return SK_OK;
 }

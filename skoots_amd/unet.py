@@ -263,7 +263,7 @@ class HipUNet:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
         if mix_in:   # precision "mix8": the source holds [hi | x8 | lo8] lines
-            assert len(srcs) == 1 and layer.ksize == 3 and layer.cin == layer.cout == 32 and arr[0].affine is None and not fold
+            assert len(srcs) == 1 and layer.ksize == 3 and layer.cin == layer.cout and arr[0].affine is None and not fold
             wimg, wexp = layer.packed_mix8()
             box = None
             if store_box is not None and not activate:
@@ -296,14 +296,14 @@ class HipUNet:
         aff = self._norm_act(layer, out, partial, nblk, apply=activate, mix_out=mix_out and activate)
         return out if activate else (out, aff)
 
-    def _down(self, layer: _ConvLayer, src, out_shape, tag: str, want_raw: bool):
+    def _down(self, layer: _ConvLayer, src, out_shape, tag: str, want_raw: bool, mix_out: bool = False):
         """Stride-2 down conv.  ``src`` = (tensor, affine | None).  With an affine the tensor is the RAW output of the
         previous block: the kernel activates it while staging it (GroupNorm affine + SiLU in LDS) and writes the
         activated values back -- the tensor is activated afterwards, as the decoder's skip conv needs it -- which saves
         the separate in-place GroupNorm pass over the skip tensor.  Returns (output, affine | None)."""
         t, aff = src
         if aff is None:
-            out = self._conv(layer, [(t, 0, None)], out_shape, tag, activate=not want_raw)
+            out = self._conv(layer, [(t, 0, None)], out_shape, tag, activate=not want_raw, mix_out=mix_out)
             return out if want_raw else (out, None)
         B = t.shape[0]
         ox, oy, oz = out_shape
@@ -315,7 +315,7 @@ class HipUNet:
         _ffi.check(fn(_ffi.ptr(t), _ffi.ptr(aff), _ffi.ptr(layer.packed(split)), _ffi.ptr(layer.bias),
                       _ffi.ptr(out), B, ox, oy, oz, layer.cin, layer.cout, _ffi.ptr(partial),
                       _ffi.ptr(self.zeros), _ffi.stream_ptr(self.device)))
-        aff_out = self._norm_act(layer, out, partial, nblk, apply=not want_raw)
+        aff_out = self._norm_act(layer, out, partial, nblk, apply=not want_raw, mix_out=mix_out and not want_raw)
         return (out, aff_out if want_raw else None)
 
     def _stem(self, layer: _ConvLayer, image: Tensor, origins, tile, mean: float, std: float,
@@ -403,7 +403,7 @@ class HipUNet:
         mix8 = self.mix8 and not keep_features
 
         def mixes(nxt):
-            return mix8 and nxt.ksize == 3 and nxt.cin == 32 and nxt.cout == 32
+            return mix8 and nxt.ksize == 3 and nxt.cin == nxt.cout and nxt.cout in (32, 64, 128)
 
         stem_raw = self.stem_single_pass and len(self.enc0) > 1 and lds_act(self.enc0[1])
         a_mix = len(self.enc0) > 1 and mixes(self.enc0[1])
@@ -420,32 +420,43 @@ class HipUNet:
             a_mix = nxt_mix
             keep(layer.name, a)
         s0 = a
-        a = self._down(self.down0, s0, L1, "L1a", False)   # activates s0 in place when it came in raw
+        a_mix = len(self.enc1) > 0 and mixes(self.enc1[0])
+        a = self._down(self.down0, s0, L1, "L1a", False, mix_out=a_mix)   # activates s0 in place when it came in raw
         s0 = (s0[0], None)
         keep("down0", a)
         tags = ["L1b", "L1a"]
         for i, layer in enumerate(self.enc1):
             last = i == len(self.enc1) - 1
             raw = last and fuse_down and (self.down1.cin, self.down1.cout) == (64, 128)
-            a = block(layer, [(a, 0)], L1, "skip1" if last else tags[i % 2], raw)
+            nxt_mix = not last and mixes(self.enc1[i + 1])
+            a = block(layer, [(a, 0)], L1, "skip1" if last else tags[i % 2], raw, mix_in=a_mix, mix_out=nxt_mix)
+            a_mix = nxt_mix
             keep(layer.name, a)
         s1 = a
-        a = self._down(self.down1, s1, L2, "L2a", False)
+        a_mix = len(self.mid) > 0 and mixes(self.mid[0])
+        a = self._down(self.down1, s1, L2, "L2a", False, mix_out=a_mix)
         s1 = (s1[0], None)
         keep("down1", a)
         tags = ["L2b", "L2a"]
         for i, layer in enumerate(self.mid):
             # the last one is read only by red1 (1x1x1, gather GEMM): activated on load there (both fast modes)
-            raw = self.defer_activation and not keep_features and i == len(self.mid) - 1
-            a = block(layer, [(a, 0)], L2, tags[i % 2], raw)
+            last = i == len(self.mid) - 1
+            raw = self.defer_activation and not keep_features and last
+            nxt_mix = not last and mixes(self.mid[i + 1])
+            a = block(layer, [(a, 0)], L2, tags[i % 2], raw, mix_in=a_mix, mix_out=nxt_mix)
+            a_mix = nxt_mix
             keep(layer.name, a)
         r1 = block(self.red1, [(a, 0)], L2, "L2r", False)
         keep("red1", r1)
         tags = ["L1a", "L1b"]
+        a_mix = False
         for i, layer in enumerate(self.dec1):
-            raw = self.defer_activation and not keep_features and i == len(self.dec1) - 1  # last: consumed by red0 (on load)
+            last = i == len(self.dec1) - 1
+            raw = self.defer_activation and not keep_features and last  # last: consumed by red0 (on load)
             src = [(s1, 0), (r1, 1)] if i == 0 else [(a, 0)]
-            a = block(layer, src, L1, tags[i % 2], raw)
+            nxt_mix = not last and mixes(self.dec1[i + 1])
+            a = block(layer, src, L1, tags[i % 2], raw, mix_in=a_mix, mix_out=nxt_mix)
+            a_mix = nxt_mix
             keep(layer.name, a)
         r0 = block(self.red0, [(a, 0)], L1, "L1r", False)
         keep("red0", r0)
@@ -625,7 +636,7 @@ def pack_conv_weight(weight: Tensor, device, split: bool = False) -> Tensor:
 
 
 def pack_conv_weight_mix8(weight: Tensor, device) -> Tuple[Tensor, int]:
-    """(32, 32, 3, 3, 3) fp32 -> (weight image of ``sk_conv3d_mix8`` on the device, its fp8 scale exponent)."""
+    """(C, C, 3, 3, 3) fp32, C = 32 | 64 | 128 -> (weight image of ``sk_conv3d_mix8`` on the device, its fp8 scale exponent)."""
     w = weight.detach().float().cpu().contiguous().numpy()
     fpt = w.ctypes.data_as(C.POINTER(C.c_float))
     nbytes = _ffi.lib.sk_conv3d_pack_weight_mix8_host(fpt, w.shape[0], w.shape[1], None, None)
@@ -638,14 +649,20 @@ def pack_conv_weight_mix8(weight: Tensor, device) -> Tuple[Tensor, int]:
 
 
 def mix8_line(hi: Tensor, x8: Tensor, lo8: Tensor) -> Tensor:
-    """The mix8 voxel line from its three parts: hi (..., 32) fp16, x8 and lo8 (..., 32) float8_e4m3fn (the CODES are
-    stored: x8 stands for 16 x, lo8 for 2^15 (x - hi)) -> (..., 64) fp16-typed tensor [hi | x8 | lo8]."""
-    b = torch.cat([hi.contiguous().view(torch.uint8), x8.contiguous().view(torch.uint8), lo8.contiguous().view(torch.uint8)], dim=-1)
+    """The mix8 voxel line from its three parts: hi (..., C) fp16, x8 and lo8 (..., C) float8_e4m3fn (the CODES are
+    stored: x8 stands for 16 x, lo8 for 2^15 (x - hi)) -> (..., 2C) fp16-typed tensor
+    [hi (C) | per 32-channel chunk: x8 (32 bytes) | lo8 (32 bytes)]."""
+    C = hi.shape[-1]
+    lead = hi.shape[:-1]
+    xb = x8.contiguous().view(torch.uint8).reshape(lead + (C // 32, 1, 32))
+    lb = lo8.contiguous().view(torch.uint8).reshape(lead + (C // 32, 1, 32))
+    tail = torch.cat([xb, lb], dim=-2).reshape(lead + (2 * C,))
+    b = torch.cat([hi.contiguous().view(torch.uint8), tail], dim=-1)
     return b.contiguous().view(torch.float16)
 
 
 def mix8_of(x: Tensor) -> Tensor:
-    """fp32 (..., 32) -> its mix8 line (host restatement of sk_groupnorm_silu_mix8's store)."""
+    """fp32 (..., C) -> its mix8 line (host restatement of sk_groupnorm_silu_mix8's store)."""
     hi = x.half()
     x8 = (x * 16.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
     lo8 = ((x - hi.float()) * 32768.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
@@ -654,19 +671,21 @@ def mix8_of(x: Tensor) -> Tensor:
 
 def conv3d_mix8(src: Tensor, packed_weight: Tensor, scale_exp: int, bias: Tensor, out_shape: Sequence[int], zeros: Tensor,
                 store_box=None, out: Optional[Tensor] = None):
-    """Raw 3x3x3 32 -> 32 conv of precision "mix8": src (B, x, y, z, 64) mix8 lines -> ((B, x, y, z, 64) split pair, gn_partial)."""
+    """Raw 3x3x3 C -> C conv of precision "mix8" (C = 32 | 64 | 128): src (B, x, y, z, 2C) mix8 lines -> ((B, x, y, z, 2C) split
+    pair, gn_partial)."""
     _ffi.require_gpu(src, "src")
     B, dev = src.shape[0], src.device
+    ch = src.shape[-1] // 2
     ox, oy, oz = (int(v) for v in out_shape)
     if out is None:
-        out = torch.empty((B, ox, oy, oz, 64), dtype=torch.float16, device=dev)
-    nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, 32, 3)
-    partial = torch.zeros((B, nblk, 8, 2), dtype=torch.float32, device=dev)
+        out = torch.empty((B, ox, oy, oz, 2 * ch), dtype=torch.float16, device=dev)
+    nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, ch, 3)
+    partial = torch.zeros((B, nblk, ch // 4, 2), dtype=torch.float32, device=dev)
     arr = (_ffi.ConvSrc * 1)()
-    arr[0].data, arr[0].c, arr[0].upsample, arr[0].affine = src.data_ptr(), 32, 0, None
+    arr[0].data, arr[0].c, arr[0].upsample, arr[0].affine = src.data_ptr(), ch, 0, None
     box = (C.c_int32 * 6)(*[int(v) for v in store_box]) if store_box is not None else None
     _ffi.check(_ffi.lib.sk_conv3d_mix8(arr, 1, _ffi.ptr(packed_weight), int(scale_exp), _ffi.ptr(bias), _ffi.ptr(out), B, ox, oy, oz,
-                                       32, _ffi.ptr(partial), _ffi.ptr(zeros), box, _ffi.stream_ptr(dev)))
+                                       ch, _ffi.ptr(partial), _ffi.ptr(zeros), box, _ffi.stream_ptr(dev)))
     return out, partial
 
 
