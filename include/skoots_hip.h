@@ -243,6 +243,13 @@ int sk_conv3d_down_act_split(void* in_raw, const float* affine, const void* weig
                              int B, int ox, int oy, int oz, int cin, int cout, float* gn_partial,
                              void* zero_page, void* stream);
 
+/* sk_conv3d_down_act_split for precision "mix8": the same conv, but the activated input is written back as a mix8 line
+ * [hi fp16 (cin) | per 32-channel chunk: x8 (32 bytes) | lo8 (32 bytes)] (sk_groupnorm_silu_mix8's format) -- for a skip
+ * tensor whose other reader is sk_conv3d_upfold_mix8. */
+int sk_conv3d_down_act_mix8(void* in_raw, const float* affine, const void* weight, const float* bias, void* out,
+                            int B, int ox, int oy, int oz, int cin, int cout, float* gn_partial,
+                            void* zero_page, void* stream);
+
 /* Decoder conv over cat([skip, nearest-upsample x2 (up)]) with the upsample FOLDED INTO THE WEIGHTS of the upsampled
  * channels (csrc/conv3d_up.hip): 3x3x3, stride 1, zero pad 1, the same function as sk_conv3d(ksize 3) with sources
  * {skip, up (upsample = 1)} -- the first conv of each decoder level (oracle/unet_spec.py; skoots/lib/utils.py:17-107)
@@ -266,6 +273,15 @@ int sk_conv3d_upfold_split(const void* skip, int c_skip, const void* up, int c_u
                            const float* bias, void* out, int B, int ox, int oy, int oz, int cout,
                            float* gn_partial, void* stream);
 int64_t sk_conv3d_pack_weight_upfold_split_host(const float* w_host, int cout, int c_skip, int c_up, void* dst_host);
+/* The same for precision "mix8": skip and up hold mix8 lines (sk_groupnorm_silu_mix8 / sk_conv3d_down_act_mix8), out is a RAW
+ * split pair; per logical chunk one fp16 phase (hi halves x w_hi) and one block-scaled fp8 phase (K = 128 = two taps x
+ * {w_lo . x8, w . lo8}; the folded weights are summed in double, then split into fp16 hi and the fp8 images).
+ * weight + weight_scale_exp: sk_conv3d_pack_weight_upfold_mix8_host. */
+int sk_conv3d_upfold_mix8(const void* skip, int c_skip, const void* up, int c_up, const void* weight, int weight_scale_exp,
+                          const float* bias, void* out, int B, int ox, int oy, int oz, int cout,
+                          float* gn_partial, void* stream);
+int64_t sk_conv3d_pack_weight_upfold_mix8_host(const float* w_host, int cout, int c_skip, int c_up, void* dst_host,
+                                               int* scale_exp);
 
 /* Rows of gn_partial per batch item that sk_conv3d writes for this output shape. */
 int sk_conv3d_num_blocks(int B, int ox, int oy, int oz, int cout, int ksize);

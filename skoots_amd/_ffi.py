@@ -95,6 +95,9 @@ _SIGS = {
     "sk_conv3d_split": (i32, [C.POINTER(ConvSrc), i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "sk_conv3d_pack_weight_split_host": (i64, [fp, i32, i32, i32, vp]),
     "sk_conv3d_stem_apply_split": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
+    "sk_conv3d_down_act_mix8": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "sk_conv3d_upfold_mix8": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "sk_conv3d_pack_weight_upfold_mix8_host": (i64, [fp, i32, i32, i32, vp, ip]),
     "sk_conv3d_stem_apply_mix8": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
     "sk_groupnorm_silu_mix8": (i32, [vp, vp, i32, i64, i32, vp]),
     "sk_conv3d_mix8": (i32, [C.POINTER(ConvSrc), i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, ip, vp]),
@@ -149,7 +152,7 @@ _SIGS = {
 # exported with the suffix _bf16, same signatures
 BF16_TWINS = (
     "sk_conv3d", "sk_conv3d_box", "sk_conv3d_box_split", "sk_conv3d_down_act", "sk_conv3d_down_act_split", "sk_conv3d_num_blocks", "sk_conv3d_pack_weight_host", "sk_conv3d_pack_weight_split_host",
-    "sk_conv3d_mix8", "sk_conv3d_pack_weight_mix8_host", "sk_conv3d_stem_apply_mix8", "sk_groupnorm_silu_mix8",
+    "sk_conv3d_mix8", "sk_conv3d_down_act_mix8", "sk_conv3d_pack_weight_mix8_host", "sk_conv3d_stem_apply_mix8", "sk_groupnorm_silu_mix8",
     "sk_conv3d_split", "sk_conv3d_stem", "sk_conv3d_stem_raw", "sk_conv3d_stem_apply", "sk_conv3d_stem_apply_split",
     "sk_conv3d_stem_num_blocks", "sk_conv3d_stem_workspace_bytes", "sk_groupnorm_finalize",
     "sk_groupnorm_finalize_stats", "sk_groupnorm_silu", "sk_groupnorm_silu_split", "sk_heads", "sk_heads_split",

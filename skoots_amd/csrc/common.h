@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <cmath>
 #include <stdio.h>
 
 #include "../../include/skoots_hip.h"
@@ -69,6 +70,30 @@ long long* timing_buffer();
     } while (0)
 
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// HOST: fp32 -> OCP e4m3fn code (round to nearest even, saturating at 448; the device's v_cvt_pk_fp8_f32 on gfx950)
+static inline uint8_t f32_to_e4m3(float v) {
+    const uint8_t sgn = std::signbit(v) ? 0x80 : 0x00;
+    float a = std::fabs(v);
+    if (!(a == a)) return 0x7F;
+    if (a >= 448.0f) return sgn | 0x7E;
+    if (a < 0.0009765625f) return sgn;                              // below half of the smallest subnormal 2^-9
+    int e;
+    (void)std::frexp(a, &e);                                        // a = m * 2^e, m in [0.5, 1)
+    e -= 1;                                                         // a in [2^e, 2^(e+1))
+    if (e < -6) {                                                   // subnormal: units of 2^-9
+        const int q = (int)std::nearbyint(a * 512.0f);
+        return sgn | (uint8_t)(q >= 8 ? 0x08 : q);
+    }
+    int m = (int)std::nearbyint((a / std::ldexp(1.0f, e) - 1.0f) * 8.0f);
+    if (m == 8) {
+        m = 0;
+        ++e;
+    }
+    if (e > 8) return sgn | 0x7E;
+    const int code = ((e + 7) << 3) | m;
+    return sgn | (uint8_t)(code > 0x7E ? 0x7E : code);
+}
 
 // Memory-bound grids: cap and grid-stride (256 CUs x 8 blocks).
 static inline unsigned stream_grid(int64_t n, int block, int per_thread = 1) {

@@ -990,7 +990,12 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
 
     int step = 0, k = 0, ch = ch0, rot = 0;   // k: position of the phase in its step's chunk order
     SK_T_DECL
-    for (int ph = 0; ph < nphases; ++ph) {
+    // MIX8: (fp16, fp8) phase pairs with the kind a compile-time value (see conv3_kernel)
+    constexpr int kSub = MIX8 ? 2 : 1;
+    for (int ph0 = 0; ph0 < nphases; ph0 += kSub)
+#pragma unroll
+    for (int sub = 0; sub < kSub; ++sub) {
+        const int ph = ph0 + sub;
         const int x0 = xa + step * XS;
         if (k == 0) {
 #pragma unroll
@@ -1049,7 +1054,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
             // takes 2.1x its MFMA cycles -- 2x is the share of the pipe when the co-resident wave multiplies too, the
             // rest is a wave that has the SIMD to itself exposing one LDS latency per body.  dec0.0 (two chunks):
             // 1.316 -> 1.228 ms per 8 tiles (-6.7 %); the single-chunk layers keep RES = 2 (resident rows beat it, +3 %).
-            const bool f8phase = MIX8 && (a.chinfo[ch] & 4u);
+            const bool f8phase = MIX8 && sub == 1;   // (= a.chinfo[ch] & 4)
             if (f8phase) {
                 if constexpr (MIX8) {
                     typedef int v8i __attribute__((ext_vector_type(8)));
@@ -2447,10 +2452,38 @@ __global__ void __launch_bounds__(256, 2) down2_act_split_kernel(DownArgs a) {
                     }
                     *lph = rh;
                     *lpl = rl;
-                    if (a.writeback && vin[j] >= 0) {
+                    if (a.writeback == 1 && vin[j] >= 0) {
                         char* g = inb + (vin[j] + toff) * VB + src_off;
                         *reinterpret_cast<half8*>(g) = rh;
                         *reinterpret_cast<half8*>(g + VB / 2) = rl;
+                    }
+                    if (a.writeback == 2 && vin[j] >= 0) {
+                        // precision "mix8": the activated line as [hi (CIN) | per 32-channel chunk: x8 = e4m3(16 x) | lo8 = e4m3(2^15 (x - hi))]
+                        // (sk_groupnorm_silu_mix8's store).  The 8-bit pieces land on raw lo halves that OTHER lanes staged: the
+                        // CPR lanes that stage a row's two voxel lines sit in one wave, whose LDS-DMA of this stage has landed
+                        // (the vmcnt wait above) before any of its lanes gets here.
+                        float xs[8], ls[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float y = fmaf(ga[e], (float)vh[e] + (float)vl[e], gb[e]);
+                            const float sv = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+                            xs[e] = fminf(fmaxf(sv * 16.0f, -448.0f), 448.0f);
+                            ls[e] = fminf(fmaxf((sv - (float)rh[e]) * 32768.0f, -448.0f), 448.0f);
+                        }
+                        int px[2] = {0, 0}, pl[2] = {0, 0};
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2) {
+                            px[k2] = __builtin_amdgcn_cvt_pk_fp8_f32(xs[4 * k2], xs[4 * k2 + 1], px[k2], false);
+                            px[k2] = __builtin_amdgcn_cvt_pk_fp8_f32(xs[4 * k2 + 2], xs[4 * k2 + 3], px[k2], true);
+                            pl[k2] = __builtin_amdgcn_cvt_pk_fp8_f32(ls[4 * k2], ls[4 * k2 + 1], pl[k2], false);
+                            pl[k2] = __builtin_amdgcn_cvt_pk_fp8_f32(ls[4 * k2 + 2], ls[4 * k2 + 3], pl[k2], true);
+                        }
+                        const int oct = csrc % CPVH;
+                        char* line = inb + (vin[j] + toff + csrc / CPVH) * VB;
+                        *reinterpret_cast<half8*>(line + 16 * oct) = rh;
+                        char* part8 = line + VB / 2 + 64 * (oct >> 2) + 8 * (oct & 3);
+                        *reinterpret_cast<int2*>(part8) = make_int2(px[0], px[1]);
+                        *reinterpret_cast<int2*>(part8 + 32) = make_int2(pl[0], pl[1]);
                     }
                 }
             }
@@ -2993,29 +3026,6 @@ int sk_conv3d_down_act(void* in_raw, const float* affine, const void* weight, co
 }
 
 // OCP e4m3fn of a float, round to nearest even, saturating at +-448
-static uint8_t f32_to_e4m3(float v) {
-    const uint8_t sgn = std::signbit(v) ? 0x80 : 0x00;
-    float a = std::fabs(v);
-    if (!(a == a)) return 0x7F;
-    if (a >= 448.0f) return sgn | 0x7E;
-    if (a < 0.0009765625f) return sgn;                              // below half of the smallest subnormal 2^-9
-    int e;
-    (void)std::frexp(a, &e);                                        // a = m * 2^e, m in [0.5, 1)
-    e -= 1;                                                         // a in [2^e, 2^(e+1))
-    if (e < -6) {                                                   // subnormal: units of 2^-9
-        const int q = (int)std::nearbyint(a * 512.0f);
-        return sgn | (uint8_t)(q >= 8 ? 0x08 : q);
-    }
-    int m = (int)std::nearbyint((a / std::ldexp(1.0f, e) - 1.0f) * 8.0f);
-    if (m == 8) {
-        m = 0;
-        ++e;
-    }
-    if (e > 8) return sgn | 0x7E;
-    const int code = ((e + 7) << 3) | m;
-    return sgn | (uint8_t)(code > 0x7E ? 0x7E : code);
-}
-
 int64_t sk_conv3d_pack_weight_mix8_host(const float* w, int cout, int cin, void* dst, int* scale_exp) {
     // precision "mix8", 3x3x3, C -> C (C = 32 | 64 | 128): [w_hi as sk_conv3d_pack_weight_host packs it] [fp8 fragments of 2 KiB].
     // b = *scale_exp: the largest power of two with 2^b max|w| <= 240; w_lo = w - fp16(w).
@@ -3046,8 +3056,8 @@ int64_t sk_conv3d_pack_weight_mix8_host(const float* w, int cout, int cin, void*
     uint8_t* o = reinterpret_cast<uint8_t*>(dst) + f16b;
     // torch layout (co, ci, dx, dy, dz); row = dy * 3 + dz
     auto W = [&](int co, int ci, int dx, int row) { return (((int64_t)co * cin + ci) * 3 + dx) * 9 + row; };
-    auto lo8 = [&](int64_t idx) { return f32_to_e4m3(std::ldexp(w[idx] - hi[idx], b + 11)); };
-    auto w8 = [&](int64_t idx) { return f32_to_e4m3(std::ldexp(w[idx], b)); };
+    auto lo8 = [&](int64_t idx) { return sk::f32_to_e4m3(std::ldexp(w[idx] - hi[idx], b + 11)); };
+    auto w8 = [&](int64_t idx) { return sk::f32_to_e4m3(std::ldexp(w[idx], b)); };
     if (cout == 32) {
         for (int rp = 0; rp < 5; ++rp)
             for (int i = 0; i < 2; ++i)
@@ -3088,6 +3098,12 @@ int sk_conv3d_down_act_split(void* in_raw, const float* affine, const void* weig
                              int ox, int oy, int oz, int cin, int cout, float* gn_partial, void* zeros, void* stream) {
     SK_CHECK_ARG(affine, "sk_conv3d_down_act_split: affine is NULL (use sk_conv3d_split for an activated input)");
     return launch_down2(in_raw, affine, 1, weight, bias, out, B, ox, oy, oz, cin, cout, gn_partial, zeros, (hipStream_t)stream, true);
+}
+
+int sk_conv3d_down_act_mix8(void* in_raw, const float* affine, const void* weight, const float* bias, void* out, int B,
+                            int ox, int oy, int oz, int cin, int cout, float* gn_partial, void* zeros, void* stream) {
+    SK_CHECK_ARG(affine, "sk_conv3d_down_act_mix8: affine is NULL");
+    return launch_down2(in_raw, affine, 2, weight, bias, out, B, ox, oy, oz, cin, cout, gn_partial, zeros, (hipStream_t)stream, true);
 }
 
 int sk_conv3d_split(const sk_conv_src* srcs, int n_src, const void* weight, const float* bias, void* out,

@@ -30,6 +30,10 @@
 // rows ahead; everything else (x-marching ring, LDS-DMA through buffer descriptors, permlane epilogue, GroupNorm partials on
 // v_dot2c) as in conv3_m16_kernel, whose comments explain those parts.
 #include <stdlib.h>
+#include <string.h>
+
+#include <cmath>
+#include <vector>
 
 #include "common.h"
 
@@ -62,7 +66,11 @@ struct UpfArgs {
     int out_vs, cout_off;        // bytes per output voxel line; first output channel of this launch (a launch computes 32)
     int pstride, poff;           // floats per gn_partial row (cout/4 * 2); offset of this launch's 16 in it
     long long* dbg;              // -DSK_TIMING builds: per-wave phase cycle sums (tools/upfold_phase_timing.py)
+    int w8_off, w8_scale, wpk_bytes;   // MIX8: byte offset of the fp8 fragments, E8M0 scale of the weights (x 4), bytes of the image
 };
+
+constexpr int kSkipFrags8 = 30;  // MIX8, 2 KiB fp8 fragments of a skip chunk: [tap-row pair 5][cout half 2][dx 3]
+constexpr int kUpFrags8 = 64;    // of an upsampled chunk: [class 4][ty 2][cout half 2][px 2][tx 2] (K = two tz taps)
 
 // Phase timing (-DSK_TIMING build only): per wave, cycles between the marks of a phase
 #ifdef SK_TIMING
@@ -76,473 +84,16 @@ struct UpfArgs {
 #define SK_T_DUMP(a, w, lane)
 #endif
 
-// WLDS (one skip chunk only): tap rows 0 and 1 of the skip chunk's weights sit in LDS behind the ring, one copy per
-// workgroup, instead of being streamed by each of the four waves (conv3_m16_kernel's WL): 12 of the 54 + 32 weight loads
-// per wave and step become LDS reads and the hand-off to the skip phase requests no weights at all.
-// SPLIT (precision "split", sk_conv3d_upfold_split): every tensor holds fp16 hi + lo pairs, [hi (C) | lo (C)] per voxel
-// line, and every weight is a hi + lo pair; a logical chunk runs as three phases -- (x_hi, w_lo), (x_hi again: no LDS-DMA,
-// w_hi), (x_lo, w_hi) -- as in conv3_m16_kernel's split mode, and the fp32 accumulator is stored as hi = fp16(v),
-// lo = fp16(v - hi).  The folded weights are split AFTER the fold (the sum is formed in double on the host).
-template <int XS, bool WLDS, bool SPLIT>
-__global__ void __launch_bounds__(256, 2) conv3_upf_kernel(UpfArgs a) {
-    constexpr int R = XS + 2;          // fine planes of a step
-    constexpr int RL = XS / 2 + 2;     // low-resolution planes of a step
-    static_assert(XS == 4, "x parity of an output plane must be a compile-time constant");
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int py = w >> 1, pz = w & 1;   // parity class of this wave's output voxels
-    const int c16 = lane & 15, g = lane >> 4;
-
-    // XCD-aware workgroup order (conv3d.hip)
-    int blk = blockIdx.x;
-    {
-        const int nwg = gridDim.x, xcd = blk & 7, qn = nwg >> 3, rn = nwg & 7;
-        blk = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blk >> 3);
-    }
-    const int patch = blk % a.npatch;
-    blk /= a.npatch;
-    const int xc = blk % a.nxc;
-    const int b = blk / a.nxc;
-    const int block_in_batch = xc * a.npatch + patch;
-    const int nblk = a.npatch * a.nxc;
-
-    const int Zl = a.Zl, Zt = a.Zt;
-    const int yl0 = patch * a.K;             // first low-resolution row of this workgroup
-    const int nseg = a.K * Zl;               // columns in use (<= 32)
-
-    // per-lane flags of column (j): bit j: the z-1 tap wraps (class pz = 0, zl = 0) | bit 8 + j: the z+1 tap wraps
-    // (pz = 1, zl = Zl-1) | bit 16 + j: a real voxel
-    unsigned vflags = 0;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = 16 * j + c16;
-        const int r = m / Zl, c = m - r * Zl;
-        vflags |= (unsigned)(pz == 0 && c == 0) << j;
-        vflags |= (unsigned)(pz == 1 && c == Zl - 1) << (8 + j);
-        vflags |= (unsigned)(m < nseg && yl0 + r < a.Yl) << (16 + j);
-    }
-    auto zlo = [&](int j) { return (vflags >> j) & 1u; };
-    auto zhi = [&](int j) { return (vflags >> (8 + j)) & 1u; };
-    auto vvalid = [&](int j) { return (vflags >> (16 + j)) & 1u; };
-
-    // the voxel this lane STORES (after the permlane transpose it owns 8 channels of column c16 + 16 (g & 1))
-    int ovox;      // in-plane fine voxel index, -1: none
-    {
-        const int m = c16 + 16 * (g & 1);
-        const int r = m / Zl, c = m - r * Zl;
-        ovox = (m < nseg && yl0 + r < a.Yl) ? (2 * (yl0 + r) + py) * Zt + 2 * c + pz : -1;
-    }
-
-    // ---- LDS-DMA bookkeeping ------------------------------------------------------------
-    // fine plane: position q = sub * SUBP + 1 + ylr * Zl + zl, sub = 2 (y & 1) + (z & 1), rows ylr = (y >> 1) - (yl0 - (y & 1))
-    const int ndma = a.nposp / 16, ndmal = a.nposl / 16;
-    const int d_cs = ((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 16;   // source chunk of this lane's slot (conv3_m16_kernel)
-    int d_vox[kMaxDma], d_low[kMaxDmaL];
-#pragma unroll
-    for (int k = 0; k < kMaxDma; ++k) {
-        const int t = w + 4 * k;
-        const int q = (64 * t + lane) >> 2;
-        const int sub = q / a.SUBP, rem = q - sub * a.SUBP - 1;
-        const int ylr = rem >= 0 ? rem / Zl : 0, zl = rem - ylr * Zl;
-        const int yp = sub >> 1, zp = sub & 1;
-        const int y = 2 * (yl0 - yp + ylr) + yp, z = 2 * zl + zp;
-        const bool ok = t < ndma && sub < 4 && rem >= 0 && ylr <= a.K && y >= 0 && y < a.Yt;
-        d_vox[k] = ok ? y * Zt + z : -1;
-    }
-    // low-resolution plane: position q = 1 + (yl - (yl0 - 1)) * Zl + zl
-#pragma unroll
-    for (int k = 0; k < kMaxDmaL; ++k) {
-        const int t = w + 4 * k;
-        const int q = (64 * t + lane) >> 2;
-        const int rem = q - 1;
-        const int ylr = rem >= 0 ? rem / Zl : 0, zl = rem - ylr * Zl;
-        const int yl = yl0 - 1 + ylr;
-        const bool ok = t < ndmal && rem >= 0 && ylr < a.K + 2 && yl >= 0 && yl < a.Yl;
-        d_low[k] = ok ? yl * Zl + zl : -1;
-    }
-
-    f32x4 acc[XS][2][2];   // [output plane][cout half i][voxel half j]
-    float gsum[2], gsq[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) gsum[q] = gsq[q] = 0.0f;
-
-    const int xa = xc * a.XC;
-    const int xb = min(xa + a.XC, a.Xt);
-    const int Xl = a.Xt >> 1;
-    const int plane_bytes = (a.nposp + sk::kZeroPos) * kPosBytes;
-    const int zero_addr = a.nposp * kPosBytes;   // never written by either image's DMA (nposl <= nposp)
-    const long long out_plane = (long long)a.Yt * Zt * a.out_vs;
-    char* outb = a.out + (long long)b * a.Xt * out_plane;
-    const float* biasp = a.bias + a.cout_off + 4 * g;
-
-    const int nsteps = (xb - xa + XS - 1) / XS;
-    // Virtual chunks: plain mode one per 32-channel chunk; split mode three -- part 0: hi halves x lo weights, part 1: the
-    // SAME staged planes x hi weights (no LDS-DMA), part 2: lo halves x hi weights
-    constexpr int kParts = SPLIT ? 3 : 1;
-    const int nvs = a.ns * kParts, nvu = a.nu * kParts;
-    auto v_chunk = [](int v) { return SPLIT ? v / 3 : v; };
-    auto v_part = [](int v) { return SPLIT ? v % 3 : 0; };
-    auto v_dma = [&](int v) { return v_part(v) != 1; };
-
-    // Phase order of a step: the skip chunks, then the upsampled chunks.  Fine plane i of the step lives in ring slot
-    // (rot + i) % R; the low-resolution planes of the step take the slots of fine planes 0 .. RL-1, which the step is
-    // done with -- fine planes XS, XS + 1 stay staged through the upsampled phases and are planes 0, 1 of the next
-    // step's skip chunk when there is only one (`reuse`: XS instead of XS + 2 plane loads per step).
-    auto issue_fine = [&](int step, int chs, bool reuse, int rot_n) {
-        const int x0 = xa + step * XS;
-        const int xlo = max(x0 - 1, 0);
-        const long long wbytes = min((long long)(R + 1) * a.skip_plane, a.skip_batch - (long long)xlo * a.skip_plane);
-        const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(a.skip + (long long)b * a.skip_batch + (long long)xlo * a.skip_plane, (unsigned)wbytes);
-        const unsigned vstride = (unsigned)(a.skipC * 2 * (SPLIT ? 2 : 1));
-        const int choff = v_chunk(chs) * 64 + (v_part(chs) == 2 ? a.skipC * 2 : 0);   // split: the lo halves follow the hi halves
-        for (int i = reuse ? 2 : 0; i < R; ++i) {
-            const int x = x0 - 1 + i;
-            const bool xok = x >= 0 && x < a.Xt;
-            char* lbase = lds + ((rot_n + i) % R) * plane_bytes;
-            const unsigned xoff = (unsigned)((x - xlo) * (int)a.skip_plane + choff + d_cs);
-#pragma unroll
-            for (int k = 0; k < kMaxDma; ++k) {
-                const int t = w + 4 * k;
-                if (t < ndma) {
-                    int dv = d_vox[k];
-                    asm volatile("" : "+v"(dv));   // keep the offset arithmetic here: hoisted out of the step loop it costs registers
-                    const unsigned voff = (xok && dv >= 0) ? xoff + (unsigned)dv * vstride : sk::kOob;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lbase + t * 1024), 16, voff, 0, 0, 0);
-                }
-            }
-        }
-    };
-    auto issue_low = [&](int step, int chu, bool /*reuse: never -- the skip phases overwrite these slots*/, int rotl_n) {
-        const int xl0 = ((xa + step * XS) >> 1) - 1;
-        const int xlo = max(xl0, 0);
-        const long long wbytes = min((long long)(RL + 1) * a.up_plane, a.up_batch - (long long)xlo * a.up_plane);
-        const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(a.up + (long long)b * a.up_batch + (long long)xlo * a.up_plane, (unsigned)wbytes);
-        const unsigned vstride = (unsigned)(a.upC * 2 * (SPLIT ? 2 : 1));
-        const int choff = v_chunk(chu) * 64 + (v_part(chu) == 2 ? a.upC * 2 : 0);
-        for (int i = 0; i < RL; ++i) {
-            const int xl = xl0 + i;
-            const bool xok = xl >= 0 && xl < Xl;
-            char* lbase = lds + ((rotl_n + i) % R) * plane_bytes;
-            const unsigned xoff = (unsigned)((xl - xlo) * (int)a.up_plane + choff + d_cs);
-#pragma unroll
-            for (int k = 0; k < kMaxDmaL; ++k) {
-                const int t = w + 4 * k;
-                if (t < ndmal) {
-                    const unsigned voff = (xok && d_low[k] >= 0) ? xoff + (unsigned)d_low[k] * vstride : sk::kOob;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lbase + t * 1024), 16, voff, 0, 0, 0);
-                }
-            }
-        }
-    };
-    const __amdgpu_buffer_rsrc_t wrsrc = sk::make_rsrc(a.wpk, (unsigned)((a.ns * kSkipFrags + a.nu * kUpFrags) * (SPLIT ? 2 : 1) * 1024));
-    const unsigned wlane = lane * 16;
-    auto wload = [&](unsigned off) {
-        return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, __builtin_amdgcn_readfirstlane(off), 0));
-    };
-    // first fragment of a chunk for this wave
-    // split: per chunk the lo-weight fragment set, then the hi-weight set; part 0 multiplies by lo, parts 1 and 2 by hi
-    auto wbase_skip = [&](int v) {
-        return (unsigned)((SPLIT ? (2 * v_chunk(v) + (v_part(v) != 0)) : v) * kSkipFrags * 1024);
-    };
-    auto wbase_up = [&](int v) {
-        const int frag0 = SPLIT ? 2 * a.ns * kSkipFrags + (2 * v_chunk(v) + (v_part(v) != 0)) * kUpFrags
-                                : a.ns * kSkipFrags + v * kUpFrags;
-        return (unsigned)((frag0 + w * 32) * 1024);
-    };
-
-    // Weight fragments that cross a phase boundary (requested before the closing barrier of the phase before): ONE
-    // register set for both kinds of chunk -- a value carried around the phase loop stays allocated through every phase.
-    // skip chunk: wq[ks * 3 + dx] = the two cout halves of a tap row; upsampled chunk: wq[(i*2 + px)*2 + tx]
-    // of a (ty, tz) row.
-    half8 wq[8];
-    auto load_af = [&](unsigned wch, int tytz, half8 (&dst)[8]) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dst[e] = wload(wch + (unsigned)((tytz * 8 + e) * 1024));
-    };
-    const char* wlds = lds + R * plane_bytes + lane * 16;   // WLDS: fragments 0 .. 11 of the skip chunk
-    auto prefetch_skip = [&](int cs) {   // the first fragments of a phase
-        if constexpr (WLDS) return;      // row 0 comes from LDS at the start of the phase
-#pragma unroll
-        for (int e = 0; e < 6; ++e) wq[e] = wload(wbase_skip(cs) + e * 1024);
-    };
-    half8 wq1[8];   // upsampled chunk: second tap row (live from the hand-off before the phase to its second row only)
-    auto prefetch_up = [&](int cu) {
-        load_af(wbase_up(cu), 0, wq);
-        load_af(wbase_up(cu), 1, wq1);
-    };
-
-    if (tid < R * 4 * sk::kZeroPos)
-        *reinterpret_cast<uint4*>(lds + (tid / (4 * sk::kZeroPos)) * plane_bytes + zero_addr + (tid % (4 * sk::kZeroPos)) * 16) = make_uint4(0, 0, 0, 0);
-    if constexpr (WLDS) {
-        for (int i = tid; i < 12 * 64; i += 256)
-            *reinterpret_cast<uint4*>(lds + R * plane_bytes + i * 16) = *reinterpret_cast<const uint4*>(a.wpk + i * 16);
-    }
-    issue_fine(0, 0, false, 0);
-    prefetch_skip(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const bool ring = !SPLIT && a.ns == 1;   // the same skip chunk every step: its two trailing planes are reused
-    int rot = 0;
-    SK_T_DECL
-    for (int step = 0; step < nsteps; ++step) {
-        const int x0 = xa + step * XS;
-#pragma unroll
-        for (int o = 0; o < XS; ++o)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc[o][i][0] = acc[o][i][1] = *reinterpret_cast<const f32x4*>(biasp + 16 * i);
-        // The LDS addresses of the taps are cheap functions of the lane's column: recomputed every step.  Without this
-        // opaque copy the compiler hoists all 18 + 8 of them out of the step loop and spills.
-        int c16v = c16;
-        asm volatile("" : "+v"(c16v));
-
-        for (int cs = 0; cs < nvs; ++cs) {
-            const unsigned wch = wbase_skip(cs);
-            // ---------------- skip chunk: 27 taps on the de-interleaved fine planes -----------------
-            int pslot[R];
-#pragma unroll
-            for (int i = 0; i < R; ++i) pslot[i] = ((rot + i) % R) * plane_bytes;
-            // A body = (tap row, voxel half j): R fragments feeding 6 XS MFMAs (both cout halves); the next body's fragments
-            // and the NEXT ROW's six weight fragments are requested before this body's MFMAs.
-            half8 bb[2][R];
-            half8 wb[6];
-            auto load_body = [&](int dydz, int j, half8 (&dst)[R]) {
-                const int dy = dydz / 3 - 1, dz = dydz % 3 - 1;
-                // fine (y, z) = (2 yl + py + dy, 2 zl + pz + dz): sub-plane by the parities, position offset by the halves
-                const int Y = py + dy, Z = pz + dz;
-                const int tapoff = ((Y & 1) * 2 + (Z & 1)) * a.SUBP + 1 + (Y >= 1 ? Zl : 0) + (Z >> 1);   // Z >> 1: floor
-                const int q = c16v + tapoff;
-                int addr = (q * 4 + (g ^ (((q >> 2) & 1) << 1))) * 16 + 1024 * j;   // (q + 16) >> 2 has the parity of q >> 2
-                if (dz < 0) addr = zlo(j) ? sk::zero_of(zero_addr, addr) : addr;
-                if (dz > 0) addr = zhi(j) ? sk::zero_of(zero_addr, addr) : addr;
-#pragma unroll
-                for (int i = 0; i < R; ++i) dst[i] = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
-            };
-            auto mma_body = [&](int j, const half8* wf, const half8 (&src)[R]) {
-#pragma unroll
-                for (int i = 0; i < R; ++i)
-#pragma unroll
-                    for (int d = 0; d < 3; ++d)
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
-                            const int o = i - d;
-                            if (o >= 0 && o < XS) acc[o][ks][j] = SK_MFMA_16x16x32_T16(wf[ks * 3 + d], src[i], acc[o][ks][j], 0, 0, 0);
-                        }
-            };
-            if constexpr (WLDS) {
-#pragma unroll
-                for (int e = 0; e < 6; ++e) wq[e] = *reinterpret_cast<const half8*>(wlds + e * 1024);
-            }
-            load_body(0, 0, bb[0]);
-#pragma unroll
-            for (int dydz = 0; dydz < 9; ++dydz) {
-                half8* wcur = (dydz & 1) ? wb : wq;
-                half8* wnext = (dydz & 1) ? wq : wb;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (j == 0) {
-                        load_body(dydz, 1, bb[1]);
-                        if (dydz < 8) {
-#pragma unroll
-                            for (int e = 0; e < 6; ++e) {
-                                if (WLDS && dydz + 1 < 2)
-                                    wnext[e] = *reinterpret_cast<const half8*>(wlds + ((dydz + 1) * 6 + e) * 1024);
-                                else
-                                    wnext[e] = wload(wch + (unsigned)(((dydz + 1) * 6 + e) * 1024));
-                            }
-                        }
-                    } else if (dydz < 8) {
-                        load_body(dydz + 1, 0, bb[0]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma_body(j, wcur, bb[j]);
-                }
-            }
-            SK_T(0)   // skip MFMA loop
-            if (cs + 1 < nvs) {
-                // hand the planes to the next skip chunk: barrier (all waves done reading) -> LDS-DMA + first weights of the
-                // next phase -> landed -> barrier; split part 1 multiplies the planes that are staged: weights only
-                if (v_dma(cs + 1)) {
-                    __syncthreads();
-                    issue_fine(step, cs + 1, false, rot);
-                    prefetch_skip(cs + 1);
-                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                } else {
-                    prefetch_skip(cs + 1);
-                }
-            }
-        }
-        // ... and to the first upsampled chunk (outside the loop: the weight rows requested here must not look live
-        // through the skip chunks' MFMA loops)
-        __syncthreads();
-        SK_T(1)   // barrier
-        issue_low(step, 0, false, rot);
-        prefetch_up(0);
-        SK_T(2)   // LDS-DMA issue + weight prefetch
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        SK_T(3)   // landing wait
-        asm volatile("s_barrier" ::: "memory");
-        SK_T(4)   // barrier
-
-        for (int cu = 0; cu < nvu; ++cu) {
-            const unsigned wch = wbase_up(cu);
-            // ---------------- upsampled chunk: 2 x 2 x 2 folded taps on the low-resolution planes -----------------
-            int pslot[RL];
-#pragma unroll
-            for (int i = 0; i < RL; ++i) pslot[i] = ((rot + i) % R) * plane_bytes;
-            // a body = (tap row (ty, tz), voxel half j): RL fragments feeding 4 XS MFMAs
-            half8 bl[2][RL];
-            auto load_low = [&](int tytz, int j, half8 (&dst)[RL]) {
-                const int sy = (tytz >> 1) + py - 1, sz = (tytz & 1) + pz - 1;   // low-resolution offsets of this tap
-                const int q = c16v + 1 + (1 + sy) * Zl + sz;
-                int addr = (q * 4 + (g ^ (((q >> 2) & 1) << 1))) * 16 + 1024 * j;
-                addr = (sz < 0 && zlo(j)) ? sk::zero_of(zero_addr, addr) : addr;
-                addr = (sz > 0 && zhi(j)) ? sk::zero_of(zero_addr, addr) : addr;
-#pragma unroll
-                for (int i = 0; i < RL; ++i) dst[i] = *reinterpret_cast<const half8*>(lds + pslot[i] + addr);
-            };
-            // Weight fragments two tap rows ahead: a fragment here feeds 4 MFMAs (2 planes of its x parity x 2 voxel halves)
-            // and the four waves stream four different sets, which mostly come from L2 -- one row (32 MFMAs) of lead left
-            // the wave waiting on every row (the phase took 5.6x its MFMA cycles).  Rows 0, 1 were requested before the
-            // phase's opening barrier (wq, wq1), row 2 goes out now, row 3 takes row 0's registers.
-            half8 wq2[8];
-            load_af(wch, 2, wq2);
-            load_low(0, 0, bl[0]);
-#pragma unroll
-            for (int tytz = 0; tytz < 4; ++tytz) {
-                const half8* af = tytz == 1 ? wq1 : (tytz == 2 ? wq2 : wq);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (j == 0) {
-                        load_low(tytz, 1, bl[1]);
-                    } else if (tytz < 3) {
-                        load_low(tytz + 1, 0, bl[0]);
-                    }
-                    if (tytz == 1 && j == 0) load_af(wch, 3, wq);   // row 0 is done with wq
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int o = 0; o < XS; ++o)
-#pragma unroll
-                        for (int tx = 0; tx < 2; ++tx)
-#pragma unroll
-                            for (int i = 0; i < 2; ++i) {
-                                const int px = o & 1, il = (o >> 1) + tx + px;   // low plane of tap tx for output plane o
-                                acc[o][i][j] = SK_MFMA_16x16x32_T16(af[(i * 2 + px) * 2 + tx], bl[j][il], acc[o][i][j], 0, 0, 0);
-                            }
-                }
-            }
-            const bool last = cu + 1 == nvu;
-            const bool have_next = !last || step + 1 < nsteps;
-            const int rot_n = (last && ring) ? (rot + XS) % R : rot;
-            SK_T(5)   // upsampled MFMA loop
-            __syncthreads();
-            SK_T(6)   // barrier
-            if (have_next) {
-                if (!last) {
-                    if (v_dma(cu + 1)) issue_low(step, cu + 1, false, rot);
-                    prefetch_up(cu + 1);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                } else {
-                    issue_fine(step + 1, 0, ring, rot_n);
-                    prefetch_skip(0);
-                }
-            }
-            SK_T(7)   // LDS-DMA issue + weight prefetch
-            if (last) {
-                // ---------------- epilogue (overlaps the DMA): raw fp16 store + GroupNorm partials ------
-                char* outw = outb + (long long)x0 * out_plane;
-                const __amdgpu_buffer_rsrc_t rout = sk::make_rsrc(outw, (unsigned)(XS * out_plane));
-    #pragma unroll
-                for (int o = 0; o < XS; ++o) {
-                    const int x = x0 + o;
-    #pragma unroll
-                    for (int part = 0; part < (SPLIT ? 2 : 1); ++part) {   // SPLIT: the hi halves, then the lo halves
-    #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        unsigned d[2][2];
-    #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const f32x4 r = acc[o][i][j];
-                            half4 hv = {(t16)r[0], (t16)r[1], (t16)r[2], (t16)r[3]};
-                            if (part == 1)   // lo = fp16(v - hi): exact difference, rounded once
-                                hv = half4{(t16)(r[0] - (float)hv[0]), (t16)(r[1] - (float)hv[1]),
-                                           (t16)(r[2] - (float)hv[2]), (t16)(r[3] - (float)hv[3])};
-                            const uint2 u = __builtin_bit_cast(uint2, hv);
-                            d[j][0] = u.x;
-                            d[j][1] = u.y;
-                            const bool in = vvalid(j) && x < xb;
-                            if (SPLIT) {
-                                if (part == 0 && in) {   // split: statistics of the fp32 accumulators
-                                    gsum[i] += (r[0] + r[1]) + (r[2] + r[3]);
-                                    gsq[i] += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
-                                }
-                            } else {
-                                const t16x2 z2 = {(t16)0.0f, (t16)0.0f}, one2 = {(t16)1.0f, (t16)1.0f};
-                                const t16x2 lo2 = in ? t16x2{hv[0], hv[1]} : z2, hi2 = in ? t16x2{hv[2], hv[3]} : z2;
-                                gsum[i] = SK_DOT2_T16(lo2, one2, gsum[i]);
-                                gsum[i] = SK_DOT2_T16(hi2, one2, gsum[i]);
-                                gsq[i] = SK_DOT2_T16(lo2, lo2, gsq[i]);
-                                gsq[i] = SK_DOT2_T16(hi2, hi2, gsq[i]);
-                            }
-                        }
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(d[0][0], d[1][0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(d[0][1], d[1][1], false, false);
-                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                        const u32x4 lv = {s0[0], s1[0], s0[1], s1[1]};
-                        const bool sok = x < xb && ovox >= 0;
-                        // split: the voxel line is [hi (cout) | lo (cout)]: out_vs = 4 cout bytes, the lo halves cout * 2 bytes on
-                        const unsigned off = (unsigned)(o * (int)out_plane + ovox * a.out_vs + part * (a.out_vs / 2) + a.cout_off * 2 +
-                                                        32 * i + 16 * (g >> 1));
-                        // always issued (the counted wait below relies on it); a masked lane's offset is out of range: dropped
-                        __builtin_amdgcn_raw_buffer_store_b128(lv, rout, sok ? off : sk::kOob, 0, 0);
-                    }
-                    }
-                }
-                SK_T(8)   // epilogue
-                if (have_next) {
-                    // vmcnt retires in order: everything older than the epilogue's XS * 2 stores -- the LDS-DMA and the
-                    // weight fragments -- has landed (conv3_m16_kernel)
-                    constexpr int kStores = XS * 2 * (SPLIT ? 2 : 1);
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
-                }
-            }
-            SK_T(9)   // deferred landing wait
-            if (have_next) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            SK_T(10)  // closing barrier
-            rot = rot_n;
-        }
-    }
-
-    SK_T_DUMP(a, w, lane)
-    // ---- block-level reduction of the GroupNorm partials ------------------------------------
-    if (a.partial) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(lds);  // [4 waves][8 quads][2]
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float s = gsum[i], ss = gsq[i];
-#pragma unroll
-            for (int m = 8; m > 0; m >>= 1) {
-                s += __shfl_xor(s, m);
-                ss += __shfl_xor(ss, m);
-            }
-            if (c16 == 0) {
-                red[(w * 8 + 4 * i + g) * 2 + 0] = s;
-                red[(w * 8 + 4 * i + g) * 2 + 1] = ss;
-            }
-        }
-        __syncthreads();
-        if (tid < 16) {
-            float t = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) t += red[q * 16 + tid];
-            a.partial[((long long)b * nblk + block_in_batch) * a.pstride + a.poff + tid] = t;
-        }
-    }
-}
+#define SK_UPF_NAME conv3_upf_kernel
+#define SK_UPF_MIX8 0
+#include "conv3d_up_kernel.inc"
+#undef SK_UPF_NAME
+#undef SK_UPF_MIX8
+#define SK_UPF_NAME conv3_upf_mix8_kernel
+#define SK_UPF_MIX8 1
+#include "conv3d_up_kernel.inc"
+#undef SK_UPF_NAME
+#undef SK_UPF_MIX8
 
 struct UpfPlan {
     int K, SUBP, nposp, nposl, npatch, XC, nxc;
@@ -651,8 +202,79 @@ int64_t sk_conv3d_pack_weight_upfold_split_host(const float* w, int cout, int c_
     return pack_upfold(w, cout, c_skip, c_up, dst, true);
 }
 
+// precision "mix8": per 32 output channels [the fp16 fragments of the hi weights, as sk_conv3d_pack_weight_upfold_host lays them
+// out][fp8 fragments of 2 KiB: skip chunks [chunk][tap-row pair 5][cout half 2][dx 3] -- lane l: cout 16 i + (l & 15), K block
+// g = l >> 4: row 2 rp + (g >> 1), g & 1 = 0: e4m3(2^(b+11) w_lo) | 1: e4m3(2^b w) -- then upsampled chunks [chunk][class 4][ty 2]
+// [cout half 2][px 2][tx 2] -- K block g: tap tz = g >> 1, g & 1 as above, of the FOLDED weight (summed in double; w_lo = sum -
+// fp16(sum))].  b = *scale_exp: the largest power of two with 2^b max(|w|, |folded sums|) <= 240.
+int64_t sk_conv3d_pack_weight_upfold_mix8_host(const float* w, int cout, int c_skip, int c_up, void* dst, int* scale_exp) {
+    const int64_t f16b = pack_upfold(w, cout, c_skip, c_up, nullptr, false);
+    if (f16b < 0) return f16b;
+    const int ns = c_skip / 32, nu = c_up / 32, cin = c_skip + c_up, ncg = cout / 32;
+    const int64_t f16_cg = f16b / ncg, f8_cg = ((int64_t)ns * kSkipFrags8 + (int64_t)nu * kUpFrags8) * 2048;
+    const int64_t total = (f16_cg + f8_cg) * ncg;
+    if (!dst) return total;
+    auto W = [&](int co, int ci, int kx, int ky, int kz) { return w[((((int64_t)co * cin + ci) * 3 + kx) * 3 + ky) * 3 + kz]; };
+    auto lo = [](int p, int t) { return p == 0 ? (t == 0 ? 0 : 1) : (t == 0 ? 0 : 2); };
+    auto hi = [](int p, int t) { return p == 0 ? (t == 0 ? 0 : 2) : (t == 0 ? 1 : 2); };
+    auto folded = [&](int co, int ci, int px, int tx, int py, int ty, int pz, int tz) {
+        double sacc = 0.0;
+        for (int kx = lo(px, tx); kx <= hi(px, tx); ++kx)
+            for (int ky = lo(py, ty); ky <= hi(py, ty); ++ky)
+                for (int kz = lo(pz, tz); kz <= hi(pz, tz); ++kz) sacc += (double)W(co, ci, kx, ky, kz);
+        return sacc;
+    };
+    double wmax = 0.0;
+    for (int co = 0; co < cout; ++co) {
+        for (int ci = 0; ci < c_skip; ++ci)
+            for (int t = 0; t < 27; ++t) wmax = std::fmax(wmax, std::fabs((double)W(co, ci, t / 9, (t / 3) % 3, t % 3)));
+        for (int ci = c_skip; ci < cin; ++ci)
+            for (int c = 0; c < 64; ++c)
+                wmax = std::fmax(wmax, std::fabs(folded(co, ci, c & 1, (c >> 1) & 1, (c >> 2) & 1, (c >> 3) & 1, (c >> 4) & 1, (c >> 5) & 1)));
+    }
+    int b = 0;
+    while (b < 40 && std::ldexp(wmax, b + 1) <= 240.0) ++b;
+    if (scale_exp) *scale_exp = b;
+    auto enc = [&](double v, int kind) {   // kind 0: the lo part at 2^(b+11), 1: the value at 2^b
+        const double h = (double)(float)(t16)(float)v;
+        return sk::f32_to_e4m3((float)std::ldexp(kind ? v : v - h, kind ? b : b + 11));
+    };
+    std::vector<char> f16(f16b);
+    if (pack_upfold(w, cout, c_skip, c_up, f16.data(), false) != f16b) return SK_ERR_ARG;
+    for (int cg = 0; cg < ncg; ++cg) {
+        char* img = reinterpret_cast<char*>(dst) + cg * (f16_cg + f8_cg);
+        memcpy(img, f16.data() + cg * f16_cg, (size_t)f16_cg);
+        uint8_t* o = reinterpret_cast<uint8_t*>(img + f16_cg);
+        int64_t f = 0;
+        for (int ch = 0; ch < ns; ++ch)
+            for (int rp = 0; rp < 5; ++rp)
+                for (int i = 0; i < 2; ++i)
+                    for (int dx = 0; dx < 3; ++dx, ++f)
+                        for (int l = 0; l < 64; ++l)
+                            for (int j = 0; j < 32; ++j) {
+                                const int g = l >> 4, row = 2 * rp + (g >> 1);
+                                o[f * 2048 + l * 32 + j] =
+                                    row < 9 ? enc((double)W(32 * cg + 16 * i + (l & 15), ch * 32 + j, dx, row / 3, row % 3), g & 1) : 0;
+                            }
+        for (int ch = 0; ch < nu; ++ch)
+            for (int cls = 0; cls < 4; ++cls)
+                for (int ty = 0; ty < 2; ++ty)
+                    for (int i = 0; i < 2; ++i)
+                        for (int px = 0; px < 2; ++px)
+                            for (int tx = 0; tx < 2; ++tx, ++f)
+                                for (int l = 0; l < 64; ++l)
+                                    for (int j = 0; j < 32; ++j) {
+                                        const int g = l >> 4;
+                                        const double v = folded(32 * cg + 16 * i + (l & 15), c_skip + ch * 32 + j, px, tx, cls >> 1, ty, cls & 1, g >> 1);
+                                        o[f * 2048 + l * 32 + j] = enc(v, g & 1);
+                                    }
+    }
+    return total;
+}
+
 static int upfold_impl(const void* skip, int c_skip, const void* up, int c_up, const void* weight, const float* bias,
-                       void* out, int B, int ox, int oy, int oz, int cout, float* gn_partial, void* stream_, const bool split) {
+                       void* out, int B, int ox, int oy, int oz, int cout, float* gn_partial, void* stream_, const bool split,
+                       const bool mix8 = false, const int w8_scale_exp = 0) {
     hipStream_t stream = (hipStream_t)stream_;
     SK_CHECK_ARG(skip && up && weight && bias && out, "sk_conv3d_upfold: NULL pointer");
     SK_CHECK_ARG(cout == 32 || cout == 64, "sk_conv3d_upfold: cout must be 32 or 64 (got %d)", cout);
@@ -696,7 +318,15 @@ static int upfold_impl(const void* skip, int c_skip, const void* up, int c_up, c
     a.dbg = sk::timing_buffer();
 #endif
     const bool wlds = !split && a.ns == 1 && p.lds + 12288 <= 80 * 1024;   // two tap rows of the single skip chunk in LDS
-    auto kern = split ? conv3_upf_kernel<4, false, true> : (wlds ? conv3_upf_kernel<4, true, false> : conv3_upf_kernel<4, false, false>);
+    auto kern = mix8 ? conv3_upf_mix8_kernel<4, false, true>
+                     : (split ? conv3_upf_kernel<4, false, true> : (wlds ? conv3_upf_kernel<4, true, false> : conv3_upf_kernel<4, false, false>));
+    const size_t f16_cg = (size_t)(a.ns * kSkipFrags + a.nu * kUpFrags) * 1024, f8_cg = (size_t)(a.ns * kSkipFrags8 + a.nu * kUpFrags8) * 2048;
+    if (mix8) {
+        SK_CHECK_ARG(split && w8_scale_exp >= 0 && w8_scale_exp < 64, "sk_conv3d_upfold_mix8: bad weight scale exponent %d", w8_scale_exp);
+        a.w8_off = (int)f16_cg;
+        a.wpk_bytes = (int)(f16_cg + f8_cg);
+        a.w8_scale = 0x01010101 * (127 - w8_scale_exp);
+    }
     const size_t lds = p.lds + (wlds ? 12288 : 0);
     if (lds > 48 * 1024)
         SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -708,7 +338,7 @@ static int upfold_impl(const void* skip, int c_skip, const void* up, int c_up, c
     for (int cg = 0; cg < cout / 32; ++cg) {
         a.cout_off = 32 * cg;
         a.poff = 16 * cg;
-        a.wpk = (const char*)weight + (size_t)cg * (a.ns * kSkipFrags + a.nu * kUpFrags) * lanes * 1024;
+        a.wpk = (const char*)weight + (mix8 ? (size_t)cg * (f16_cg + f8_cg) : (size_t)cg * (a.ns * kSkipFrags + a.nu * kUpFrags) * lanes * 1024);
         kern<<<grid, 256, lds, stream>>>(a);
         SK_CHECK_LAUNCH();
     }
@@ -724,6 +354,11 @@ int sk_conv3d_upfold(const void* skip, int c_skip, const void* up, int c_up, con
 int sk_conv3d_upfold_split(const void* skip, int c_skip, const void* up, int c_up, const void* weight, const float* bias,
                            void* out, int B, int ox, int oy, int oz, int cout, float* gn_partial, void* stream) {
     return upfold_impl(skip, c_skip, up, c_up, weight, bias, out, B, ox, oy, oz, cout, gn_partial, stream, true);
+}
+
+int sk_conv3d_upfold_mix8(const void* skip, int c_skip, const void* up, int c_up, const void* weight, int weight_scale_exp,
+                          const float* bias, void* out, int B, int ox, int oy, int oz, int cout, float* gn_partial, void* stream) {
+    return upfold_impl(skip, c_skip, up, c_up, weight, bias, out, B, ox, oy, oz, cout, gn_partial, stream, true, true, weight_scale_exp);
 }
 
 }  // extern "C"

@@ -90,6 +90,15 @@ class _ConvLayer:
         return t
 
 
+    def packed_upfold_mix8(self, c_skip: int) -> Tuple[Tensor, int]:
+        """Weight image of ``sk_conv3d_upfold_mix8`` and its fp8 scale exponent; packed on first use."""
+        key = ("upfold_mix8", c_skip)
+        t = self._packed.get(key)
+        if t is None:
+            t = self._packed[key] = pack_conv_weight_upfold_mix8(self._w_cpu, c_skip, self._device)
+        return t
+
+
 class ConvProfile:
     """HIP-event timing of every 3x3x3 MFMA conv launch (the dominant kernel), recorded on
     the stream the kernels are launched on; bench.py turns it into the roofline figure."""
@@ -262,8 +271,13 @@ class HipUNet:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
-        if mix_in:   # precision "mix8": the source holds [hi | x8 | lo8] lines
-            assert len(srcs) == 1 and layer.ksize == 3 and layer.cin == layer.cout and arr[0].affine is None and not fold
+        if mix_in and fold:   # precision "mix8", decoder conv: both sources hold mix8 lines
+            wimg, wexp = layer.packed_upfold_mix8(arr[0].c)
+            _ffi.check(_ffi.lib.sk_conv3d_upfold_mix8(arr[0].data, arr[0].c, arr[1].data, arr[1].c, _ffi.ptr(wimg), wexp,
+                                                      _ffi.ptr(layer.bias), _ffi.ptr(out), B, ox, oy, oz, layer.cout,
+                                                      _ffi.ptr(partial), _ffi.stream_ptr(self.device)))
+        elif mix_in:   # precision "mix8": the source holds [hi | x8 | lo8] lines
+            assert len(srcs) == 1 and layer.ksize == 3 and layer.cin == layer.cout and arr[0].affine is None
             wimg, wexp = layer.packed_mix8()
             box = None
             if store_box is not None and not activate:
@@ -296,7 +310,7 @@ class HipUNet:
         aff = self._norm_act(layer, out, partial, nblk, apply=activate, mix_out=mix_out and activate)
         return out if activate else (out, aff)
 
-    def _down(self, layer: _ConvLayer, src, out_shape, tag: str, want_raw: bool, mix_out: bool = False):
+    def _down(self, layer: _ConvLayer, src, out_shape, tag: str, want_raw: bool, mix_out: bool = False, mix_writeback: bool = False):
         """Stride-2 down conv.  ``src`` = (tensor, affine | None).  With an affine the tensor is the RAW output of the
         previous block: the kernel activates it while staging it (GroupNorm affine + SiLU in LDS) and writes the
         activated values back -- the tensor is activated afterwards, as the decoder's skip conv needs it -- which saves
@@ -312,6 +326,8 @@ class HipUNet:
         nblk = _ffi.lib.sk_conv3d_num_blocks(B, ox, oy, oz, layer.cout, 2)
         partial = self._buf("partial", (B * nblk * (layer.cout // 4) * 2,), torch.float32)
         fn = _ffi.lib.sk_conv3d_down_act_split if split else _ffi.lib.sk_conv3d_down_act
+        if mix_writeback:   # the activated input goes back as mix8 lines (its other reader is sk_conv3d_upfold_mix8)
+            fn = _ffi.lib.sk_conv3d_down_act_mix8
         _ffi.check(fn(_ffi.ptr(t), _ffi.ptr(aff), _ffi.ptr(layer.packed(split)), _ffi.ptr(layer.bias),
                       _ffi.ptr(out), B, ox, oy, oz, layer.cin, layer.cout, _ffi.ptr(partial),
                       _ffi.ptr(self.zeros), _ffi.stream_ptr(self.device)))
@@ -405,6 +421,12 @@ class HipUNet:
         def mixes(nxt):
             return mix8 and nxt.ksize == 3 and nxt.cin == nxt.cout and nxt.cout in (32, 64, 128)
 
+        def folds_mix(layer, shape, skip):
+            """Does this decoder conv run sk_conv3d_upfold_mix8?  Then its skip tensor (activated and written back by the fused
+            stride-2 conv: ``skip`` arrived raw) and its upsampled source are produced as mix8 lines."""
+            return (mix8 and self.fold_upsample and layer.ksize == 3 and skip[1] is not None
+                    and _ffi.lib.sk_conv3d_upfold_num_blocks(shape[0], shape[1], shape[2], layer.cout) > 0)
+
         stem_raw = self.stem_single_pass and len(self.enc0) > 1 and lds_act(self.enc0[1])
         a_mix = len(self.enc0) > 1 and mixes(self.enc0[1])
         a = self._stem(self.enc0[0], image, origins, L0, float(mean), float(std),
@@ -421,7 +443,8 @@ class HipUNet:
             keep(layer.name, a)
         s0 = a
         a_mix = len(self.enc1) > 0 and mixes(self.enc1[0])
-        a = self._down(self.down0, s0, L1, "L1a", False, mix_out=a_mix)   # activates s0 in place when it came in raw
+        dec0_mix = folds_mix(self.dec0[0], L0, s0)
+        a = self._down(self.down0, s0, L1, "L1a", False, mix_out=a_mix, mix_writeback=dec0_mix)   # activates s0 in place when it came in raw
         s0 = (s0[0], None)
         keep("down0", a)
         tags = ["L1b", "L1a"]
@@ -434,7 +457,8 @@ class HipUNet:
             keep(layer.name, a)
         s1 = a
         a_mix = len(self.mid) > 0 and mixes(self.mid[0])
-        a = self._down(self.down1, s1, L2, "L2a", False, mix_out=a_mix)
+        dec1_mix = folds_mix(self.dec1[0], L1, s1)
+        a = self._down(self.down1, s1, L2, "L2a", False, mix_out=a_mix, mix_writeback=dec1_mix)
         s1 = (s1[0], None)
         keep("down1", a)
         tags = ["L2b", "L2a"]
@@ -446,7 +470,7 @@ class HipUNet:
             a = block(layer, [(a, 0)], L2, tags[i % 2], raw, mix_in=a_mix, mix_out=nxt_mix)
             a_mix = nxt_mix
             keep(layer.name, a)
-        r1 = block(self.red1, [(a, 0)], L2, "L2r", False)
+        r1 = block(self.red1, [(a, 0)], L2, "L2r", False, mix_out=dec1_mix)
         keep("red1", r1)
         tags = ["L1a", "L1b"]
         a_mix = False
@@ -455,10 +479,10 @@ class HipUNet:
             raw = self.defer_activation and not keep_features and last  # last: consumed by red0 (on load)
             src = [(s1, 0), (r1, 1)] if i == 0 else [(a, 0)]
             nxt_mix = not last and mixes(self.dec1[i + 1])
-            a = block(layer, src, L1, tags[i % 2], raw, mix_in=a_mix, mix_out=nxt_mix)
+            a = block(layer, src, L1, tags[i % 2], raw, mix_in=dec1_mix if i == 0 else a_mix, mix_out=nxt_mix)
             a_mix = nxt_mix
             keep(layer.name, a)
-        r0 = block(self.red0, [(a, 0)], L1, "L1r", False)
+        r0 = block(self.red0, [(a, 0)], L1, "L1r", False, mix_out=dec0_mix)
         keep("red0", r0)
         tags = ["L0a", "L0b"]
         a_mix = False
@@ -469,7 +493,7 @@ class HipUNet:
             # the last conv's raw output is read by the heads alone, and with an out_box only inside it
             sbox = out_box if (last and raw and out_box is not None and not keep_features and self.box_store) else None
             nxt_mix = not last and not raw and mixes(self.dec0[i + 1])
-            a = block(layer, src, L0, tags[i % 2], raw, store_box=sbox, mix_in=a_mix, mix_out=nxt_mix)
+            a = block(layer, src, L0, tags[i % 2], raw, store_box=sbox, mix_in=dec0_mix if i == 0 else a_mix, mix_out=nxt_mix)
             a_mix = nxt_mix
             keep(layer.name, a)
         a, aff = a
@@ -741,6 +765,39 @@ def pack_conv_weight_upfold(weight: Tensor, c_skip: int, device, split: bool = F
     buf = np.empty(nbytes, dtype=np.uint8)
     fn(fpt, cout, c_skip, cin - c_skip, buf.ctypes.data_as(C.c_void_p))
     return torch.from_numpy(buf).to(device)
+
+
+def pack_conv_weight_upfold_mix8(weight: Tensor, c_skip: int, device) -> Tuple[Tensor, int]:
+    """Torch-layout (cout, c_skip + c_up, 3, 3, 3) fp32 weight -> (weight image of ``sk_conv3d_upfold_mix8``, fp8 scale exponent)."""
+    w = weight.detach().float().cpu().contiguous()
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    fn = _ffi.lib.sk_conv3d_pack_weight_upfold_mix8_host
+    fpt = w.numpy().ctypes.data_as(C.POINTER(C.c_float))
+    nbytes = fn(fpt, cout, c_skip, cin - c_skip, None, None)
+    if nbytes < 0:
+        _ffi.check(int(nbytes))
+    buf = np.empty(nbytes, dtype=np.uint8)
+    exp = C.c_int32(0)
+    fn(fpt, cout, c_skip, cin - c_skip, buf.ctypes.data_as(C.c_void_p), C.byref(exp))
+    return torch.from_numpy(buf).to(device), int(exp.value)
+
+
+def conv3d_upfold_mix8(skip: Tensor, up: Tensor, packed_weight: Tensor, scale_exp: int, bias: Tensor, cout: int):
+    """``conv3d_upfold`` for precision "mix8": skip / up hold mix8 lines (:func:`mix8_of`), the result is a split pair."""
+    _ffi.require_gpu(skip, "skip")
+    _ffi.require_gpu(up, "up")
+    B, ox, oy, oz = (int(v) for v in skip.shape[:4])
+    if tuple(up.shape[:4]) != (B, ox // 2, oy // 2, oz // 2):
+        raise ValueError(f"up {tuple(up.shape)} is not half of skip {tuple(skip.shape)}")
+    nblk = _ffi.lib.sk_conv3d_upfold_num_blocks(ox, oy, oz, cout)
+    if nblk <= 0:
+        raise ValueError(f"sk_conv3d_upfold does not cover the output shape {(ox, oy, oz)} / cout {cout}")
+    out = torch.empty((B, ox, oy, oz, cout * 2), dtype=torch.float16, device=skip.device)
+    partial = torch.zeros((B, nblk, cout // 4, 2), dtype=torch.float32, device=skip.device)
+    _ffi.check(_ffi.lib.sk_conv3d_upfold_mix8(_ffi.ptr(skip), skip.shape[-1] // 2, _ffi.ptr(up), up.shape[-1] // 2, _ffi.ptr(packed_weight),
+                                              int(scale_exp), _ffi.ptr(bias), _ffi.ptr(out), B, ox, oy, oz, cout, _ffi.ptr(partial),
+                                              _ffi.stream_ptr(skip.device)))
+    return out, partial
 
 
 def conv3d_upfold(skip: Tensor, up: Tensor, packed_weight: Tensor, bias: Tensor, cout: int, want_stats: bool = True,

@@ -207,6 +207,17 @@ def test_down_conv_with_fused_activation_split(U, B, osp, cin, cout):
     assert torch.allclose(partial.sum(1), want_partial.sum(1), rtol=1e-5, atol=1e-4)
     ref = F.conv3d(_cf(U.join_pair(act.cpu())).double(), w.double(), bias.cpu().double(), stride=2)
     assert (_cf(g64) - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # precision "mix8": the same conv with the activated input written back as mix8 lines (sk_groupnorm_silu_mix8's store)
+    xm = raw.clone()
+    gotm = torch.empty_like(got)
+    partm = torch.zeros_like(partial)
+    _ffi.check(_ffi.lib.sk_conv3d_down_act_mix8(_ffi.ptr(xm), _ffi.ptr(aff), _ffi.ptr(wp), _ffi.ptr(bias), _ffi.ptr(gotm), B,
+                                                osp[0], osp[1], osp[2], cin, cout, _ffi.ptr(partm), _ffi.ptr(zeros), st))
+    actm = raw.clone()
+    _ffi.check(_ffi.lib.sk_groupnorm_silu_mix8(_ffi.ptr(actm), _ffi.ptr(aff), B, vox, cin, st))
+    torch.cuda.synchronize()
+    assert torch.equal(xm, actm), "written-back mix8 lines differ from sk_groupnorm_silu_mix8"
+    assert torch.equal(gotm, got) and torch.equal(partm, partial)
     # the raw source of a 1x1x1 conv is activated on load by the split gather kernel (sk_conv3d_split, affine != NULL)
     if cin == 64:
         w1 = torch.randn((32, cin, 1, 1, 1), generator=gen) / cin ** 0.5

@@ -169,3 +169,81 @@ def test_upfold_split_vs_float64(shape):
     wq = want.reshape(B, cout // 4, 4, -1)
     assert torch.allclose(p[..., 0], wq.sum(dim=(2, 3)), rtol=1e-4, atol=1e-3 * wq.shape[-1] ** 0.5)
     assert torch.allclose(p[..., 1], (wq ** 2).sum(dim=(2, 3)), rtol=1e-4)
+
+
+def _e4m3(t):
+    return t.to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("shape", [(1, (8, 12, 20), 32, 32, 32), (2, (12, 14, 20), 32, 32, 32), (1, (14, 22, 10), 64, 64, 64),
+                                   (1, (8, 8, 12), 32, 64, 32)])
+def test_upfold_mix8_fp8_phases_exact(shape):
+    """sk_conv3d_upfold_mix8, the two block-scaled fp8 phases alone (hi halves = 0): every (cout, cin) pair has ONE non-zero
+    tap w = s (1 + m / 8) + j 2^-14, so a folded weight is that tap or zero and all four fp8 images (x8, lo8 of both sources,
+    2^(b+11) w_lo, 2^b w) are exact small integers: the result 2^-(b+15) (conv(x8, 2^(b+11) w_lo) + conv(lo8, 2^b w)) over
+    cat([skip, upsample(up)]) is exact in fp32.  Pins the tap-row pairing of the skip chunks on the de-interleaved planes, the
+    (ty; tz pair) K blocks of the upsampled chunks per parity class, both lane maps and the zero halos of the 8-bit bytes."""
+    from skoots_amd import unet as U
+    B, osp, c_skip, c_up, cout = shape
+    gen = torch.Generator().manual_seed(5 + osp[1])
+    lo = tuple(v // 2 for v in osp)
+    cin = c_skip + c_up
+    base = (1 + torch.randint(0, 8, (cout, cin), generator=gen).float() / 8) * (torch.randint(0, 2, (cout, cin), generator=gen) * 2 - 1).float()
+    j = torch.randint(-3, 4, (cout, cin), generator=gen).float()
+    tap = torch.randint(0, 27, (cout, cin), generator=gen)
+    onehot = torch.nn.functional.one_hot(tap, 27).float().reshape(cout, cin, 3, 3, 3)
+    w = onehot * (base + j * 2.0 ** -14)[..., None, None, None]
+    wp, b = U.pack_conv_weight_upfold_mix8(w, c_skip, DEV)
+    assert b == 6
+    parts = {}
+    for name, c, sp in (("skip", c_skip, osp), ("up", c_up, lo)):
+        x8 = torch.randint(-3, 4, (B,) + sp + (c,), generator=gen).float()
+        l8 = torch.randint(-3, 4, (B,) + sp + (c,), generator=gen).float()
+        parts[name] = (x8, l8, U.mix8_line(torch.zeros((B,) + sp + (c,), dtype=torch.float16), _e4m3(x8), _e4m3(l8)).to(DEV))
+    got, _ = U.conv3d_upfold_mix8(parts["skip"][2], parts["up"][2], wp, b, torch.zeros(cout, device=DEV), cout)
+    torch.cuda.synchronize()
+
+    def cat(k):
+        return torch.cat([_cf(parts["skip"][k]).double(), F.interpolate(_cf(parts["up"][k]).double(), scale_factor=2, mode="nearest")], dim=1)
+    wlo = (onehot * (j * 2.0 ** -14 * 2.0 ** (b + 11))[..., None, None, None]).double()
+    wv = (onehot * (base * 2.0 ** b)[..., None, None, None]).double()
+    want = (F.conv3d(cat(0), wlo, padding=1) + F.conv3d(cat(1), wv, padding=1)) * 2.0 ** -(b + 15)
+    assert torch.equal(_cf(U.join_pair(got.cpu()).double()), want)
+
+
+@pytest.mark.parametrize("shape", [(1, (8, 12, 20), 32, 32, 32), (2, (12, 14, 20), 32, 32, 32), (1, (14, 22, 10), 64, 64, 64),
+                                   (1, (8, 8, 12), 32, 64, 32)])
+def test_upfold_mix8_vs_float64(shape):
+    """sk_conv3d_upfold_mix8 on realistic operands against a float64 conv of the same activations (what a split pair holds) and
+    fp32 weights, next to sk_conv3d_upfold_split: the fp8 corrections leave <= 1/10 of the error of the uncorrected fp16 product
+    (sk_conv3d_mix8's bound, tests/test_hip_unet.py); integer weights and activations (no lo parts) come out exactly."""
+    from skoots_amd import unet as U
+    B, osp, c_skip, c_up, cout = shape
+    gen = torch.Generator().manual_seed(31 + osp[1])
+    lo = tuple(v // 2 for v in osp)
+    skip = U.join_pair(U.split_pair(torch.nn.functional.silu(torch.randn((B,) + osp + (c_skip,), generator=gen) * 1.5)))
+    up = U.join_pair(U.split_pair(torch.nn.functional.silu(torch.randn((B,) + lo + (c_up,), generator=gen) * 1.5)))
+    w = torch.randn((cout, c_skip + c_up, 3, 3, 3), generator=gen) / ((c_skip + c_up) * 27) ** 0.5
+    bias = torch.randn(cout, generator=gen) * 0.1
+    x = torch.cat([_cf(skip).double(), F.interpolate(_cf(up).double(), scale_factor=2, mode="nearest")], dim=1)
+    want = F.conv3d(x, w.double(), bias.double(), padding=1)
+    scale = max(1.0, want.abs().max().item())
+    wp, b = U.pack_conv_weight_upfold_mix8(w, c_skip, DEV)
+    got, partial = U.conv3d_upfold_mix8(U.mix8_of(skip).to(DEV), U.mix8_of(up).to(DEV), wp, b, bias.to(DEV), cout)
+    sp, sp_partial = U.conv3d_upfold(U.split_pair(skip).to(DEV), U.split_pair(up).to(DEV),
+                                     U.pack_conv_weight_upfold(w, c_skip, DEV, split=True), bias.to(DEV), cout, split=True)
+    torch.cuda.synchronize()
+    e_mix = (_cf(U.join_pair(got.cpu())).double() - want).abs().max().item()
+    e_split = (_cf(U.join_pair(sp.cpu())).double() - want).abs().max().item()
+    e_f16 = (F.conv3d(x.half().float(), w.half().float(), bias, padding=1).double() - want).abs().max().item()
+    print(f"upfold mix8 {shape}: max-abs split {e_split:.2e} mix8 {e_mix:.2e} fp16 operands {e_f16:.2e} (scale {scale:.2f})")
+    assert e_mix <= 3e-5 * scale and e_mix <= e_f16 / 10
+    assert torch.allclose(partial.sum(1), sp_partial.sum(1), rtol=1e-4, atol=3e-2)
+    # integers: only the fp16 phases contribute, exactly
+    xi = torch.randint(-3, 4, (B,) + osp + (c_skip,), generator=gen).float()
+    ui = torch.randint(-3, 4, (B,) + lo + (c_up,), generator=gen).float()
+    wi = torch.randint(-1, 2, (cout, c_skip + c_up, 3, 3, 3), generator=gen).float()
+    wpi, bi = U.pack_conv_weight_upfold_mix8(wi, c_skip, DEV)
+    goti, _ = U.conv3d_upfold_mix8(U.mix8_of(xi).to(DEV), U.mix8_of(ui).to(DEV), wpi, bi, torch.zeros(cout, device=DEV), cout)
+    wanti = F.conv3d(torch.cat([_cf(xi), F.interpolate(_cf(ui), scale_factor=2, mode="nearest")], dim=1), wi, padding=1)
+    assert torch.equal(_cf(U.join_pair(goti.cpu())), wanti)
