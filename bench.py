@@ -22,7 +22,7 @@ north_star tolerance) or "fp32" (exact-fp32 MFMA).  Every line states its own me
 ``--config train``: BASELINE configs[4], one training step on a synthetic 256^3 crop (see train_measure).
 
 The default N = 1 line (what the driver runs) carries three measurements from ONE process: ``value`` = the fp16 eval
-path (BASELINE's dtype), ``also.split`` (and ``also.mix8``, its variant with fp8 correction products in the two 32 -> 32 convs)
+path (BASELINE's dtype), ``also.split`` (and ``also.mix8``, its variant with fp8 correction products in the 3x3x3 convs)
 = the same volume at the precision that meets north_star's 1e-3 tolerance
 (value, ms_per_step, roofline, parity_vs_fp32_mode measured live) and ``also.train_bf16`` = configs[4] (ms_per_step,
 Mvoxels/s trained, roofline); ``--no-also`` prints the first alone.  ``box`` = a bare-MFMA-loop probe of this device:
@@ -614,7 +614,7 @@ def eval_main(args, rank, world, local):
                 "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": {"fp16": "f16", "split": "f16 hi+lo pairs (3 MFMA products, f32 accumulate)",
-                          "mix8": "f16 hi+lo pairs; the 32->32 convs: f16 product + block-scaled fp8 correction product", "fp32": "f32"}[precision],
+                          "mix8": "f16 hi+lo pairs; 3x3x3 convs: f16 product + block-scaled fp8 (e4m3) correction product, f32 accumulate", "fp32": "f32"}[precision],
                 "data": "synthetic",
                 "config": {"workload": f"{X}x{Y}x{Z} fp16 volume, 300x300x20 tiles (margin 50,50,5), "
                                        f"U-Net dims [32,64,128,64,32] depths [2,2,2,2,2], N=10 follow, "
@@ -677,11 +677,13 @@ def eval_main(args, rank, world, local):
         also["split"]["stage_ms"] = sp["config"]["stage_ms"]
         also["split"]["step_ms_min_max"] = sp["config"]["step_ms_min_max"]
         also["split"]["allocator_in_timed_steps"] = sp["config"]["allocator_in_timed_steps"]
-        # "split" with the 32 -> 32 convs' correction products on the block-scaled fp8 matrix instruction (sk_conv3d_mix8)
+        # "split" with every 3x3x3 conv's two correction products as one block-scaled fp8 matrix product (sk_conv3d_mix8, sk_conv3d_upfold_mix8)
         mx = measure("mix8", args.also_steps, 1, args.streams)
         also["mix8"] = {k: mx[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "parity_vs_fp32_mode") if k in mx}
-        also["mix8"]["layers"] = {k: v for k, v in mx["roofline"]["layers"].items() if k in ("enc0.1", "dec0.1")}
-        also["mix8"]["split_layers"] = {k: v for k, v in sp["roofline"]["layers"].items() if k in ("enc0.1", "dec0.1")}
+        also["mix8"]["layer_launch_ms"] = {k: [sp["roofline"]["layers"][k]["avg_launch_ms"], v["avg_launch_ms"]]
+                                           for k, v in mx["roofline"]["layers"].items() if k in sp["roofline"]["layers"]}
+        also["mix8"]["layer_launch_ms_note"] = "[split, mix8] per 3x3x3 conv launch of one tile batch, HIP events"
+        also["mix8"]["stage_ms"] = mx["config"]["stage_ms"]
         also["mix8"]["step_ms_min_max"] = mx["config"]["step_ms_min_max"]
     if rank == 0:
         line["box"] = probe

@@ -18,7 +18,7 @@ NAMES = ["skip_mfma", "barrier", "dma_low_issue", "landing_wait", "barrier", "up
 def main():
     from skoots_amd import _ffi, unet
     dev = torch.device("cuda", 0)
-    B, ext = 8, (300, 300, 20)
+    B, ext = int(os.environ.get("BATCH", "8")), (300, 300, 20)
     dbg = torch.zeros((4096, 4, 16), dtype=torch.int64, device=dev)
     _ffi.check(_ffi.lib.sk_debug_set_timing_buffer(_ffi.ptr(dbg), dbg.numel() * 8))
     g = torch.Generator(device=dev).manual_seed(1)
@@ -27,16 +27,25 @@ def main():
     w = torch.randn((32, 64, 3, 3, 3)) / (64 * 27) ** 0.5
     wp = unet.pack_conv_weight_upfold(w, 32, dev)
     bias = torch.zeros(32, device=dev)
-    for _ in range(2):
-        dbg.zero_()
-        unet.conv3d_upfold(skip, up, wp, bias, 32)
-        torch.cuda.synchronize()
+    sf, uf = skip.float().cpu(), up.float().cpu()
+    wps = unet.pack_conv_weight_upfold(w, 32, dev, split=True)
+    wpm, wexp = unet.pack_conv_weight_upfold_mix8(w, 32, dev)
+    ss, us = unet.split_pair(sf).to(dev), unet.split_pair(uf).to(dev)
+    sm, um = unet.mix8_of(sf).to(dev), unet.mix8_of(uf).to(dev)
+    runs = (("fp16", lambda: unet.conv3d_upfold(skip, up, wp, bias, 32)),
+            ("split", lambda: unet.conv3d_upfold(ss, us, wps, bias, 32, split=True)),
+            ("mix8", lambda: unet.conv3d_upfold_mix8(sm, um, wpm, wexp, bias, 32)))
+    for name, fn in runs:
+        for _ in range(2):
+            dbg.zero_()
+            fn()
+            torch.cuda.synchronize()
+        d = dbg.double()
+        used = d.sum(dim=(1, 2)) > 0
+        m = d[used].mean(dim=(0, 1))
+        tot = m.sum().item()
+        print(name, json.dumps({"cycles_per_wave": round(tot), **{f"{i}_{n}": round(v / tot, 4) for i, (n, v) in enumerate(zip(NAMES, m.tolist()))}}), flush=True)
     _ffi.check(_ffi.lib.sk_debug_set_timing_buffer(None, 0))   # detach before `dbg` can be freed
-    d = dbg.double()
-    used = d.sum(dim=(1, 2)) > 0
-    m = d[used].mean(dim=(0, 1))
-    tot = m.sum().item()
-    print(json.dumps({"cycles_per_wave": round(tot), **{f"{i}_{n}": round(v / tot, 4) for i, (n, v) in enumerate(zip(NAMES, m.tolist()))}}))
 
 
 if __name__ == "__main__":
