@@ -860,7 +860,9 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     // the order is a function of the ABSOLUTE x position of the step (x-chunks start at multiples of XS), so that the
     // summation order of an output plane -- and with it every bit of the result -- does not depend on how the launch
     // was cut into x-chunks (which varies with the batch size)
-    auto chunk_of = [&](int step, int k) { return (a.alt && ((xc * (a.XC / XS) + step) & 1)) ? nck - 1 - k : k; };
+    // (MIX8: the two phases of a step -- fp16, fp8 -- swap on odd steps OF THE X-CHUNK, so that a step starts with the kind the
+    // step before ended with and reuses its two trailing planes; the x-chunk cut is a function of the tile geometry alone)
+    auto chunk_of = [&](int step, int k) { return MIX8 ? ((step & 1) ? nck - 1 - k : k) : ((a.alt && ((xc * (a.XC / XS) + step) & 1)) ? nck - 1 - k : k); };
     const int ch0 = chunk_of(0, 0);
     // SPLIT: the output voxel line is [hi (COUT fp16) | lo (COUT fp16)], value = hi + lo (~22 significant bits)
     constexpr int kOvs = COUT * 2 * (SPLIT ? 2 : 1);   // bytes per output voxel
@@ -990,12 +992,13 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
 
     int step = 0, k = 0, ch = ch0, rot = 0;   // k: position of the phase in its step's chunk order
     SK_T_DECL
-    // MIX8: (fp16, fp8) phase pairs with the kind a compile-time value (see conv3_kernel)
-    constexpr int kSub = MIX8 ? 2 : 1;
+    // MIX8: the phase kind is a compile-time value (see conv3_kernel): two steps = (fp16, fp8), (fp8, fp16)
+    constexpr int kSub = MIX8 ? 4 : 1;
     for (int ph0 = 0; ph0 < nphases; ph0 += kSub)
 #pragma unroll
     for (int sub = 0; sub < kSub; ++sub) {
         const int ph = ph0 + sub;
+        if (MIX8 && ph >= nphases) break;   // an odd number of steps: the last pair of the four does not exist
         const int x0 = xa + step * XS;
         if (k == 0) {
 #pragma unroll
@@ -1054,7 +1057,7 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
             // takes 2.1x its MFMA cycles -- 2x is the share of the pipe when the co-resident wave multiplies too, the
             // rest is a wave that has the SIMD to itself exposing one LDS latency per body.  dec0.0 (two chunks):
             // 1.316 -> 1.228 ms per 8 tiles (-6.7 %); the single-chunk layers keep RES = 2 (resident rows beat it, +3 %).
-            const bool f8phase = MIX8 && sub == 1;   // (= a.chinfo[ch] & 4)
+            const bool f8phase = MIX8 && (sub == 1 || sub == 2);   // (= a.chinfo[ch] & 4)
             if (f8phase) {
                 if constexpr (MIX8) {
                     typedef int v8i __attribute__((ext_vector_type(8)));
