@@ -266,7 +266,7 @@ def eval(image_path: str, checkpoint_path: str, used_cached_data: bool = False, 
     ``precision`` (not in the reference's signature; keyword with the reference's behaviour as default): "fp16" = what the
     reference's fp16 autocast does (eval.py:142); "split" = fp16 hi + lo operand pairs, network outputs within 1e-3 of an
     fp32 forward at about a third of the speed; "mix8" = "split" with the 3x3x3 convs' correction products on the block-scaled fp8
-    matrix instruction (same tolerance, ~14 % faster); "fp32" = exact-fp32 matrix instructions (:class:`skoots_amd.unet.HipUNet`).
+    matrix instruction (same tolerance, ~20 % faster); "fp32" = exact-fp32 matrix instructions (:class:`skoots_amd.unet.HipUNet`).
 
     Writes next to the image, with the reference's names: ``<base>_skoots_skeleton`` (1,X,Y,Z) u1
     and ``<base>_skoots_vectors`` (3,X,Y,Z) f2 as ``.zarr`` directory stores (zarr v2 layout, uncompressed,
