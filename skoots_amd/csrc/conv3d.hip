@@ -1446,7 +1446,7 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
         // positions >= needed are padding that the LDS-DMA never writes (d_vox -2: the lane sits out of the instruction):
         // two of them hold the bias / the GroupNorm coefficients of a raw source, the last four are the zero window
         const bool ok = (t < ndma) && y >= 0 && y < a.Yt && z >= 0 && z < a.Zt;
-        d_vox[k] = q >= needed ? -2 : (ok ? y * a.Zt + z : -1);
+        d_vox[k] = q >= needed ? -2 : (ok ? (y * a.Zt + z) * 64 + d_cs : -1);   // the BYTE offset of this lane's 16-byte piece in a plane
     }
 
     const int xa = xc * a.XC;
@@ -1477,7 +1477,7 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
         for (int k = 0; k < kMaxDma; ++k) {
             const int tt = w + 4 * k;
             if (tt < ndma && d_vox[k] != -2) {   // padding lanes are masked out of the plane's last piece (EXEC)
-                const unsigned voff = d_vox[k] >= 0 ? (unsigned)d_vox[k] * 64u + (unsigned)d_cs : sk::kOob;
+                const unsigned voff = d_vox[k] >= 0 ? (unsigned)d_vox[k] : sk::kOob;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lbase + tt * 1024), 16, voff, 0, 0, 0);
             }
         }
