@@ -224,3 +224,54 @@ def test_eval_signature_is_the_references_plus_precision():
     sig = inspect.signature(E.eval)
     assert list(sig.parameters)[:3] == ["image_path", "checkpoint_path", "used_cached_data"]   # skoots/lib/eval.py:33-37
     assert sig.parameters["used_cached_data"].default is False and sig.parameters["precision"].default == "fp16"
+
+
+@pytest.mark.parametrize("ch", [32, 64])
+def test_mix8_weight_image_layout_and_e4m3_encoder(ch):
+    """sk_conv3d_pack_weight_mix8_host (a host function: no GPU): the fp16 part equals sk_conv3d_pack_weight_host of fp16(w); every
+    byte of the fp8 part is torch's e4m3fn image (round to nearest even) of 2^(b+11) (w - fp16(w)) or 2^b w at the position the
+    header documents -- i.e. the library's own fp32 -> e4m3 encoder against torch's over ~10^5 values incl. subnormal images -- and
+    b is the largest power of two with 2^b max|w| <= 240."""
+    from skoots_amd import _ffi
+    gen = torch.Generator().manual_seed(ch)
+    w = (torch.randn((ch, ch, 3, 3, 3), generator=gen) / (ch * 27) ** 0.5 * torch.exp(torch.randn((ch, ch, 3, 3, 3), generator=gen))).contiguous()
+    fpt = w.numpy().ctypes.data_as(C.POINTER(C.c_float))
+    n = _ffi.lib.sk_conv3d_pack_weight_mix8_host(fpt, ch, ch, None, None)
+    buf = np.empty(n, dtype=np.uint8)
+    exp = C.c_int32(-1)
+    assert _ffi.lib.sk_conv3d_pack_weight_mix8_host(fpt, ch, ch, buf.ctypes.data_as(C.c_void_p), C.byref(exp)) == n
+    b = exp.value
+    wmax = w.abs().max().item()
+    assert wmax * 2.0 ** b <= 240 < wmax * 2.0 ** (b + 1)
+    hi = w.half().float().contiguous()
+    n16 = _ffi.lib.sk_conv3d_pack_weight_host(hi.numpy().ctypes.data_as(C.POINTER(C.c_float)), ch, ch, 3, None)
+    ref16 = np.empty(n16, dtype=np.uint8)
+    _ffi.lib.sk_conv3d_pack_weight_host(hi.numpy().ctypes.data_as(C.POINTER(C.c_float)), ch, ch, 3, ref16.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(buf[:n16], ref16)
+    lo8 = ((w - hi) * 2.0 ** (b + 11)).to(torch.float8_e4m3fn).view(torch.uint8)   # (co, ci, dx, dy, dz)
+    w8 = (w * 2.0 ** b).to(torch.float8_e4m3fn).view(torch.uint8)
+    img = torch.from_numpy(buf[n16:].copy())
+    lane = torch.arange(64)
+    if ch == 32:   # [tap-row pair 5][cout half 2][dx 3][lane 64][byte 32]: K block g = lane >> 4: row 2 rp + (g >> 1), g & 1: w_lo | w
+        img = img.reshape(5, 2, 3, 64, 32)
+        for rp in range(5):
+            for i in range(2):
+                for dx in range(3):
+                    g, co = lane >> 4, 16 * i + (lane & 15)
+                    row = 2 * rp + (g >> 1)
+                    ok = row < 9
+                    rowc = row.clamp(max=8)
+                    want = torch.where((g & 1).bool()[:, None], w8[co, :, dx, rowc // 3, rowc % 3], lo8[co, :, dx, rowc // 3, rowc % 3])
+                    want = torch.where(ok[:, None], want, torch.zeros_like(want))
+                    assert torch.equal(img[rp, i, dx], want), (rp, i, dx)
+    else:          # [chunk][row 9][dx 3][cout tile][lane 64][byte 32]: row lane & 31 of the tile, K block lane >> 5: w_lo | w
+        nt = ch // 32
+        img = img.reshape(ch // 32, 9, 3, nt, 64, 32)
+        for k in range(ch // 32):
+            for row in range(9):
+                for dx in range(3):
+                    for t in range(nt):
+                        co = 32 * t + (lane & 31)
+                        src = torch.where((lane >> 5).bool()[:, None], w8[co, 32 * k:32 * k + 32, dx, row // 3, row % 3],
+                                          lo8[co, 32 * k:32 * k + 32, dx, row // 3, row % 3])
+                        assert torch.equal(img[k, row, dx, t], src), (k, row, dx, t)
