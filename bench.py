@@ -684,6 +684,11 @@ def eval_main(args, rank, world, local):
                                            for k, v in mx["roofline"]["layers"].items() if k in sp["roofline"]["layers"]}
         also["mix8"]["layer_launch_ms_note"] = "[split, mix8] per 3x3x3 conv launch of one tile batch, HIP events"
         also["mix8"]["stage_ms"] = mx["config"]["stage_ms"]
+        also["mix8"]["roofline"] = {k: mx["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "executed",
+                                                                    "frac_executed", "launches", "avg_launch_ms", "timed_over")}
+        also["mix8"]["roofline"]["note"] = ("achieved = ALGORITHMIC FLOPs / conv time; executed = fp16-pass equivalents: per chunk one fp16 "
+                                            "product + one block-scaled fp8 instruction stream that takes 10/9 (K = 128) or 1 (K = 64, "
+                                            "folded taps) fp16-pass times")
         also["mix8"]["step_ms_min_max"] = mx["config"]["step_ms_min_max"]
     if rank == 0:
         line["box"] = probe

@@ -304,9 +304,20 @@ class HipUNet:
         if timed:
             e1.record(torch.cuda.current_stream(self.device))
             self.profile.events.append((e0, e1, layer.flops_per_out_voxel * B * ox * oy * oz, layer.name))
-            per_voxel = 2.0 * layer.cout * (arr[0].c * 27 + arr[1].c * 8) if fold else layer.flops_per_out_voxel
-            # split mode: three fp16 MFMA products (w_lo x_hi, w_hi x_hi, w_hi x_lo) per algorithmic product
-            self.profile.executed_flops += per_voxel * B * ox * oy * oz * (3 if split else 1)
+            # split mode: three fp16 MFMA products (w_lo x_hi, w_hi x_hi, w_hi x_lo) per algorithmic product; mix8: the fp16 product
+            # + one fp8 instruction stream that takes the time of 10/9 (K = 128: ten tap rows for nine) or 1 (K = 64, folded taps)
+            # fp16 passes -- counted in fp16-pass equivalents against the fp16 peak
+            passes = 3.0 if split else 1.0
+            k128 = 1.0 + 10.0 / 9.0
+            if mix_in and fold:
+                per_voxel = 2.0 * layer.cout * (arr[0].c * 27 * k128 + arr[1].c * 8 * 2.0)
+                passes = 1.0
+            elif mix_in:
+                per_voxel = layer.flops_per_out_voxel
+                passes = k128 if layer.cout == 32 else 2.0
+            else:
+                per_voxel = 2.0 * layer.cout * (arr[0].c * 27 + arr[1].c * 8) if fold else layer.flops_per_out_voxel
+            self.profile.executed_flops += per_voxel * B * ox * oy * oz * passes
         aff = self._norm_act(layer, out, partial, nblk, apply=activate, mix_out=mix_out and activate)
         return out if activate else (out, aff)
 
