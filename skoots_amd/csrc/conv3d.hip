@@ -52,7 +52,7 @@ constexpr int kPatch = 128;      // voxels per (y,z) patch = 4 waves x 32 column
 constexpr int kMaxDma = 4;       // DMA wave-instructions per plane per wave (nposp <= 256)
 constexpr int kPadStride = 64;   // bytes per voxel in the epilogue transpose pad (16-B chunks XOR-swizzled)
 constexpr int kPadBytes = 32 * kPadStride;
-constexpr int kMaxChunks = 16;   // phase chunks per step: 4 plain (128 channels) or 12 split (3 per 32 channels)
+constexpr int kMaxChunks = 24;   // phase chunks per step: 8 plain (256 channels: a 128 + 128 concat) or 24 split (3 per 32 channels)
 
 struct SrcDev {
     const char* data;

@@ -675,3 +675,33 @@ def test_eval_is_deterministic(U):
     assert torch.equal(a["labels"], b["labels"])
     assert torch.equal(a["instance_mask"], b["instance_mask"])
     assert a["n_instances"] == b["n_instances"]
+
+
+@pytest.mark.parametrize("dims,depths", [((32, 32, 64, 32, 32), (1, 2, 3, 2, 1)), ((32, 64, 64, 64, 32), (3, 1, 1, 1, 3)),
+                                         ((32, 128, 128, 128, 32), (2, 2, 1, 2, 2))])
+@pytest.mark.parametrize("precision", ["fp16", "split", "mix8"])
+def test_network_other_widths_and_depths_vs_oracle(U, dims, depths, precision):
+    """MODEL.DIMS / MODEL.DEPTHS other than the default (lib/utils.py:46-57 reads them from the checkpoint's cfg): every width
+    the kernels are built for on each level, blocks of depth 1 (the stem feeds the stride-2 conv directly; a decoder level is
+    its concat conv alone) and 3 (a middle layer between two 3x3x3 convs), in the three fast precisions against the fp32
+    oracle -- the fused-activation and mix8 hand-offs are decided per layer from these."""
+    from oracle import unet_spec
+    ref = unet_spec.build(11, dims=dims, depths=depths)
+    hip = U.HipUNet.from_module(ref, DEV, precision=precision)
+    tile, origins = (36, 40, 20), [(0, 0, 0), (5, 3, 2)]
+    gen = torch.Generator().manual_seed(sum(dims) + sum(depths))
+    shape = tuple(max(o[k] for o in origins) + tile[k] for k in range(3))
+    vol = torch.randint(0, 256, shape, generator=gen).to(torch.float16)
+    mean, std = float(vol.mean()), float(vol.std())
+    out5 = hip.forward_tiles(vol.to(DEV), origins, tile, mean, std).cpu().float()
+    box = ([4, 6, 3], [30, 33, 17])
+    boxed = hip.forward_tiles(vol.to(DEV), origins, tile, mean, std, out_box=box).cpu().float()
+    for b, (x, y, z) in enumerate(origins):
+        crop = vol[x:x + tile[0], y:y + tile[1], z:z + tile[2]][None, None].sub(mean).div(std).float()
+        with torch.no_grad():
+            want = ref(crop)[0]
+        e = (out5[b] - want).abs().max().item()
+        print(f"dims {dims} depths {depths} {precision} tile {b}: max abs err {e:.2e}")
+        assert e <= (1e-2 if precision == "fp16" else 1e-3)
+        (x0, y0, z0), (x1, y1, z1) = box
+        assert torch.equal(boxed[b][:, x0:x1, y0:y1, z0:z1], out5[b][:, x0:x1, y0:y1, z0:z1])
