@@ -95,8 +95,8 @@ def test_production_batch_vs_oracle(production, precision, boxed):
         assert e.max().item() <= tol_max and rms <= tol_rms, (precision, b, e.max().item(), rms)
 
 
-@pytest.mark.parametrize("nb", [8, 16, 32, 64])
-def test_production_batch_is_batch_invariant(production, nb):
+@pytest.mark.parametrize("nb,precision", [(8, "fp16"), (16, "fp16"), (32, "fp16"), (64, "fp16"), (16, "split"), (16, "mix8")])
+def test_production_batch_is_batch_invariant(production, nb, precision):
     """A tile's output must not depend on its position in the batch, on its batch mates or on the batch size (per-sample
     GroupNorm, batch strides; the x-chunking of a conv launch is a function of the tile geometry only, because a
     batch-dependent cut changes the grouping of the fp32 GroupNorm partial sums and with it the last bits of the
@@ -106,7 +106,7 @@ def test_production_batch_is_batch_invariant(production, nb):
     ref, vol, origins, mean, std, _ = production
     grid = cropper.distinct_origins(SHAPE, list(TILE), OVERLAP)
     batch = (origins + [o for o in grid if o not in origins])[:nb]
-    hip = unet.HipUNet.from_module(ref, DEV)
+    hip = unet.HipUNet.from_module(ref, DEV, precision=precision)
     out = hip.forward_tiles(vol, batch, TILE, mean, std)
     picks = [2, nb - 1]
     kept = [out[i].clone() for i in picks]
