@@ -200,3 +200,28 @@ def test_config1_network_vs_fp32_mode(precision):
     print(f"{precision} vs fp32 mode at 512x512x128: max {e.max().item():.2e} rms {rms:.2e}")
     tol_max, tol_rms = BOUNDS[precision]
     assert e.max().item() <= tol_max and rms <= tol_rms
+
+
+@pytest.mark.parametrize("precision", ["fp16", "mix8"])
+def test_two_streams_equal_one_stream(precision):
+    """ShardedVolume.run(streams=2): two tile batches in flight on two HIP streams, each with its own activation context
+    (HipUNet.clone_context), the owner tables making the scatter order-independent -- vectors, skeleton and instance mask must
+    equal the single-stream run bit for bit, with the REAL network (a tile's output does not depend on its batch or context)."""
+    from skoots_amd import unet
+    from skoots_amd.parallel import ShardedVolume
+    shape = (400, 364, 44)
+    vol = _volume(shape, 9)
+    sd = unet.random_state_dict(seed=5)
+    with torch.no_grad():   # open the gate so that stages 2-3 have something to do
+        sd["heads.bias"][4] = 3.0
+        sd["heads.bias"][3] = 1.4
+    hip = unet.HipUNet(sd, DEV, precision=precision)
+    res = []
+    for streams in (1, 2):
+        sv = ShardedVolume(shape, 0, 1, torch.device(DEV))
+        r = sv.run(vol, hip, (60, 60, 12), 127.5, 73.9, tile_batch=3, streams=streams)
+        res.append((r["vec4"].clone(), r["skeleton"].clone(), r["instance_mask"].clone(), int(r["n_instances"])))
+    assert res[0][1].any()
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, b)
+    assert res[0][3] == res[1][3]
