@@ -862,7 +862,13 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
     // was cut into x-chunks (which varies with the batch size)
     // (MIX8: the two phases of a step -- fp16, fp8 -- swap on odd steps OF THE X-CHUNK, so that a step starts with the kind the
     // step before ended with and reuses its two trailing planes; the x-chunk cut is a function of the tile geometry alone)
-    auto chunk_of = [&](int step, int k) { return MIX8 ? ((step & 1) ? nck - 1 - k : k) : ((a.alt && ((xc * (a.XC / XS) + step) & 1)) ? nck - 1 - k : k); };
+    // (SPLIT, one logical chunk = three phases [x_hi w_lo | x_hi w_hi | x_lo w_hi]: odd steps of the x-chunk run them as
+    // [x_lo w_hi | x_hi w_lo | x_hi w_hi], so that every step starts on the half the step before ended on)
+    auto chunk_of = [&](int step, int k) {
+        if (MIX8) return (step & 1) ? nck - 1 - k : k;
+        if (SPLIT && nck == 3) return (step & 1) ? (k + 2) % 3 : k;
+        return (a.alt && ((xc * (a.XC / XS) + step) & 1)) ? nck - 1 - k : k;
+    };
     const int ch0 = chunk_of(0, 0);
     // SPLIT: the output voxel line is [hi (COUT fp16) | lo (COUT fp16)], value = hi + lo (~22 significant bits)
     constexpr int kOvs = COUT * 2 * (SPLIT ? 2 : 1);   // bytes per output voxel
@@ -1214,7 +1220,8 @@ __global__ void __launch_bounds__(256, 2) conv3_m16_kernel(Conv3Args a) {
         }
         const int nch = chunk_of(nstep, nk);
         const bool have_next = ph + 1 < nphases;
-        const bool reuse_n = step_done && nch == ch;   // same chunk, next step: its planes XS, XS + 1 stay
+        // same staged data (source and byte offset in the voxel line), next step: its planes XS, XS + 1 stay
+        const bool reuse_n = step_done && (SPLIT ? ((a.chinfo[nch] ^ a.chinfo[ch]) & ~6u) == 0 : nch == ch);
         const int rot_n = reuse_n ? (rot + XS) % R : rot;
         SK_T(0)           // MFMA phase
         __syncthreads();  // every wave is done reading the planes about to be overwritten
