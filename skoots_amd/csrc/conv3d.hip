@@ -1878,6 +1878,423 @@ __global__ void __launch_bounds__(256, 2) conv3_px_kernel(Conv3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// conv3_pxm_kernel (round 4): conv3_px_kernel's plane streaming for precision "mix8" -- the single-chunk 32 -> 32 convs of the
+// production tile on [hi fp16 | x8 | lo8] lines.  conv3_m16_kernel's mix8 form stages six planes of the hi halves and six planes of
+// the 8-bit halves for four output planes (3.4 plane-halves per output plane-half with the patch halo; it fetches 2.9 x its input
+// and is bound by that).  Here every input plane is staged ONCE: a step consumes two input planes in two
+// phases -- the fp16 product on their hi halves (conv3_px_kernel's body), the block-scaled fp8 product on their 8-bit halves
+// (conv3_m16_kernel's K = 128 blocks) -- and four 11 KiB slots suffice: the 8-bit halves of a step land during its fp16 phase,
+// the hi halves of the NEXT step during its fp8 phase, in the slots the fp16 phase has just freed.  Same LDS budget as
+// conv3_px_kernel (four slots + twelve half tap rows of fp16 weights: 80 KiB, two workgroups per CU); the 60 KiB fp8 weight image
+// streams from L2.  Output: a RAW split pair, statistics from the fp32 accumulators, store box honoured.
+template <int RESH, int NPOSP>
+__global__ void __launch_bounds__(256, 2) conv3_pxm_kernel(Conv3Args a) {
+    constexpr int NSLOT = 4;
+    constexpr int plane_bytes = NPOSP * kPosBytes;   // compile-time: a slot's offset is an immediate of its ds_read_b128
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // column tile of this wave (32 voxels of the 128-voxel patch)
+    const int c16 = lane & 15, g = lane >> 4;
+
+    int blk = blockIdx.x;   // XCD-aware order, see conv3_kernel
+    {
+        const int nwg = gridDim.x, xcd = blk & 7, qn = nwg >> 3, rn = nwg & 7;
+        blk = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blk >> 3);
+    }
+    const int patch = blk % a.npatch;
+    blk /= a.npatch;
+    const int xc = blk % a.nxc;
+    const int b = blk / a.nxc;
+    const int block_in_batch = xc * a.npatch + patch;
+    const int nblk = a.npatch * a.nxc;
+
+    // ---- patch geometry (conv3_m16_kernel's, one column tile per wave) ---------------------------
+    const int pitch = a.pitch;
+    int off, ybase, zbase, q_row, out_vox0, tile_nvox;
+    int svy, svz;             // (y, z) of the voxel this lane STORES: column c16 + 16 (g & 1) of the wave's tile
+    unsigned vflags = 0;      // bit j: voxel 16 j + c16 on the z = 0 face | << 8: on the z = Zt-1 face | << 16: inside the tile
+    auto zlo = [&](int j) { return (vflags >> j) & 1u; };
+    auto zhi = [&](int j) { return (vflags >> (8 + j)) & 1u; };
+    auto vvalid = [&](int j) { return (vflags >> (16 + j)) & 1u; };
+    // linear mode only (Zt <= 40, conv3_m16_kernel's comment): region position q <-> in-plane voxel v0 - Zt - 1 + q
+    const int needed = kPatch + 2 * a.Zt + 2;   // positions a plane really holds; NPOSP rounds it up to a DMA granule
+    {
+        const int v0 = patch * kPatch;
+        off = v0 - a.Zt - 1;
+        ybase = 0;
+        zbase = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int v = v0 + 32 * w + 16 * j + c16;
+            const int vy = v / a.Zt, vz = v - vy * a.Zt;
+            vflags |= (unsigned)(v < a.Yt * a.Zt) << (16 + j);
+            vflags |= (unsigned)(vz == 0) << j;
+            vflags |= (unsigned)(vz == a.Zt - 1) << (8 + j);
+            if (j == 0) q_row = v - off;
+        }
+        out_vox0 = v0 + 32 * w;
+        tile_nvox = a.Yt * a.Zt;
+        const int sv = out_vox0 + c16 + 16 * (g & 1);
+        svy = sv / a.Zt;
+        svz = sv - svy * a.Zt;
+    }
+    const bool sbox = !a.has_box || (svy >= a.box_lo[1] && svy < a.box_hi[1] && svz >= a.box_lo[2] && svz < a.box_hi[2]);
+
+    // ---- LDS-DMA bookkeeping: this lane's slots of a plane (conv3_m16_kernel's swizzle) -----------
+    constexpr int ndma = NPOSP / 16;
+    int d_vox[kMaxDma];
+    const int d_cs = ((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 16;
+#pragma unroll
+    for (int k = 0; k < kMaxDma; ++k) {
+        const int t = w + 4 * k;
+        const int q = (64 * t + lane) >> 2;
+        const int Pq = q + off;
+        const int y = ybase + (Pq >= 0 ? Pq / pitch : -1), z = zbase + (Pq >= 0 ? Pq % pitch : 0);
+        // positions >= needed are padding that the LDS-DMA never writes (d_vox -2: the lane sits out of the instruction):
+        // two of them hold the bias / the GroupNorm coefficients of a raw source, the last four are the zero window
+        const bool ok = (t < ndma) && y >= 0 && y < a.Yt && z >= 0 && z < a.Zt;
+        d_vox[k] = q >= needed ? -2 : (ok ? (y * a.Zt + z) * 128 + d_cs : -1);   // the BYTE offset of this lane's 16-byte piece of the hi halves in a plane of [hi | x8 | lo8] lines
+    }
+
+    const int xa = xc * a.XC;
+    const int xb = min(xa + a.XC, a.Xt);
+    const int n = xb - xa;                 // output planes xa .. xb-1 of this workgroup
+    // The last four positions of every slot are a 256-byte window of zeros (never written by the LDS-DMA).  A tap that
+    // leaves the tile through a z face reads zeros at `zero_addr + (its own address & 255)`: the SAME banks its data
+    // read would have used.  With one shared zero line instead, the four lanes of a z-face voxel (one per K group, one
+    // in each ds_read_b128 lane group) each collide with another lane's banks: 8 LDS cycles instead of 4 for the reads
+    // of six of the nine tap rows, SQ_LDS_BANK_CONFLICT 18-35 % of the LDS-active cycles in every conv3 kernel
+    // (simulated on the documented lane groups: 6.13 cycles per B read on average against 4.00).
+    constexpr int zero_addr = (NPOSP - 4) * kPosBytes;
+    static_assert(zero_addr % 256 == 0, "the zero window must cover the 64 banks once");
+    constexpr int kOvs = 128;              // bytes per output voxel: a split pair [hi (32) | lo (32)]
+    const long long out_plane = (long long)a.Yt * a.Zt * kOvs;
+    char* outb = a.out + (long long)b * a.Xt * out_plane;
+    const SrcDev s0 = a.src[0];
+    const char* srcb = s0.data + (long long)b * s0.batch;
+
+    // H slots 0, 1: the hi halves of the step's two input planes; E slots 2, 3: their 8-bit halves ([x8 | lo8], 64 bytes on in the
+    // voxel line).  A plane outside the tile stages zeros (every lane's offset out of range).
+    auto issue_half = [&](int slot, int x, int half) {
+        const bool xok = x >= 0 && x < a.Xt;
+        const __amdgpu_buffer_rsrc_t rsrc = sk::make_rsrc(srcb + (long long)(xok ? x : 0) * s0.plane, (unsigned)s0.plane);
+        char* lbase = lds + slot * plane_bytes;
+#pragma unroll
+        for (int k = 0; k < kMaxDma; ++k) {
+            const int tt = w + 4 * k;
+            if (tt < ndma && d_vox[k] != -2) {   // padding lanes are masked out of the plane's last piece (EXEC)
+                const unsigned voff = (xok && d_vox[k] >= 0) ? (unsigned)(d_vox[k] + 64 * half) : sk::kOob;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lbase + tt * 1024), 16, voff, 0, 0, 0);
+            }
+        }
+    };
+    // ---- weights: half rows (tap row dydz, cout half i) 0 .. RESH-1 in registers, RESH .. 17 in LDS behind the ring ----
+    // fragment of (row dydz, cout half i, x tap d): ((dydz * 2 + i) * 3 + d) KiB into the packed weight
+    const __amdgpu_buffer_rsrc_t wrsrc = sk::make_rsrc(a.wpk, (unsigned)a.wpk_bytes);
+    half8 wres[RESH][3];
+#pragma unroll
+    for (int r = 0; r < RESH; ++r)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            wres[r][d] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, (r * 3 + d) * 1024, 0));
+    char* wlds = lds + NSLOT * plane_bytes;
+    for (int i = tid; i < (18 - RESH) * 3 * 64; i += 256)
+        *reinterpret_cast<uint4*>(wlds + i * 16) = *reinterpret_cast<const uint4*>(a.wpk + RESH * 3 * 1024 + i * 16);
+    // padding positions of a slot: needed, needed + 1 (128 bytes: slot 0 the GroupNorm scales of a raw source, slot 1 the
+    // bias, slot 2 the GroupNorm shifts) | the zero window NPOSP - 4 .. NPOSP - 1
+    if (tid < NSLOT * 16)
+        *reinterpret_cast<uint4*>(lds + (tid >> 4) * plane_bytes + zero_addr + (tid & 15) * 16) = make_uint4(0, 0, 0, 0);
+    if (tid >= 128 && tid < 160) reinterpret_cast<float*>(lds + plane_bytes + needed * kPosBytes)[tid - 128] = a.bias[tid - 128];
+    SK_T_DECL
+    issue_half(0, xa - 1, 0);
+    issue_half(1, xa, 0);
+    issue_half(2, xa - 1, 1);
+    issue_half(3, xa, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- accumulators ----------------------------------------------------------------------------------------
+    // element r of [i][j]: cout 16 i + 4 g + r, voxel 16 j + c16 of the wave's column tile
+    f32x4 P0[2][2], P1[2][2], Q0[2][2], Q1[2][2];
+    // the bias (the accumulators' initial value) is re-read from its copy in LDS -- padding positions of slot 1 -- at every
+    // reset: eight registers less in the loop
+    const float* lbias = reinterpret_cast<const float*>(lds + plane_bytes + needed * kPosBytes) + 4 * g;
+    auto reset = [&](f32x4 (&o)[2][2]) {
+        o[0][0] = o[0][1] = *reinterpret_cast<const f32x4*>(lbias);
+        o[1][0] = o[1][1] = *reinterpret_cast<const f32x4*>(lbias + 16);
+    };
+    reset(P0);   // (behind the barrier above: the bias in LDS was written by another wave)
+    reset(P1);
+    reset(Q0);
+    reset(Q1);
+    float gsum[2] = {0.0f, 0.0f}, gsq[2] = {0.0f, 0.0f};
+
+    auto baddr = [&](int dydz, int j) -> int {
+        const int dz = dydz % 3 - 1;
+        const int q = q_row + (dydz / 3 - 1) * pitch + dz;
+        int addr = (q * 4 + (g ^ (((q >> 2) & 1) << 1))) * 16 + 1024 * j;
+        if (dz < 0) addr = zlo(j) ? zero_addr + (addr & 255) : addr;
+        if (dz > 0) addr = zhi(j) ? zero_addr + (addr & 255) : addr;
+        return addr;
+    };
+    auto wfrag = [&](int dydz, int i, half8 (&dst)[3]) {
+        if (2 * dydz + i < RESH) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) dst[d] = wres[2 * dydz + i][d];
+        } else {
+            const char* p = wlds + (2 * dydz + i - RESH) * 3 * 1024 + lane * 16;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) dst[d] = *reinterpret_cast<const half8*>(p + d * 1024);
+        }
+    };
+
+    // A step over the input planes A (slot sA) and B = A + 1 (slot sB).  oA1 / oA / oB / oB1: the accumulators of the
+    // output planes A-1, A, B, B+1.  Tap d of a weight row multiplies x_in = x_out + d - 1.
+    auto pair_step = [&](auto SA, auto SB, f32x4 (&oA1)[2][2], f32x4 (&oA)[2][2], f32x4 (&oB)[2][2], f32x4 (&oB1)[2][2]) {
+        // compile-time slots: the 18 tap addresses of the patch (plane-relative, loop-invariant) serve both planes of
+        // every step through the immediate offset of ds_read_b128
+        const char* pa = lds + decltype(SA)::value * plane_bytes;
+        const char* pb = lds + decltype(SB)::value * plane_bytes;
+        half8 bq[2][2][2];   // [buffer][plane][j]: the B fragments of a tap row, one row ahead
+        half8 wq[2][3];      // [buffer][d]: the weight fragments of a half row (cout half i of a tap row), one half row ahead
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ad = baddr(0, j);
+            bq[0][0][j] = *reinterpret_cast<const half8*>(pa + ad);
+            bq[0][1][j] = *reinterpret_cast<const half8*>(pb + ad);
+        }
+        wfrag(0, 0, wq[0]);
+        // The 18 half rows of a step, 12 MFMAs each (192 cycles of the matrix pipe).  The LDS reads of half row h + 1 -- its
+        // three weight fragments when its tap row lives in LDS, and the four B fragments of the next tap row -- are issued
+        // in the FIRST MFMA gaps of half row h, in the order half row h + 1 consumes them, so the youngest read is 80+
+        // cycles old (and not needed before the seventh MFMA) when half row h + 1 starts.  The order is pinned: left to
+        // itself the scheduler spread the reads to the END of the half row and every half row began with an
+        // `s_waitcnt lgkmcnt(0)` on a read issued one MFMA earlier (SQ_WAIT_ANY 38 % of the wave-cycles).
+#pragma unroll
+        for (int dydz = 0; dydz < 9; ++dydz) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int h = dydz * 2 + i;   // its weights sit in wq[h & 1], its B fragments in bq[dydz & 1]
+                const half8(&W)[3] = wq[h & 1];
+                const int ndy = i == 0 ? dydz : dydz + 1, ni = i ^ 1;         // the next half row
+                bool wread = ndy < 9 && 2 * ndy + ni >= RESH;                  // ... reads its weights from LDS
+                bool bread = i == 1 && dydz < 8;                               // ... starts a new tap row: B fragments
+                if (SK_PX_ABL(16) && wread) {   // timing experiment: no LDS weight reads (a resident half row instead)
+                    wread = false;
+                    wfrag((2 * ndy + ni) % RESH / 2, (2 * ndy + ni) % RESH % 2, wq[(h + 1) & 1]);
+                } else if (ndy < 9 && !wread) {
+                    wfrag(ndy, ni, wq[(h + 1) & 1]);                           // resident row: register names only
+                }
+                if (SK_PX_ABL(32) && bread) {   // timing experiment: no B fragment reads after the first tap row
+                    bread = false;
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) bq[(dydz + 1) & 1][pl][jj] = bq[dydz & 1][pl][jj];
+                }
+                // read k of the next half row, in consumption order: W0, A0, B0, W1, W2, A1, B1
+                auto next_read = [&](int k) {
+                    const char* wp = wlds + (2 * ndy + ni - RESH) * 3 * 1024 + lane * 16;
+                    int kk = k;
+                    if (!wread) kk = (k == 0 ? 1 : k == 1 ? 2 : k == 2 ? 5 : 6);   // B fragments only: A0, B0, A1, B1
+                    if (!bread && kk > 0) kk = (kk == 1 ? 3 : 4);                  // weights only: W0, W1, W2
+                    switch (kk) {
+                        case 0: wq[(h + 1) & 1][0] = *reinterpret_cast<const half8*>(wp); break;
+                        case 1: bq[(dydz + 1) & 1][0][0] = *reinterpret_cast<const half8*>(pa + baddr(dydz + 1, 0)); break;
+                        case 2: bq[(dydz + 1) & 1][1][0] = *reinterpret_cast<const half8*>(pb + baddr(dydz + 1, 0)); break;
+                        case 3: wq[(h + 1) & 1][1] = *reinterpret_cast<const half8*>(wp + 1024); break;
+                        case 4: wq[(h + 1) & 1][2] = *reinterpret_cast<const half8*>(wp + 2048); break;
+                        case 5: bq[(dydz + 1) & 1][0][1] = *reinterpret_cast<const half8*>(pa + baddr(dydz + 1, 1)); break;
+                        default: bq[(dydz + 1) & 1][1][1] = *reinterpret_cast<const half8*>(pb + baddr(dydz + 1, 1)); break;
+                    }
+                };
+                const int nreads = (wread ? 3 : 0) + (bread ? 4 : 0);
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    const int j = m / 6;
+                    const half8 fa = bq[dydz & 1][0][j], fb = bq[dydz & 1][1][j];
+                    switch (m % 6) {   // tap d of a weight row multiplies x_in = x_out + d - 1
+                        case 0: oB[i][j] = SK_MFMA_16x16x32_T16(W[0], fa, oB[i][j], 0, 0, 0); break;
+                        case 1: oB1[i][j] = SK_MFMA_16x16x32_T16(W[0], fb, oB1[i][j], 0, 0, 0); break;
+                        case 2: oA[i][j] = SK_MFMA_16x16x32_T16(W[1], fa, oA[i][j], 0, 0, 0); break;
+                        case 3: oA1[i][j] = SK_MFMA_16x16x32_T16(W[2], fa, oA1[i][j], 0, 0, 0); break;
+                        case 4: oB[i][j] = SK_MFMA_16x16x32_T16(W[1], fb, oB[i][j], 0, 0, 0); break;
+                        default: oA[i][j] = SK_MFMA_16x16x32_T16(W[2], fb, oA[i][j], 0, 0, 0); break;
+                    }
+                    if (m < nreads) next_read(m);
+                    if (m <= nreads) __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // The fp8 phase of a step: the same two input planes' 8-bit halves (E slots 2, 3) against the fp8 weight image, tap rows in
+    // pairs (conv3_m16_kernel's K = 128 blocks: lane group g >> 1 = the row of the pair, g & 1 = x8 | lo8).
+    auto pair_f8 = [&](f32x4 (&oA1)[2][2], f32x4 (&oA)[2][2], f32x4 (&oB)[2][2], f32x4 (&oB1)[2][2]) {
+        typedef int v8i __attribute__((ext_vector_type(8)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const char* pa = lds + 2 * plane_bytes;
+        const char* pb = lds + 3 * plane_bytes;
+        const int halfsel = (g & 1) * 2;
+        const int sa = a.w8_scale, sb = 0x70707070;   // E8M0: weights 2^-b (host), activations 2^-15
+        const unsigned w8 = (unsigned)a.w8_off + (unsigned)lane * 32u;
+        auto rd = [&](const char* p) {
+            const u32x4 lo4 = *reinterpret_cast<const u32x4*>(p);
+            const u32x4 hi4 = *reinterpret_cast<const u32x4*>(p + 16);
+            return v8i{(int)lo4[0], (int)lo4[1], (int)lo4[2], (int)lo4[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+        };
+#pragma unroll 1
+        for (int rp = 0; rp < 5; ++rp) {
+            const int rr = min(2 * rp + (g >> 1), 8);   // (the tenth row does not exist: its weights are zero)
+            const int dz = rr % 3 - 1;
+            const int q = q_row + (rr / 3 - 1) * pitch + dz;
+            v8i af[2][3];
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const unsigned wo = w8 + (unsigned)(((rp * 2 + i2) * 3 + d) * 2048);
+                    const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wo, 0, 0);
+                    const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wo + 16, 0, 0);
+                    af[i2][d] = v8i{(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int addr = (q * 4 + (halfsel ^ (((q >> 2) & 1) << 1))) * 16 + 1024 * j;
+                if ((dz < 0 && zlo(j)) || (dz > 0 && zhi(j))) addr = zero_addr + (addr & 255);
+                const v8i fa = rd(pa + addr), fb = rd(pb + addr);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {   // tap d of a weight row multiplies x_in = x_out + d - 1
+                    oB[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i][0], fa, oB[i][j], 0, 0, 0, sa, 0, sb);
+                    oB1[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i][0], fb, oB1[i][j], 0, 0, 0, sa, 0, sb);
+                    oA[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i][1], fa, oA[i][j], 0, 0, 0, sa, 0, sb);
+                    oA1[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i][2], fa, oA1[i][j], 0, 0, 0, sa, 0, sb);
+                    oB[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i][1], fb, oB[i][j], 0, 0, 0, sa, 0, sb);
+                    oA[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i][2], fb, oA[i][j], 0, 0, 0, sa, 0, sb);
+                }
+            }
+        }
+    };
+
+    // store of one finished output plane as a RAW split pair [hi | lo] + its GroupNorm partial sums from the fp32 accumulators
+    // (conv3_m16_kernel's SPLIT epilogue); returns the number of store instructions issued (0 or 4)
+    auto finish_plane = [&](f32x4 (&o)[2][2], int x) -> int {
+        const bool xbox = !a.has_box || (x >= a.box_lo[0] && x < a.box_hi[0]);   // wave-uniform
+        const __amdgpu_buffer_rsrc_t rout = sk::make_rsrc(outb + (long long)x * out_plane, (unsigned)out_plane);
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                unsigned d[2][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 r = o[i][j];
+                    half4 hv = {(t16)r[0], (t16)r[1], (t16)r[2], (t16)r[3]};
+                    if (part == 1)   // lo = fp16(v - hi): exact difference, rounded once
+                        hv = half4{(t16)(r[0] - (float)hv[0]), (t16)(r[1] - (float)hv[1]), (t16)(r[2] - (float)hv[2]), (t16)(r[3] - (float)hv[3])};
+                    const uint2 u = __builtin_bit_cast(uint2, hv);
+                    d[j][0] = u.x;
+                    d[j][1] = u.y;
+                    if (part == 0 && vvalid(j)) {
+                        gsum[i] += (r[0] + r[1]) + (r[2] + r[3]);
+                        gsq[i] += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+                    }
+                }
+                if (xbox) {
+                    const auto s0_ = __builtin_amdgcn_permlane16_swap(d[0][0], d[1][0], false, false);
+                    const auto s1_ = __builtin_amdgcn_permlane16_swap(d[0][1], d[1][1], false, false);
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 lv = {s0_[0], s1_[0], s0_[1], s1_[1]};
+                    const int vv = c16 + 16 * (g & 1);
+                    const bool sok = sbox && out_vox0 + vv < tile_nvox;
+                    const unsigned so = (unsigned)((out_vox0 + vv) * kOvs + 64 * part + 32 * i + 16 * (g >> 1));
+                    __builtin_amdgcn_raw_buffer_store_b128(lv, rout, sok ? so : sk::kOob, 0, 0);
+                }
+            }
+        return xbox ? 4 : 0;
+    };
+    typedef std::integral_constant<int, 0> S0_;
+    typedef std::integral_constant<int, 1> S1_;
+    // ---- the march -----------------------------------------------------------------------------------------------
+    // Step s consumes the input planes A = xa - 1 + 2 s and B = A + 1 in two phases and completes the output planes A - 1
+    // and A.  Every input plane xa - 1 .. xb goes through a pair step (planes outside the tile are zeros; the taps of the
+    // end planes that reach outside [xa, xb) land in accumulators that are never stored: ~1 % of an x-chunk's MFMAs).
+    //   fp16 phase on the H slots | wait: the 8-bit halves have landed | barrier: every wave is done with the H slots |
+    //   LDS-DMA of the NEXT step's hi halves into the H slots | fp8 phase on the E slots | epilogue | counted wait: the
+    //   hi halves have landed | barrier: every wave is done with the E slots | LDS-DMA of the next step's 8-bit halves
+    // -- each LDS-DMA has a whole phase of matrix instructions to land in.
+    const int nsteps = (n + 3) >> 1;
+    auto step = [&](int s, f32x4 (&oA1)[2][2], f32x4 (&oA)[2][2], f32x4 (&oB)[2][2], f32x4 (&oB1)[2][2]) {
+        const int xA = xa - 1 + 2 * s;
+        pair_step(S0_{}, S1_{}, oA1, oA, oB, oB1);
+        SK_T(0)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        SK_T(1)
+        if (s + 1 < nsteps) {
+            issue_half(0, xA + 2, 0);
+            issue_half(1, xA + 3, 0);
+        }
+        SK_T(2)
+        pair_f8(oA1, oA, oB, oB1);
+        SK_T(0)
+        int ns = 0;
+        if (xA - 1 >= xa && xA - 1 < xb) ns += finish_plane(oA1, xA - 1);
+        if (xA >= xa && xA < xb) ns += finish_plane(oA, xA);
+        reset(oA1);
+        reset(oA);
+        SK_T(3)
+        if (ns == 8)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ns == 4)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SK_T(4)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        SK_T(1)
+        if (s + 1 < nsteps) {
+            issue_half(2, xA + 2, 1);
+            issue_half(3, xA + 3, 1);
+        }
+        SK_T(2)
+    };
+    SK_T(6)
+    for (int s = 0; s < nsteps; s += 2) {   // the accumulator pairs P / Q swap roles: two straight-line bodies
+        step(s, P0, P1, Q0, Q1);
+        if (s + 1 < nsteps) step(s + 1, Q0, Q1, P0, P1);
+    }
+    SK_T_DUMP(a, w, lane)
+
+    // ---- block-level reduction of the GroupNorm partials (conv3_m16_kernel's) --------------------------------
+    if (a.partial) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float s = gsum[i], ss = gsq[i];
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) {
+                s += __shfl_xor(s, m);
+                ss += __shfl_xor(ss, m);
+            }
+            if (c16 == 0) {
+                red[(w * 8 + 4 * i + g) * 2 + 0] = s;
+                red[(w * 8 + 4 * i + g) * 2 + 1] = ss;
+            }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            float tsum = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tsum += red[q * 16 + tid];
+            a.partial[((long long)b * nblk + block_in_batch) * 16 + tid] = tsum;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Gather GEMM for the layers with no spatial reuse of activations: 2x2x2 stride-2
 // down-sampling convs (8 taps, each input voxel feeds one output voxel) and 1x1x1
 // channel reducers.  B fragments come straight from global memory (16 B per lane),
@@ -2703,6 +3120,15 @@ int launch_conv3_px(const Conv3Args& a, const Plan& p, hipStream_t stream) {
     return SK_OK;
 }
 
+int launch_conv3_pxm(const Conv3Args& a, const Plan& p, hipStream_t stream) {
+    auto kern = conv3_pxm_kernel<kPxResidentHalfRows, kPxPositions>;
+    SK_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPxLds));
+    unsigned grid = (unsigned)(p.npatch * p.nxc * a.B);
+    kern<<<grid, 256, kPxLds, stream>>>(a);
+    SK_CHECK_LAUNCH();
+    return SK_OK;
+}
+
 template <int COUT, int XS, int RES = 0, bool SPLIT = false, bool MIX8 = false>
 int launch_conv3(const Conv3Args& a, const Plan& p, hipStream_t stream) {
     auto kern = conv3_kernel<COUT, XS, RES, SPLIT, MIX8>;
@@ -2936,7 +3362,14 @@ static int conv3d_impl(const sk_conv_src* srcs, int n_src, const void* weight, c
             a.w8_off = mix8_fp16_bytes(cout, cin);
             a.wpk_bytes = a.w8_off + mix8_fp8_bytes(cout, cin);
             a.w8_scale = 0x01010101 * (127 - w8_scale_exp);
-            if (cout == 32) return p.xs == 3 ? launch_conv3_m16<3, 0, true, 0, true>(a, p, stream) : launch_conv3_m16<4, 0, true, 0, true>(a, p, stream);
+            if (cout == 32) {
+                bool use_pxm = conv3_px_covers(p, oz, false);
+#ifdef SK_TUNING
+                if (getenv("SK_CONV_NO_PX")) use_pxm = false;   // A/B: conv3_m16_kernel's mix8 form
+#endif
+                if (use_pxm) return launch_conv3_pxm(a, p, stream);
+                return p.xs == 3 ? launch_conv3_m16<3, 0, true, 0, true>(a, p, stream) : launch_conv3_m16<4, 0, true, 0, true>(a, p, stream);
+            }
             if (cout == 64) return p.xs == 3 ? launch_conv3<64, 3, 0, true, true>(a, p, stream) : launch_conv3<64, 4, 0, true, true>(a, p, stream);
             return launch_conv3<128, 2, 0, true, true>(a, p, stream);
         }
