@@ -336,7 +336,9 @@ def _e4m3(t):
 
 @pytest.mark.parametrize("osp,ch", [((6, 9, 20), 32), ((12, 30, 20), 32), ((9, 21, 12), 32), ((6, 9, 10), 64), ((9, 14, 10), 64),
                                     ((7, 12, 5), 128), ((5, 9, 36), 64),
-                                    ((7, 10, 100), 32), ((7, 9, 64), 64), ((5, 6, 48), 128)])   # rectangle patches (z > 40; 64: XS = 3)
+                                    ((7, 10, 100), 32), ((7, 9, 64), 64), ((5, 6, 48), 128),   # rectangle patches (z > 40; 64: XS = 3)
+                                    ((7, 11, 20), 32), ((9, 13, 16), 32), ((5, 8, 18), 32), ((1, 7, 20), 32), ((2, 40, 20), 32),
+                                    ((37, 9, 20), 32)])   # conv3_pxm_kernel (z 16 .. 20): odd plane counts, one plane, ragged patches, two x-chunks
 def test_conv_mix8_fp8_phase_exact(U, osp, ch):
     """sk_conv3d_mix8, the block-scaled fp8 phase alone (hi = 0): with operands whose fp8 images are exact small integers
     the result 2^-(b+15) (conv(x8, 2^(b+11) w_lo) + conv(lo8, 2^b w)) is an integer multiple of 2^-(b+15) below 2^24 of
