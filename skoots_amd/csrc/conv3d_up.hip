@@ -323,6 +323,8 @@ static int upfold_impl(const void* skip, int c_skip, const void* up, int c_up, c
     const size_t f16_cg = (size_t)(a.ns * kSkipFrags + a.nu * kUpFrags) * 1024, f8_cg = (size_t)(a.ns * kSkipFrags8 + a.nu * kUpFrags8) * 2048;
     if (mix8) {
         SK_CHECK_ARG(split && w8_scale_exp >= 0 && w8_scale_exp < 64, "sk_conv3d_upfold_mix8: bad weight scale exponent %d", w8_scale_exp);
+        // a low-resolution plane holds both halves of its lines in one ring slot, in front of the slot's zero window
+        SK_CHECK_ARG(2 * p.nposl <= p.nposp, "sk_conv3d_upfold_mix8: geometry (%d,%d,%d) unsupported", ox, oy, oz);
         a.w8_off = (int)f16_cg;
         a.wpk_bytes = (int)(f16_cg + f8_cg);
         a.w8_scale = 0x01010101 * (127 - w8_scale_exp);
